@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- step!() calls/s and achieved HBM GB/s of the MI355X-native L-BFGS hot path.
+
+Workload (BASELINE.json metric / configs[2]): L-BFGS, m = 20, on the N-D chained Rosenbrock
+function, n = 10^7, fp64, one MI355X.  A "step" is one full step!(opt)
+(src/DZOptimization.jl:454-509): two-loop direction, backtracking trial(s) with the device
+objective, gradient, delta_gradient + rho, history push.  State is resident in HBM before
+the timed region starts; the only per-step host traffic is the 40-byte {f_new, changed}
+read-back the reference's host-side `f_new < f` test needs.
+
+N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`): one process per GPU, each
+rank owns an independent optimizer instance (north_star: "batched-problems mode shards
+independent optimizer instances across the GPUs ... RCCL only for the global convergence
+flag; single huge-n problems stay on one GPU").  There is no data-path collective; the
+convergence flag is all-reduced over RCCL every --poll steps.  scaling = "weak".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+
+
+# ------------------------------------------------------------------------------ inputs
+def pcg32_uniform(n, seed):
+    """Vectorised PCG32 XSH-RR stream with the reference's seeding (legacy/PCG.jl:7-22):
+    u_i = 2^-32 * extract(state_i), state_0 = advance(inc + seed)."""
+    mult = np.uint64(0x5851F42D4C957F2D)
+    inc = np.uint64(0x14057B7EF767814F)
+    block = 1 << 16
+    with np.errstate(over="ignore"):
+        # A_i, C_i with state_i = A_i * state_0 + C_i  (mod 2^64), i < block
+        A = np.empty(block + 1, np.uint64)
+        Cc = np.empty(block + 1, np.uint64)
+        A[0], Cc[0] = np.uint64(1), np.uint64(0)
+        a, c = 1, 0
+        M = (1 << 64) - 1
+        mi, ii = int(mult), int(inc)
+        for i in range(1, block + 1):
+            a = (a * mi) & M
+            c = (c * mi + ii) & M
+            A[i], Cc[i] = a, c
+        state0 = np.uint64(((ii + seed) * mi + ii) & M)
+        out = np.empty(n, np.float64)
+        pos = 0
+        while pos < n:
+            cnt = min(block, n - pos)
+            st = A[:cnt] * state0 + Cc[:cnt]
+            v = (((st >> np.uint64(18)) ^ st) >> np.uint64(27)).astype(np.uint32)
+            r = (st >> np.uint64(59)).astype(np.uint32)
+            x = (v >> r) | (v << ((np.uint32(32) - r) & np.uint32(31)))
+            out[pos:pos + cnt] = x.astype(np.float64) * 2.3283064365386962890625e-10
+            state0 = A[block] * state0 + Cc[block]
+            pos += cnt
+    return out
+
+
+def rosenbrock_chain_x0(n, seed=5):
+    """C3 start: -1.2 / 1.0 alternating plus 0.01*(u - 1/2)."""
+    u = pcg32_uniform(n, seed)
+    base = np.where(np.arange(n) % 2 == 0, -1.2, 1.0)
+    return base + 0.01 * (u - 0.5)
+
+
+# ------------------------------------------------------------------------------ helpers
+def _dist_setup(gpus):
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        if gpus != 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def _barrier(world):
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _kernel_bytes(name, n, k, esize):
+    """ALGORITHMIC bytes per launch (DESIGN.md section d)."""
+    if name == "lbfgs_gram_pass":
+        return (2 * k + 1) * n * esize           # each s_i, y_i once, g once
+    if name == "lbfgs_combine":
+        return (2 * k + 1) * n * esize           # each s_i, y_i once, d written (g re-read not counted)
+    if name == "lbfgs_chain_link":
+        return 2 * n * esize                     # (4k+2)n over 2k+1 launches, rounded per launch
+    if name == "lbfgs_trial":
+        return 4 * n * esize
+    if name == "lbfgs_delta_rho":
+        return 4 * n * esize
+    if name.startswith("objective_rosenbrock_chain"):
+        return n * esize
+    if name.startswith("gradient_rosenbrock_chain"):
+        return 2 * n * esize
+    if name == "axpby":
+        return 3 * n * esize
+    return None
+
+
+def cpu_baseline(n, m, warm, steps, threads):
+    """The oracle (C restatement of the reference's unfused op sequence) timed on host cores."""
+    from oracle import oracle as orc
+    orc.set_threads(threads)
+    try:
+        x0 = orc.rosenbrock_chain_x0(n)
+        opt = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0, 1.0, m)
+        for _ in range(warm):
+            opt.step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            opt.step()
+        dt = time.perf_counter() - t0
+        f = opt.current_objective_value
+        opt.close()
+    finally:
+        orc.set_threads(1)
+    return steps / dt, f
+
+
+# ------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--m", type=int, default=20)
+    ap.add_argument("--mode", choices=["gram", "chain"], default="gram")
+    ap.add_argument("--poll", type=int, default=10, help="all-reduce the convergence flag every POLL steps (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=None, help="n of the CPU sample (default: same n)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch  # first: loads the ROCm runtime that libdzo_hip.so then shares
+    world, rank, local = _dist_setup(args.gpus)
+    from dzo_loader import dzo
+    dzo.init(local)
+    info = dzo.device_info()
+
+    n, m, esize = args.n, args.m, 8
+    x0 = rosenbrock_chain_x0(n, seed=5 + rank)           # each rank optimises its own instance
+    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+    x_dev = dzo.DeviceArray.from_host(x0)
+    del x0
+    opt = dzo.LBFGSOptimizer(None, prob, None, x_dev, 1.0, m)
+    opt.set_two_loop_mode(dzo.TWOLOOP_GRAM if args.mode == "gram" else dzo.TWOLOOP_CHAIN)
+
+    # setup (untimed, not part of warmup): fill the (s, y) ring so that k = m in every timed step
+    for _ in range(m):
+        opt.step()
+    for _ in range(args.warmup):
+        opt.step()
+    f_start = opt.current_objective_value
+
+    if world > 1:
+        import torch.distributed as dist
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    dzo.profile_reset()
+    dzo.profile_enable(not args.no_kernel_events)
+    trials = 0
+    _barrier(world)
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        opt.step()
+        trials += opt.last_trials
+        if world > 1 and (s + 1) % args.poll == 0:
+            flag.fill_(1 if opt.is_stuck else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # RCCL: global "everyone converged" flag
+    dzo.synchronize()
+    _barrier(world)
+    elapsed = time.perf_counter() - t0
+    dzo.profile_enable(False)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        stuck = torch.tensor([1 if opt.is_stuck else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(stuck, op=dist.ReduceOp.MAX)
+        any_stuck = bool(stuck.item())
+    else:
+        any_stuck = opt.is_stuck
+
+    table = dzo.profile_table()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    k = opt.history_count
+    kernels = {}
+    for name, (launches, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+        avg_us = 1e3 * ms / launches
+        b = _kernel_bytes(name, n, k, esize)
+        kernels[name] = {"launches": launches, "avg_us": round(avg_us, 2),
+                         "algorithmic_GBps": None if b is None else round(b / (avg_us * 1e-6) / 1e9, 1)}
+    roofline = None
+    if kernels:
+        dom = next((nm for nm in kernels if nm in ("lbfgs_gram_pass", "lbfgs_combine", "lbfgs_chain_link")), None)
+        if dom:
+            ach = kernels[dom]["algorithmic_GBps"]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize),
+                        "avg_launch_us": kernels[dom]["avg_us"]}
+            tl = [kernels[x] for x in ("lbfgs_gram_pass", "lbfgs_gram_finish", "lbfgs_combine", "lbfgs_chain_head",
+                                       "lbfgs_chain_link") if x in kernels]
+            per_dir = {x: table[x][0] for x in table}
+            dir_calls = table.get("lbfgs_combine", table.get("lbfgs_chain_head", (1, 0)))[0]
+            two_loop_us = sum(1e3 * table[x][1] for x in ("lbfgs_gram_pass", "lbfgs_gram_finish", "lbfgs_combine",
+                                                            "lbfgs_chain_head", "lbfgs_chain_link") if x in table) / max(dir_calls, 1)
+            roofline["two_loop"] = {"algorithmic_bytes": (4 * k + 2) * n * esize, "avg_us": round(two_loop_us, 1),
+                                    "achieved": round((4 * k + 2) * n * esize / (two_loop_us * 1e-6) / 1e9, 1),
+                                    "frac": round((4 * k + 2) * n * esize / (two_loop_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    value = world * args.steps / elapsed
+    step_bytes = (4 * k + 10) * n * esize                     # one step ex-objective, 1 trial
+    out = {
+        "metric": "step!() calls/sec and achieved HBM GB/s, L-BFGS n=10^7 m=20 fp64",
+        "value": round(value, 3), "unit": "step!() calls/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])",
+                   "n": n, "m": m, "history_full": k == m, "two_loop": args.mode,
+                   "parallelism": "1 optimizer instance per GPU, RCCL all-reduce of the convergence flag only"
+                   if world > 1 else "single GPU",
+                   "objective_evals_per_step": round(trials / args.steps, 3), "any_stuck": any_stuck,
+                   "f_start": f_start, "f_end": opt.current_objective_value, "device": info["name"]},
+        "step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 1),
+        "roofline": roofline, "kernels": kernels,
+    }
+    if not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 16)
+        cn = args.cpu_n or n
+        cwarm = m if cn == n else m
+        v, _ = cpu_baseline(cn, m, cwarm, args.cpu_steps, threads)
+        out["cpu_baseline"] = {"value": round(v * (1.0 if cn == n else cn / n), 4), "unit": "step!() calls/s",
+                               "cores": threads, "kind": "port",
+                               "sample": f"oracle/dzo_oracle.c (unfused op sequence of the reference, OpenMP x{threads}), "
+                                         f"n={cn}, m={m}: {cwarm} untimed steps to fill the history, then {args.cpu_steps} "
+                                         f"timed step!() calls" + ("" if cn == n else f"; rate scaled by {cn}/{n}")}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,706 @@
+"""dzoptimization.jl_amd -- MI355X-native BFGS / L-BFGS ``step!()`` (host-side mirror).
+
+This package is the Python twin of the Julia host module in ``julia/DZOptimizationAMD.jl``:
+both are thin bindings over the C ABI of ``include/dzo.h`` (``libdzo_hip.so``, hand-written
+HIP for gfx950).  It mirrors the reference's optimizer interface -- constructor argument
+order, public state fields, ``step!`` -> :func:`step_` / ``opt.step()``, and the termination
+flag under all three historical names (``is_stuck`` ≡ ``has_terminated`` ≡ ``has_converged``;
+SURVEY.md 1.2) -- so that the parity tests read like the reference's own usage
+(README.md:33-41, src/DZOptimization.jl:347-427).
+
+The directory name contains a dot, so it cannot be imported by name; use the loader::
+
+    from dzo_loader import dzo        # repo root
+    opt = dzo.LBFGSOptimizer(None, problem, None, x0, 1.0, 20)
+
+There is NO CPU fallback: importing works anywhere (so ABI/symbol tests can run without a
+GPU), but every compute entry point raises :class:`DzoError` unless ``libdzo_hip.so`` is
+built and a HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdzo_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+F32, F64 = 0, 1
+ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE = 0, 1, 2, 3
+TWOLOOP_CHAIN, TWOLOOP_GRAM = 0, 1
+STEP_NULL, STEP_GRADIENT_DESCENT, STEP_BFGS = 0, 1, 2
+
+_ERR = {1: "invalid argument", 2: "HIP runtime error", 3: "reference @assert", 4: "out of memory",
+        5: "unsupported", 6: "bad call sequence"}
+
+
+class DzoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dzo error {code} ({_ERR.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class AssertionFailed(DzoError, AssertionError):
+    """A reference ``@assert`` would have fired (Julia raises AssertionError)."""
+
+
+def build(force: bool = False) -> str:
+    """Compile ``libdzo_hip.so`` for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(INCLUDE_DIR, "dzo.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        jobs = str(min(8, os.cpu_count() or 1))
+        subprocess.check_call(["make", "-C", _HERE, "-j", jobs] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+_inited = False
+
+
+def lib() -> C.CDLL:
+    """Load the C-ABI library (no device needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DzoError(2, f"{LIB_PATH} is not built; run __graft_entry__.build() "
+                              "(there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = lib().dzo_last_error().decode(errors="replace")
+        raise (AssertionFailed if rc == 3 else DzoError)(rc, msg)
+
+
+def init(device: int = 0) -> None:
+    """Select the HIP device.  Fails loudly when there is none."""
+    global _inited
+    _check(lib().dzo_init(device))
+    _inited = True
+
+
+def _need_init():
+    if not _inited:
+        init(int(os.environ.get("LOCAL_RANK", "0")) if "DZO_DEVICE" not in os.environ
+             else int(os.environ["DZO_DEVICE"]))
+
+
+def device_info():
+    _need_init()
+    name = C.create_string_buffer(128)
+    cus, hbm = C.c_int32(), C.c_int64()
+    _check(lib().dzo_device_info(name, 128, C.byref(cus), C.byref(hbm)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+
+def synchronize():
+    _check(lib().dzo_synchronize())
+
+
+# ------------------------------------------------------------------------------ ABI table
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+CONSTRAINT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p)
+GRADIENT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+_P = C.POINTER
+
+# name -> argtypes; every function returns int32 except dzo_last_error / dzo_version
+ABI = {
+    "dzo_init": [_i32], "dzo_shutdown": [], "dzo_device_info": [C.c_char_p, _i32, _P(_i32), _P(_i64)],
+    "dzo_synchronize": [],
+    "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_profile_count": [_P(_i32)],
+    "dzo_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_dbl)],
+    "dzo_malloc": [_P(_vp), _i64], "dzo_free": [_vp], "dzo_memcpy_h2d": [_vp, _vp, _i64],
+    "dzo_memcpy_d2h": [_vp, _vp, _i64], "dzo_memcpy_d2d": [_vp, _vp, _i64],
+    "dzo_axpy": [_i64, _i32, _dbl, _vp, _vp], "dzo_axpby": [_i64, _i32, _dbl, _vp, _dbl, _vp],
+    "dzo_scal": [_i64, _i32, _dbl, _vp], "dzo_copy": [_i64, _i32, _vp, _vp],
+    "dzo_fill": [_i64, _i32, _dbl, _vp], "dzo_dot": [_i64, _i32, _vp, _vp, _P(_dbl)],
+    "dzo_nrm2": [_i64, _i32, _vp, _P(_dbl)], "dzo_isequal": [_i64, _i32, _vp, _vp, _P(_i32)],
+    "dzo_trial_point": [_i64, _i32, _vp, _dbl, _vp, _vp],
+    "dzo_problem_create": [_i32, _i64, _i32, _vp, _vp, _dbl, _P(_vp)], "dzo_problem_destroy": [_vp],
+    "dzo_problem_eval": [_vp, _vp, _P(_dbl)], "dzo_problem_grad": [_vp, _vp, _vp],
+    "dzo_lbfgs_create": [_i64, _i32, _i32, _vp, _vp, _dbl, _dbl, _P(_vp)],
+    "dzo_lbfgs_create_callbacks": [CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp, _i64, _i32, _i32, _vp,
+                                   _dbl, _P(_vp)],
+    "dzo_lbfgs_create_problem": [_vp, _i32, _vp, _dbl, _P(_vp)], "dzo_lbfgs_destroy": [_vp],
+    "dzo_lbfgs_set_callbacks": [_vp, CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp],
+    "dzo_lbfgs_set_problem": [_vp, _vp], "dzo_lbfgs_set_two_loop_mode": [_vp, _i32],
+    "dzo_lbfgs_set_max_halvings": [_vp, _i64], "dzo_lbfgs_step": [_vp], "dzo_lbfgs_direction": [_vp],
+    "dzo_lbfgs_begin_search": [_vp], "dzo_lbfgs_trial": [_vp, _dbl, _P(_i32)],
+    "dzo_lbfgs_accept": [_vp, _dbl], "dzo_lbfgs_reject": [_vp], "dzo_lbfgs_pre_gradient": [_vp],
+    "dzo_lbfgs_post_gradient": [_vp], "dzo_lbfgs_get_i": [_vp, _i32, _P(_i64)],
+    "dzo_lbfgs_get_s": [_vp, _i32, _P(_dbl)], "dzo_lbfgs_set_s": [_vp, _i32, _dbl],
+    "dzo_lbfgs_set_stuck": [_vp, _i32], "dzo_lbfgs_get_ptr": [_vp, _i32, _i32, _P(_vp)],
+    "dzo_lbfgs_get_rho": [_vp, _P(_dbl), _i32, _P(_i32)],
+    "dzo_lbfgs_get_alpha": [_vp, _P(_dbl), _i32, _P(_i32)],
+    "dzo_lbfgs_set_history": [_vp, _i32, _vp, _vp, _P(_dbl), _i64], "dzo_lbfgs_stream": [_vp, _P(_vp)],
+    "dzo_line_search_eval": [CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp, _i64, _i32, _vp, _dbl, _vp, _dbl,
+                             _dbl, _i32, _vp, _vp, _P(_dbl), _P(_dbl), _P(_dbl)],
+    "dzo_adgd_create": [_i64, _i32, _vp, _vp, _dbl, _dbl, _P(_vp)],
+    "dzo_adgd_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_adgd_destroy": [_vp],
+    "dzo_adgd_set_callbacks": [_vp, CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp], "dzo_adgd_step": [_vp],
+    "dzo_adgd_get_i": [_vp, _i32, _P(_i64)], "dzo_adgd_get_s": [_vp, _i32, _P(_dbl)],
+    "dzo_adgd_get_ptr": [_vp, _i32, _P(_vp)],
+    "dzo_bfgs_create_callbacks": [OBJECTIVE_FN, GRADIENT_FN, CONSTRAINT_FN, _vp, _i64, _i32, _vp, _dbl,
+                                  _P(_vp)],
+    "dzo_bfgs_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_bfgs_destroy": [_vp], "dzo_bfgs_step": [_vp],
+    "dzo_bfgs_update": [_i64, _i32, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
+    "dzo_symv": [_i64, _i32, _vp, _vp, _vp],
+    "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32],
+    "dzo_bfgs_get_i": [_vp, _i32, _P(_i64)], "dzo_bfgs_get_s": [_vp, _i32, _P(_dbl)],
+    "dzo_bfgs_get_ptr": [_vp, _i32, _P(_vp)],
+    "dzo_bfgs_batch_create": [_i32, _i64, _i64, _i32, _vp, _dbl, _P(_vp)], "dzo_bfgs_batch_destroy": [_vp],
+    "dzo_bfgs_batch_step": [_vp, _i32, _P(_i32)], "dzo_bfgs_batch_get_ptr": [_vp, _i32, _P(_vp)],
+    "dzo_bfgs_batch_count_active": [_vp, _P(_i64)],
+}
+
+
+def _declare(L):
+    for name, args in ABI.items():
+        fn = getattr(L, name)           # AttributeError here = symbol missing from the library
+        fn.argtypes = args
+        fn.restype = C.c_int32
+    L.dzo_last_error.restype = C.c_char_p
+    L.dzo_last_error.argtypes = []
+    L.dzo_version.restype = C.c_int32
+    L.dzo_version.argtypes = []
+
+
+def _dt(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return F64
+    if dtype == np.float32:
+        return F32
+    raise TypeError(f"unsupported element type {dtype}")
+
+
+def _np(dt: int):
+    return np.float64 if dt == F64 else np.float32
+
+
+# ------------------------------------------------------------------------------ device arrays
+class DeviceArray:
+    """Dense device vector/matrix (what ``A <: AbstractArray{T}`` is for the reference).
+
+    Owns HBM allocated through the C ABI, or wraps a raw device pointer (``owner=False``) such
+    as a ``torch.Tensor.data_ptr()`` or an optimizer field."""
+
+    def __init__(self, shape, dtype=np.float64, ptr=None, owner=True):
+        _need_init()
+        self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = owner and ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            _check(lib().dzo_malloc(C.byref(p), max(self.nbytes, 16)))
+            ptr = p.value
+        self.ptr = int(ptr)
+
+    @classmethod
+    def from_host(cls, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = cls(a.shape, a.dtype)
+        d.upload(a)
+        return d
+
+    @classmethod
+    def zeros(cls, shape, dtype=np.float64):
+        d = cls(shape, dtype)
+        _check(lib().dzo_fill(d.size, _dt(dtype), 0.0, d.ptr))
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size == self.size
+        _check(lib().dzo_memcpy_h2d(self.ptr, a.ctypes.data, self.nbytes))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        _check(lib().dzo_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def copy(self):
+        d = DeviceArray(self.shape, self.dtype)
+        _check(lib().dzo_memcpy_d2d(d.ptr, self.ptr, self.nbytes))
+        return d
+
+    def view(self, offset_elems, shape):
+        return DeviceArray(shape, self.dtype, ptr=self.ptr + offset_elems * self.dtype.itemsize, owner=False)
+
+    def free(self):
+        if self._owner and self.ptr and _lib is not None:
+            lib().dzo_free(self.ptr)
+        self.ptr = 0
+        self._owner = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def _as_dev(a, dtype=None):
+    return a if isinstance(a, DeviceArray) else DeviceArray.from_host(a, dtype)
+
+
+# L1 primitives with the reference's call shapes (LinearAlgebra / Base)
+def axpy_(alpha, x, y):
+    _check(lib().dzo_axpy(x.size, _dt(x.dtype), alpha, x.ptr, y.ptr)); return y
+
+
+def axpby_(alpha, x, beta, y):
+    _check(lib().dzo_axpby(x.size, _dt(x.dtype), alpha, x.ptr, beta, y.ptr)); return y
+
+
+def rmul_(x, alpha):
+    _check(lib().dzo_scal(x.size, _dt(x.dtype), alpha, x.ptr)); return x
+
+
+def copy_(dst, src):
+    _check(lib().dzo_copy(src.size, _dt(src.dtype), src.ptr, dst.ptr)); return dst
+
+
+def fill_(x, value):
+    _check(lib().dzo_fill(x.size, _dt(x.dtype), value, x.ptr)); return x
+
+
+def dot(x, y):
+    r = C.c_double()
+    _check(lib().dzo_dot(x.size, _dt(x.dtype), x.ptr, y.ptr, C.byref(r))); return r.value
+
+
+def norm(x):
+    r = C.c_double()
+    _check(lib().dzo_nrm2(x.size, _dt(x.dtype), x.ptr, C.byref(r))); return r.value
+
+
+def isequal(a, b):
+    r = C.c_int32()
+    _check(lib().dzo_isequal(a.size, _dt(a.dtype), a.ptr, b.ptr, C.byref(r))); return bool(r.value)
+
+
+def trial_point_(dst, t, d, x):
+    _check(lib().dzo_trial_point(x.size, _dt(x.dtype), dst.ptr, t, d.ptr, x.ptr)); return dst
+
+
+# ------------------------------------------------------------------------------ profiling
+def profile_enable(on=True):
+    _check(lib().dzo_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    _check(lib().dzo_profile_reset())
+
+
+def profile_table():
+    """{kernel name: (launches, total_ms)} measured with HIP events on the launching stream."""
+    n = C.c_int32()
+    _check(lib().dzo_profile_count(C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        name = C.create_string_buffer(96)
+        launches, ms = C.c_int64(), C.c_double()
+        _check(lib().dzo_profile_get(i, name, 96, C.byref(launches), C.byref(ms)))
+        if launches.value:
+            out[name.value.decode()] = (launches.value, ms.value)
+    return out
+
+
+# ------------------------------------------------------------------------------ problems
+class Problem:
+    """Built-in device objective; callable like the reference's callbacks:
+    ``p(x)`` = objective_function(x), ``p.gradient_(g, x)`` = gradient_function!(g, x)."""
+
+    def __init__(self, kind, n, dtype=np.float64, A=None, c=None, lam=0.0):
+        _need_init()
+        self.kind, self.n, self.dtype = kind, int(n), np.dtype(dtype)
+        # device layout is column-major (legacy/DZOptimization.jl:746): C-order of A' == F-order of A
+        self.A = None if A is None else (A if isinstance(A, DeviceArray) else _as_dev(np.ascontiguousarray(np.asarray(A).T), dtype))
+        self.c = None if c is None else _as_dev(c, dtype)
+        h = C.c_void_p()
+        _check(lib().dzo_problem_create(kind, self.n, _dt(dtype), self.A.ptr if self.A else None,
+                                        self.c.ptr if self.c else None, lam, C.byref(h)))
+        self.h = h
+
+    def __call__(self, x):
+        f = C.c_double()
+        _check(lib().dzo_problem_eval(self.h, x.ptr, C.byref(f)))
+        return f.value
+
+    def gradient_(self, g, x):
+        _check(lib().dzo_problem_grad(self.h, g.ptr, x.ptr))
+        return g
+
+    def __del__(self):
+        try:
+            if self.h and _lib is not None:
+                lib().dzo_problem_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _wrap_callbacks(constraint, objective, gradient, n, dtype):
+    """Python callables taking DeviceArray views -> C function pointers."""
+    def mk(ptr):
+        return DeviceArray(n, dtype, ptr=ptr, owner=False)
+    cf = CONSTRAINT_FN(lambda ctx, x: int(bool(constraint(mk(x))))) if constraint else C.cast(None, CONSTRAINT_FN)
+    of = OBJECTIVE_FN(lambda ctx, x: float(objective(mk(x))))
+
+    def _g(ctx, g, x):
+        gradient(mk(g), mk(x))
+    gf = GRADIENT_FN(_g)
+    return cf, of, gf
+
+
+class _OptBase:
+    _prefix = ""
+    _ptr_idx = True
+
+    def _i(self, what):
+        v = C.c_int64()
+        _check(getattr(lib(), f"dzo_{self._prefix}_get_i")(self.h, what, C.byref(v)))
+        return v.value
+
+    def _s(self, what):
+        v = C.c_double()
+        _check(getattr(lib(), f"dzo_{self._prefix}_get_s")(self.h, what, C.byref(v)))
+        return v.value
+
+    def _p(self, what, idx=0, shape=None):
+        p = C.c_void_p()
+        fn = getattr(lib(), f"dzo_{self._prefix}_get_ptr")
+        _check(fn(self.h, what, idx, C.byref(p)) if self._ptr_idx else fn(self.h, what, C.byref(p)))
+        return DeviceArray(self.n if shape is None else shape, self.dtype, ptr=p.value, owner=False)
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            getattr(lib(), f"dzo_{self._prefix}_destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    iteration_count = property(lambda s: s._i(1))
+    current_objective_value = property(lambda s: s._s(0))
+    current_point = property(lambda s: s._p(0))
+    delta_point = property(lambda s: s._p(1))
+    current_gradient = property(lambda s: s._p(2))
+    delta_gradient = property(lambda s: s._p(3))
+
+
+class LBFGSOptimizer(_OptBase):
+    """``LBFGSOptimizer(constraint_function!, objective_function, gradient_function!,
+    initial_point, initial_step_length, history_length)`` (src/DZOptimization.jl:400-407), or
+    the full form with ``initial_objective_value`` and ``initial_gradient`` inserted
+    (:347-356).  ``objective_function`` may be a :class:`Problem` (then ``gradient_function!``
+    is ignored and may be ``None``).  The optimizer ALIASES ``initial_point`` (:393)."""
+
+    _prefix = "lbfgs"
+
+    def __init__(self, constraint_function_, objective_function, gradient_function_, initial_point, *rest):
+        _need_init()
+        if len(rest) == 2:
+            f0, g0 = None, None
+            initial_step_length, history_length = rest
+        elif len(rest) == 4:
+            f0, g0, initial_step_length, history_length = rest
+        else:
+            raise TypeError("LBFGSOptimizer(c, f, g!, x0, [f0, g0,] step, m)")
+        self.current_point_array = _as_dev(initial_point)
+        x = self.current_point_array
+        self.n, self.dtype = x.size, x.dtype
+        self.history_length = int(history_length)
+        self._keep = [constraint_function_, objective_function, gradient_function_, g0]
+        h = C.c_void_p()
+        if isinstance(objective_function, Problem) and constraint_function_ is None and g0 is None:
+            self.problem = objective_function
+            _check(lib().dzo_lbfgs_create_problem(self.problem.h, self.history_length, x.ptr,
+                                                  initial_step_length, C.byref(h)))
+        else:
+            if isinstance(objective_function, Problem):
+                p = objective_function
+                objective_function, gradient_function_ = p, p.gradient_
+            cbs = _wrap_callbacks(constraint_function_, objective_function, gradient_function_, self.n, self.dtype)
+            self._keep.append(cbs)
+            if g0 is None:
+                _check(lib().dzo_lbfgs_create_callbacks(cbs[0], cbs[1], cbs[2], None, self.n, self.history_length,
+                                                        _dt(self.dtype), x.ptr, initial_step_length, C.byref(h)))
+            else:
+                _check(lib().dzo_lbfgs_create(self.n, self.history_length, _dt(self.dtype), x.ptr, g0.ptr, f0,
+                                              initial_step_length, C.byref(h)))
+                _check(lib().dzo_lbfgs_set_callbacks(h, cbs[0], cbs[1], cbs[2], None))
+        self.h = h
+
+    def step(self):
+        """``step!(opt)`` (src/DZOptimization.jl:454-509)."""
+        _check(lib().dzo_lbfgs_step(self.h))
+        return self
+
+    is_stuck = property(lambda s: bool(s._i(0)))
+    has_terminated = is_stuck       # legacy/DZOptimization.jl:478
+    has_converged = is_stuck        # README.md:38
+    history_count = property(lambda s: s._i(4))
+    last_trials = property(lambda s: s._i(5))
+    delta_objective_value = property(lambda s: s._s(1))
+    step_direction = property(lambda s: s._p(4))
+
+    @property
+    def delta_point_history(self):
+        return [self._p(5, i) for i in range(self.history_count)]
+
+    @property
+    def delta_gradient_history(self):
+        return [self._p(6, i) for i in range(self.history_count)]
+
+    def _hist(self, fn):
+        buf = (C.c_double * 64)()
+        cnt = C.c_int32()
+        _check(fn(self.h, buf, 64, C.byref(cnt)))
+        return np.array(buf[: cnt.value])
+
+    rho_history = property(lambda s: s._hist(lib().dzo_lbfgs_get_rho))
+    alpha_history = property(lambda s: s._hist(lib().dzo_lbfgs_get_alpha))
+
+    # split entry points (include/dzo.h)
+    def set_two_loop_mode(self, mode):
+        _check(lib().dzo_lbfgs_set_two_loop_mode(self.h, mode))
+
+    def set_max_halvings(self, v):
+        _check(lib().dzo_lbfgs_set_max_halvings(self.h, v))
+
+    def compute_step_direction(self):
+        """``compute_lbfgs_step_direction!`` (:430-451)."""
+        _check(lib().dzo_lbfgs_direction(self.h))
+        return self.step_direction
+
+    def set_history(self, S, Y, rho=None, iteration_count=None):
+        S, Y = _as_dev(S, self.dtype), _as_dev(Y, self.dtype)
+        k = S.shape[0] if len(S.shape) == 2 else 0
+        rp = None if rho is None else (C.c_double * k)(*[float(r) for r in rho])
+        _check(lib().dzo_lbfgs_set_history(self.h, k, S.ptr, Y.ptr, rp, k if iteration_count is None else iteration_count))
+
+    def begin_search(self):
+        _check(lib().dzo_lbfgs_begin_search(self.h))
+
+    def trial(self, t):
+        ch = C.c_int32()
+        _check(lib().dzo_lbfgs_trial(self.h, t, C.byref(ch)))
+        return bool(ch.value)
+
+    def accept(self, f_new):
+        _check(lib().dzo_lbfgs_accept(self.h, f_new))
+
+    def reject(self):
+        _check(lib().dzo_lbfgs_reject(self.h))
+
+    def pre_gradient(self):
+        _check(lib().dzo_lbfgs_pre_gradient(self.h))
+
+    def post_gradient(self):
+        _check(lib().dzo_lbfgs_post_gradient(self.h))
+
+    def set_objective_value(self, f):
+        _check(lib().dzo_lbfgs_set_s(self.h, 0, f))
+
+
+class AdGDOptimizer(_OptBase):
+    """``AdGDOptimizer(constraint!, objective, gradient!, x0, initial_step_length)``
+    (src/DZOptimization.jl:245-251)."""
+
+    _prefix = "adgd"
+    _ptr_idx = False
+
+    def __init__(self, constraint_function_, objective_function, gradient_function_, initial_point,
+                 initial_step_length):
+        _need_init()
+        x = self.current_point_array = _as_dev(initial_point)
+        self.n, self.dtype = x.size, x.dtype
+        h = C.c_void_p()
+        self._keep = [constraint_function_, objective_function, gradient_function_]
+        if isinstance(objective_function, Problem) and constraint_function_ is None:
+            _check(lib().dzo_adgd_create_problem(objective_function.h, x.ptr, initial_step_length, C.byref(h)))
+        else:
+            if isinstance(objective_function, Problem):
+                p = objective_function
+                objective_function, gradient_function_ = p, p.gradient_
+            if constraint_function_ is not None and not constraint_function_(x):
+                raise AssertionFailed(3, "@assert constraint_function!(initial_point) (src/DZOptimization.jl:256-258)")
+            f0 = float(objective_function(x))
+            g0 = DeviceArray(self.n, self.dtype)
+            gradient_function_(g0, x)
+            cbs = _wrap_callbacks(constraint_function_, objective_function, gradient_function_, self.n, self.dtype)
+            self._keep += [cbs, g0]
+            _check(lib().dzo_adgd_create(self.n, _dt(self.dtype), x.ptr, g0.ptr, f0, initial_step_length, C.byref(h)))
+            _check(lib().dzo_adgd_set_callbacks(h, cbs[0], cbs[1], cbs[2], None))
+        self.h = h
+
+    def step(self):
+        _check(lib().dzo_adgd_step(self.h))
+        return self
+
+    is_stuck = property(lambda s: bool(s._i(0)))
+    delta_objective_value = property(lambda s: s._s(1))
+    current_step_size = property(lambda s: s._s(2))
+    previous_step_size = property(lambda s: s._s(3))
+
+
+class BFGSOptimizer(_OptBase):
+    """``BFGSOptimizer(objective_function, gradient_function!, [constraint_function!,]
+    initial_point, initial_step_length)`` (README.md:33-36; legacy/DZOptimization.jl:753-766).
+    COPIES ``initial_point`` (:769)."""
+
+    _prefix = "bfgs"
+    _ptr_idx = False
+
+    def __init__(self, objective_function, gradient_function_, *rest):
+        _need_init()
+        if len(rest) == 2:
+            constraint_function_, (initial_point, initial_step_length) = None, rest
+        elif len(rest) == 3:
+            constraint_function_, initial_point, initial_step_length = rest
+        else:
+            raise TypeError("BFGSOptimizer(f, g!, [c!,] x0, step)")
+        x0 = _as_dev(initial_point)
+        self.n, self.dtype = x0.size, x0.dtype
+        self._keep = [objective_function, gradient_function_, constraint_function_, x0]
+        h = C.c_void_p()
+        if isinstance(objective_function, Problem) and constraint_function_ is None:
+            _check(lib().dzo_bfgs_create_problem(objective_function.h, x0.ptr, initial_step_length, C.byref(h)))
+        else:
+            if isinstance(objective_function, Problem):
+                p = objective_function
+                objective_function, gradient_function_ = p, p.gradient_
+            cbs = _wrap_callbacks(constraint_function_, objective_function, gradient_function_, self.n, self.dtype)
+            self._keep.append(cbs)
+            _check(lib().dzo_bfgs_create_callbacks(cbs[1], cbs[2], cbs[0], None, self.n, _dt(self.dtype), x0.ptr,
+                                                   initial_step_length, C.byref(h)))
+        self.h = h
+
+    def step(self):
+        """``step!(opt)`` (legacy/DZOptimization.jl:891-994)."""
+        _check(lib().dzo_bfgs_step(self.h))
+        return self
+
+    has_terminated = property(lambda s: bool(s._i(0)))   # legacy :738
+    has_converged = has_terminated                       # README.md:38
+    is_stuck = has_terminated
+    last_step_type = property(lambda s: s._i(3))
+    objective_evaluations = property(lambda s: s._i(4))
+    last_step_length = property(lambda s: s._s(1))
+    next_step_direction = property(lambda s: s._p(4))
+
+    @property
+    def approximate_inverse_hessian(self):
+        """n x n; ``to_host()`` gives the row-major view of the column-major (symmetric) H."""
+        return self._p(5, shape=(self.n, self.n))
+
+    def line_search(self, use_gradient_direction, t0):
+        t, f = C.c_double(), C.c_double()
+        _check(lib().dzo_bfgs_line_search(self.h, int(use_gradient_direction), t0, C.byref(t), C.byref(f)))
+        return t.value, f.value
+
+    def set_max_increases(self, v):
+        _check(lib().dzo_bfgs_set_max_increases(self.h, v))
+
+
+def update_inverse_hessian_(H, step_length, d, dg, scratch, g=None, d_next=None):
+    """``update_inverse_hessian!`` (legacy/DZOptimization.jl:864-889) on device arrays, with
+    the optional fused next direction ``d_next = H_new * g`` (:958-960)."""
+    _check(lib().dzo_bfgs_update(d.size, _dt(d.dtype), H.ptr, step_length, d.ptr, dg.ptr, scratch.ptr,
+                                 g.ptr if g is not None else None, d_next.ptr if d_next is not None else None))
+    return H
+
+
+def symv_(out, H, v):
+    _check(lib().dzo_symv(v.size, _dt(v.dtype), H.ptr, v.ptr, out.ptr))
+    return out
+
+
+class BatchedBFGS:
+    """B independent ``BFGSOptimizer`` instances on one device (config 5)."""
+
+    def __init__(self, problem_kind, x0, initial_step_length):
+        _need_init()
+        x0 = _as_dev(x0)
+        self.batch, self.n = x0.shape
+        self.dtype = x0.dtype
+        self._x0 = x0
+        h = C.c_void_p()
+        _check(lib().dzo_bfgs_batch_create(problem_kind, self.batch, self.n, _dt(self.dtype), x0.ptr,
+                                           initial_step_length, C.byref(h)))
+        self.h = h
+
+    def step(self, steps=1, poll=True):
+        """Runs ``steps`` step! calls on every live instance; returns all_done if ``poll``."""
+        done = C.c_int32()
+        _check(lib().dzo_bfgs_batch_step(self.h, steps, C.byref(done) if poll else None))
+        return bool(done.value) if poll else None
+
+    def _p(self, what, shape, dtype=None):
+        p = C.c_void_p()
+        _check(lib().dzo_bfgs_batch_get_ptr(self.h, what, C.byref(p)))
+        return DeviceArray(shape, self.dtype if dtype is None else dtype, ptr=p.value, owner=False)
+
+    current_point = property(lambda s: s._p(0, (s.batch, s.n)))
+    current_gradient = property(lambda s: s._p(1, (s.batch, s.n)))
+    approximate_inverse_hessian = property(lambda s: s._p(2, (s.batch, s.n, s.n)))
+    current_objective_value = property(lambda s: s._p(3, (s.batch,), np.float64))
+    has_terminated = property(lambda s: s._p(4, (s.batch,), np.int32))
+    iteration_count = property(lambda s: s._p(5, (s.batch,), np.int64))
+    delta_point = property(lambda s: s._p(6, (s.batch, s.n)))
+    delta_gradient = property(lambda s: s._p(7, (s.batch, s.n)))
+    next_step_direction = property(lambda s: s._p(8, (s.batch, s.n)))
+    last_step_length = property(lambda s: s._p(9, (s.batch,), np.float64))
+    last_step_type = property(lambda s: s._p(10, (s.batch,), np.int32))
+
+    def count_active(self):
+        v = C.c_int64()
+        _check(lib().dzo_bfgs_batch_count_active(self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            lib().dzo_bfgs_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def step_(opt):
+    """``step!(opt)``: the reference's generic function (src/DZOptimization.jl:104)."""
+    return opt.step()
+
+
+__all__ = [
+    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "BatchedBFGS", "Problem", "DeviceArray", "step_",
+    "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_",
+    "update_inverse_hessian_", "symv_", "init", "build", "lib", "device_info", "synchronize",
+    "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",
+]

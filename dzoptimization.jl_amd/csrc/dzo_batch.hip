@@ -1,0 +1,525 @@
+// dzo_batch.hip -- batched dense BFGS (config 5, K11): B independent BFGSOptimizer instances,
+// one 256-thread workgroup per instance, the WHOLE step! (legacy/DZOptimization.jl:891-994) on
+// the device: both quadratic line searches, accept / reset / terminate, the inverse-Hessian
+// update and the next direction.  No host round trip per trial ("run multiple optimizers in
+// parallel", README.md:12).
+//
+// Per instance: vectors (x, g, d, ...) live in LDS for the duration of the launch; H (n x n,
+// column-major, 512 KiB at n = 256 fp64) streams from HBM / Infinity Cache.  A thread owns a
+// PAIR of rows (16-B loads, coalesced along each column) and walks the columns of one parity
+// (the two 128-thread halves of the workgroup take even / odd columns), so
+//     t_i      = sum_j H[i,j] * dg_j                         (the true gemv, no symmetry needed)
+//     H[i,j]  += delta*(d'_i d'_j) - (t_i d'_j + d'_i t_j)   (:882-884, reference order)
+//     dnext_i  = sum_j Hnew[i,j] * g_j                       (fused into the update pass)
+// need no cross-thread reduction; the two halves are combined through LDS in a fixed order.
+// Traffic per instance-step: 3*n^2 elements.
+//
+// The objective is the chained Rosenbrock function (n = 2 is exactly the README's 2-D
+// Rosenbrock); the search logic mirrors oracle/dzo_oracle_impl.h line for line.
+#include <cmath>
+
+#include "dzo_common.h"
+
+namespace dzo {
+
+constexpr int kHalf = kBlock / 2;
+
+struct BatchState {
+    int64_t batch, n;
+    void *x, *g, *dx, *dg, *d, *H;
+    double *f, *last_step_length;
+    int32_t *last_step_type, *has_terminated;
+    int64_t *iteration_count;
+};
+
+__device__ __forceinline__ double bsum(double v, double *red) {
+    v = wave_sum_all(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ bool bany(bool p, int *flag) {
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    if (__any(p) && (threadIdx.x & 63) == 0) *flag = 1;
+    __syncthreads();
+    const bool r = *flag != 0;
+    __syncthreads();
+    return r;
+}
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T v);
+template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
+template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return sqrtf(v); }
+template <typename T> __device__ __forceinline__ bool t_finite(T v) { return isfinite(v); }
+template <typename T> __device__ __forceinline__ T t_max();
+template <> __device__ __forceinline__ double t_max<double>() { return 1.7976931348623157e308; }
+template <> __device__ __forceinline__ float t_max<float>() { return 3.4028234663852886e38f; }
+
+// same elementwise expressions as dzo_problems.hip / the oracle
+template <typename T> __device__ __forceinline__ double b_rosen_term(T xi, T xn) {
+    T t1 = (T)1 - xi;
+    T t2 = dfma(-xi, xi, xn);
+    return (double)dfma((T)100 * t2, t2, t1 * t1);
+}
+template <typename T> __device__ __forceinline__ T b_rosen_grad(int i, int n, T xp, T xi, T xn) {
+    T gi = (T)0;
+    if (i + 1 < n) {
+        T t2 = dfma(-xi, xi, xn);
+        T t1 = (T)1 - xi;
+        gi = dfma((T)-400 * xi, t2, (T)-2 * t1);
+    }
+    if (i > 0) {
+        T t2p = dfma(-xp, xp, xi);
+        gi = dfma((T)200, t2p, gi);
+    }
+    return gi;
+}
+
+template <typename T> struct Inst {
+    int n;
+    T *x, *g, *d, *dg, *dx, *y, *yref, *tv;     // LDS vectors
+    double *red;                                // LDS [4]
+    int *flag;                                  // LDS
+    int evals;
+
+    __device__ T objective(const T *p) {
+        double acc = 0;
+        for (int i = threadIdx.x; i + 1 < n; i += kBlock) acc += b_rosen_term<T>(p[i], p[i + 1]);
+        evals += 1;
+        return (T)bsum(acc, red);
+    }
+    __device__ void gradient(T *out, const T *p) {
+        for (int i = threadIdx.x; i < n; i += kBlock)
+            out[i] = b_rosen_grad<T>(i, n, i > 0 ? p[i - 1] : (T)0, p[i], i + 1 < n ? p[i + 1] : (T)0);
+        __syncthreads();
+    }
+    __device__ T norm(const T *p) {
+        double acc = 0;
+        for (int i = threadIdx.x; i < n; i += kBlock) acc = __builtin_fma((double)p[i], (double)p[i], acc);
+        return t_sqrt<T>((T)bsum(acc, red));
+    }
+    // y = x - t*dir with the bracket flags (legacy :71-80)
+    __device__ void point(const T *dir, T t, bool *changed, bool *nonzero) {
+        bool ch = false, nz = false;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+            const T nw = dfma(-t, dir[i], x[i]);
+            y[i] = nw;
+            ch |= (x[i] != nw);
+            nz |= (dir[i] != (T)0);
+        }
+        __syncthreads();
+        if (changed) *changed = bany(ch, flag);
+        if (nonzero) *nonzero = bany(nz, flag);
+    }
+    __device__ T phi(const T *dir, T t) {
+        point(dir, t, nullptr, nullptr);
+        return objective(y);
+    }
+    __device__ bool same(const T *a, const T *b) {
+        bool df = false;
+        for (int i = threadIdx.x; i < n; i += kBlock) df |= !is_equal(a[i], b[i]);
+        return !bany(df, flag);
+    }
+    __device__ void copy(T *dst, const T *src) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+
+    // find_three_point_bracket (legacy :49-172) started at t0; see oracle bfgs_bracket
+    __device__ void bracket(const T *dir, T f0, T t0, T &x1, T &f1, T &x2, T &f2) {
+        x1 = 0; f1 = f0; x2 = 0; f2 = f0;
+        if (!t_finite(f0)) return;                               // :64-66
+        if (!(t0 > (T)0) || !t_finite(t0)) return;
+        bool changed, nonzero;
+        point(dir, t0, &changed, &nonzero);                      // :71-80
+        if (!nonzero) return;                                    // :83-85
+        T step = t0;
+        bool small = false;
+        while (!changed) {                                       // :91-101
+            step += step;
+            small = true;
+            if (!t_finite(step)) return;
+            point(dir, step, &changed, nullptr);
+        }
+        T fa = objective(y);                                     // :126
+        if (small && same(x, y)) return;                         // :119-121
+        if (fa <= f0) {                                          // :130
+            copy(yref, y);                                       // :136
+            for (;;) {                                           // :143-156
+                const T dbl = step + step;
+                const T fb = phi(dir, dbl);
+                if (!t_finite(fb) || fb > fa || same(y, yref)) { // :147-150 (max_increases = 0)
+                    x1 = step; f1 = fa; x2 = dbl; f2 = fb;
+                    return;
+                }
+                step = dbl;
+                fa = fb;
+                copy(yref, y);                                   // :155
+            }
+        } else {                                                 // :157-171
+            for (;;) {
+                const T hs = (T)0.5 * step;
+                const T fb = phi(dir, hs);
+                if (fb <= f0) { x1 = hs; f1 = fb; x2 = step; f2 = fa; return; }
+                if (hs == (T)0) return;
+                step = hs;
+                fa = fb;
+            }
+        }
+    }
+
+    // QuadraticLineSearch (legacy :191-216)
+    __device__ void search(const T *dir, T f0, T t0, T &tb, T &fbest) {
+        T x1, f1, x2, f2;
+        bracket(dir, f0, t0, x1, f1, x2, f2);                    // :195
+        T xb = 0, fb = f0;                                       // :196
+        if (f1 < fb) { xb = x1; fb = f1; }
+        if (f2 < fb) { xb = x2; fb = f2; }
+        const T d1 = f0 - f1, d2 = f2 - f1, sum = d1 + d2;       // :203-205
+        if (d1 >= (T)0 && d2 >= (T)0 && sum > (T)0) {            // :206
+            const T ratio = ((d1 + d1) + sum) / (sum + sum);     // :207-208
+            const T xq = ratio * x1;                             // :209
+            const T fq = phi(dir, xq);                           // :210
+            if (fq < fb) { xb = xq; fb = fq; }
+        }
+        tb = xb; fbest = fb;
+    }
+};
+
+// RP = row pairs per thread: n <= 256*RP, n even
+template <typename T, int RP>
+__global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int steps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = (int)st.n;
+    const int64_t b = blockIdx.x;
+    if (st.has_terminated[b]) return;
+
+    T *lds = reinterpret_cast<T *>(smem);
+    const int np = (n + 1) & ~1;
+    Inst<T> in;
+    in.n = n;
+    in.x = lds; in.g = lds + np; in.d = lds + 2 * np; in.dg = lds + 3 * np; in.dx = lds + 4 * np;
+    in.y = lds + 5 * np; in.yref = lds + 6 * np; in.tv = lds + 7 * np;
+    T *gold = lds + 8 * np;                       // previous gradient (also the GD direction)
+    double *part = reinterpret_cast<double *>(lds + 9 * np);   // [n] half-combine scratch
+    in.red = part + np;
+    in.flag = reinterpret_cast<int *>(in.red + 4);
+    in.evals = 0;
+
+    T *gx = (T *)st.x + b * n, *gg = (T *)st.g + b * n, *gd = (T *)st.d + b * n;
+    T *gdx = (T *)st.dx + b * n, *gdg = (T *)st.dg + b * n;
+    T *H = (T *)st.H + b * (int64_t)n * n;
+    for (int i = threadIdx.x; i < n; i += kBlock) { in.x[i] = gx[i]; in.g[i] = gg[i]; in.d[i] = gd[i]; in.dx[i] = gdx[i]; in.dg[i] = gdg[i]; }
+    __syncthreads();
+    T f = (T)st.f[b];
+    T last_len = (T)st.last_step_length[b];
+    int last_type = st.last_step_type[b];
+    int64_t iters = st.iteration_count[b];
+    bool terminated = false;
+
+    const int half = threadIdx.x / kHalf, lane_h = threadIdx.x % kHalf;
+
+    for (int s = 0; s < steps && !terminated; ++s) {
+        const T grad_norm = in.norm(in.g);                        // :921
+        T t_g, f_g, t_b, f_b;
+        in.search(in.g, f, last_len / grad_norm, t_g, f_g);       // :922-925
+        const T bfgs_norm = in.norm(in.d);                        // :928
+        in.search(in.d, f, last_len / bfgs_norm, t_b, f_b);       // :929-932
+        const bool take_bfgs = f_b < f && !(f_b > f_g);           // :934
+        const bool take_grad = !take_bfgs && f_g < f;             // :962
+        if (!take_bfgs && !take_grad) { terminated = true; break; }   // :989
+        const T tt = take_bfgs ? t_b : t_g;
+        const T *dir = take_bfgs ? in.d : in.g;
+        f = take_bfgs ? f_b : f_g;                                // :937 / :965
+        last_len = take_bfgs ? t_b * bfgs_norm : t_g * grad_norm; // :938 / :966
+        last_type = take_bfgs ? DZO_STEP_BFGS : DZO_STEP_GRADIENT_DESCENT;
+        iters += 1;
+        // move (:943-950 / :971-978): y = x_new, dx = x_new - x_old, then the new gradient
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+            const T xo = in.x[i];
+            const T xn = dfma(-tt, dir[i], xo);
+            in.y[i] = xn;
+            in.dx[i] = xn - xo;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock) { in.x[i] = in.y[i]; gold[i] = in.g[i]; }
+        __syncthreads();
+        in.gradient(in.g, in.x);
+        for (int i = threadIdx.x; i < n; i += kBlock) in.dg[i] = in.g[i] - gold[i];
+        __syncthreads();
+
+        if (take_bfgs) {
+            // ---- t = H*dg (:875): own row pairs, columns of this half's parity
+            double acc[RP][2];
+#pragma unroll
+            for (int r = 0; r < RP; ++r) { acc[r][0] = 0; acc[r][1] = 0; }
+#pragma unroll 4
+            for (int j = half; j < n; j += 2) {
+                const double vj = (double)in.dg[j];
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    const int row = 2 * (lane_h + kHalf * r);
+                    if (row < n) {
+                        T hv[2];
+                        if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(H + (int64_t)j * n + row); hv[0] = q.x; hv[1] = q.y; }
+                        else { const float2 q = *reinterpret_cast<const float2 *>(H + (int64_t)j * n + row); hv[0] = q.x; hv[1] = q.y; }
+                        acc[r][0] = __builtin_fma((double)hv[0], vj, acc[r][0]);
+                        acc[r][1] = __builtin_fma((double)hv[1], vj, acc[r][1]);
+                    }
+                }
+            }
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { part[row] = acc[r][0]; part[row + 1] = acc[r][1]; } }
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { in.tv[row] = (T)(acc[r][0] + part[row]); in.tv[row + 1] = (T)(acc[r][1] + part[row + 1]); } }
+            }
+            __syncthreads();
+            // ---- scalars (:873-876) with lambda = -t_b (:954)
+            double a = 0, c = 0;
+            for (int i = threadIdx.x; i < n; i += kBlock) {
+                a = __builtin_fma((double)in.d[i], (double)in.dg[i], a);
+                c = __builtin_fma((double)in.dg[i], (double)in.tv[i], c);
+            }
+            const T overlap = (T)bsum(a, in.red);                // :873
+            const T dgt = (T)bsum(c, in.red);
+            const T inv = (T)1 / overlap;
+            const T delta = (-t_b) * overlap + dgt;              // :876
+            for (int i = threadIdx.x; i < n; i += kBlock) in.d[i] = in.d[i] * inv;   // :874
+            __syncthreads();
+            // ---- rank-2 update (:878-886) fused with dnext = Hnew*g (:958-960)
+            T di[RP][2], ti[RP][2];
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                const int row = 2 * (lane_h + kHalf * r);
+                const bool ok = row < n;
+                di[r][0] = ok ? in.d[row] : (T)0; di[r][1] = ok ? in.d[row + 1] : (T)0;
+                ti[r][0] = ok ? in.tv[row] : (T)0; ti[r][1] = ok ? in.tv[row + 1] : (T)0;
+                acc[r][0] = 0; acc[r][1] = 0;
+            }
+#pragma unroll 4
+            for (int j = half; j < n; j += 2) {
+                const T sj = in.d[j], tj = in.tv[j];             // :879-880
+                const double gj = (double)in.g[j];
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    const int row = 2 * (lane_h + kHalf * r);
+                    if (row < n) {
+                        T *p = H + (int64_t)j * n + row;
+                        T hv[2];
+                        if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+                        else { const float2 q = *reinterpret_cast<const float2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            hv[q] = hv[q] + (delta * (di[r][q] * sj) - (ti[r][q] * sj + di[r][q] * tj));   // :882-884
+                            acc[r][q] = __builtin_fma((double)hv[q], gj, acc[r][q]);
+                        }
+                        if constexpr (sizeof(T) == 8) { double2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<double2 *>(p) = q; }
+                        else { float2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<float2 *>(p) = q; }
+                    }
+                }
+            }
+            __syncthreads();   // every read of the scaled d / t above is done before d is overwritten
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { part[row] = acc[r][0]; part[row + 1] = acc[r][1]; } }
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { in.d[row] = (T)(acc[r][0] + part[row]); in.d[row + 1] = (T)(acc[r][1] + part[row + 1]); } }
+            }
+            __syncthreads();
+        } else {
+            // :981-986  H = I, d = g
+            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += kBlock) H[e] = (e / n == e % n) ? (T)1 : (T)0;
+            for (int i = threadIdx.x; i < n; i += kBlock) in.d[i] = in.g[i];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kBlock) { gx[i] = in.x[i]; gg[i] = in.g[i]; gd[i] = in.d[i]; gdx[i] = in.dx[i]; gdg[i] = in.dg[i]; }
+    if (threadIdx.x == 0) {
+        st.f[b] = (double)f;
+        st.last_step_length[b] = (double)last_len;
+        st.last_step_type[b] = last_type;
+        st.iteration_count[b] = iters;
+        st.has_terminated[b] = terminated ? 1 : 0;
+    }
+}
+
+// constructor per instance (:762-810): f0, g0, H0 = I, d0 = g
+template <typename T>
+__global__ __launch_bounds__(kBlock) void batch_init_kernel(BatchState st, double initial_step_length) {
+    __shared__ double red[4];
+    const int n = (int)st.n;
+    const int64_t b = blockIdx.x;
+    const T *x = (const T *)st.x + b * n;
+    T *g = (T *)st.g + b * n, *d = (T *)st.d + b * n, *dx = (T *)st.dx + b * n, *dg = (T *)st.dg + b * n;
+    T *H = (T *)st.H + b * (int64_t)n * n;
+    double acc = 0;
+    for (int i = threadIdx.x; i + 1 < n; i += kBlock) acc += b_rosen_term<T>(x[i], x[i + 1]);
+    const double f = (double)(T)bsum(acc, red);
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const T gi = b_rosen_grad<T>(i, n, i > 0 ? x[i - 1] : (T)0, x[i], i + 1 < n ? x[i + 1] : (T)0);
+        g[i] = gi; d[i] = gi; dx[i] = (T)0; dg[i] = (T)0;
+    }
+    for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += kBlock) H[e] = (e / n == e % n) ? (T)1 : (T)0;
+    if (threadIdx.x == 0) {
+        st.f[b] = f;
+        st.last_step_length[b] = (double)(T)initial_step_length;
+        st.last_step_type[b] = DZO_STEP_NULL;
+        st.iteration_count[b] = 0;
+        st.has_terminated[b] = (f != f) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void batch_count_active_kernel(const int32_t *__restrict__ term, int64_t batch,
+                                                                    unsigned long long *__restrict__ out) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < batch; i += (int64_t)gridDim.x * kBlock) c += term[i] ? 0 : 1;
+    if (c) atomicAdd(out, c);   // integer: order-free
+}
+
+}  // namespace dzo
+
+struct dzo_bfgs_batch_s {
+    dzo::BatchState st;
+    int32_t dtype = DZO_F64;
+    hipStream_t stream = nullptr;
+    unsigned long long *count_dev = nullptr;
+    unsigned long long *count_host = nullptr;
+    size_t lds_bytes = 0;
+    int rp = 1;
+};
+
+using namespace dzo;
+
+extern "C" {
+
+int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b) {
+    if (!b) return DZO_OK;
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    void *ptrs[] = {b->st.x, b->st.g, b->st.dx, b->st.dg, b->st.d, b->st.H, b->st.f, b->st.last_step_length,
+                    b->st.last_step_type, b->st.has_terminated, b->st.iteration_count, b->count_dev};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (b->count_host) (void)hipHostFree(b->count_host);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype, const void *x0_dev,
+                              double initial_step_length, dzo_bfgs_batch_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(out && x0_dev, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    DZO_REQUIRE(problem_kind == DZO_PROBLEM_ROSENBROCK_CHAIN || (problem_kind == DZO_PROBLEM_ROSENBROCK2D && n == 2),
+                DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective only");
+    DZO_REQUIRE(batch >= 1, DZO_ERR_INVALID, "batch must be >= 1");
+    DZO_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024, DZO_ERR_UNSUPPORTED,
+                "batched mode needs an even n in 2..1024 (got %lld)", (long long)n);
+    dzo_bfgs_batch_s *b = new dzo_bfgs_batch_s();
+    b->dtype = dtype;
+    b->st.batch = batch; b->st.n = n;
+    b->rp = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
+    const size_t es = dtype_size(dtype);
+    const size_t np = (size_t)((n + 1) & ~(int64_t)1);
+    b->lds_bytes = 9 * np * es + (np + 4) * sizeof(double) + 16;
+    const size_t vb = (size_t)batch * (size_t)n * es;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc(&b->st.x, vb); alloc(&b->st.g, vb); alloc(&b->st.dx, vb); alloc(&b->st.dg, vb); alloc(&b->st.d, vb);
+    alloc(&b->st.H, vb * (size_t)n);
+    alloc((void **)&b->st.f, batch * sizeof(double)); alloc((void **)&b->st.last_step_length, batch * sizeof(double));
+    alloc((void **)&b->st.last_step_type, batch * sizeof(int32_t)); alloc((void **)&b->st.has_terminated, batch * sizeof(int32_t));
+    alloc((void **)&b->st.iteration_count, batch * sizeof(int64_t)); alloc((void **)&b->count_dev, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        dzo_bfgs_batch_destroy(b);
+        set_error("out of device memory for %lld instances of %lld x %lld", (long long)batch, (long long)n, (long long)n);
+        return DZO_ERR_NOMEM;
+    }
+    DZO_HIP(hipHostMalloc((void **)&b->count_host, sizeof(unsigned long long), hipHostMallocDefault));
+    DZO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    DZO_HIP(hipMemcpy(b->st.x, x0_dev, vb, hipMemcpyDeviceToDevice));        // :769 copy
+    if (b->lds_bytes > 48 * 1024) {
+        // gfx950 has 160 KiB of LDS per CU; dynamic requests above the default need the attribute
+        const void *fn = nullptr;
+        if (dtype == DZO_F64) fn = b->rp == 1 ? (const void *)batch_step_kernel<double, 1> : b->rp == 2 ? (const void *)batch_step_kernel<double, 2> : (const void *)batch_step_kernel<double, 4>;
+        else fn = b->rp == 1 ? (const void *)batch_step_kernel<float, 1> : b->rp == 2 ? (const void *)batch_step_kernel<float, 2> : (const void *)batch_step_kernel<float, 4>;
+        DZO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    }
+    {
+        DZO_TIMED("bfgs_batch_init", b->stream);
+        DZO_DISPATCH(dtype, hipLaunchKernelGGL(batch_init_kernel<T>, dim3((unsigned)batch), dim3(kBlock), 0, b->stream, b->st, initial_step_length));
+    }
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(b->stream));
+    *out = b;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_batch_count_active(dzo_bfgs_batch_t b, int64_t *active) {
+    DZO_REQUIRE(b && active, DZO_ERR_INVALID, "null argument");
+    DZO_HIP(hipMemsetAsync(b->count_dev, 0, sizeof(unsigned long long), b->stream));
+    int grid = (int)((b->st.batch + kBlock - 1) / kBlock);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(batch_count_active_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->st.has_terminated, b->st.batch, b->count_dev);
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipMemcpyAsync(b->count_host, b->count_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    DZO_HIP(hipStreamSynchronize(b->stream));
+    *active = (int64_t)*b->count_host;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done) {
+    DZO_REQUIRE(b, DZO_ERR_INVALID, "null batch");
+    DZO_REQUIRE(steps >= 0, DZO_ERR_INVALID, "negative step count");
+    if (steps > 0) {
+        DZO_TIMED("bfgs_batch_step", b->stream);
+        const dim3 grid((unsigned)b->st.batch), block(kBlock);
+#define L(TT, R) hipLaunchKernelGGL((batch_step_kernel<TT, R>), grid, block, b->lds_bytes, b->stream, b->st, (int)steps)
+        if (b->dtype == DZO_F64) { if (b->rp == 1) L(double, 1); else if (b->rp == 2) L(double, 2); else L(double, 4); }
+        else { if (b->rp == 1) L(float, 1); else if (b->rp == 2) L(float, 2); else L(float, 4); }
+#undef L
+    }
+    DZO_HIP(hipGetLastError());
+    if (all_done) {
+        int64_t active = 0;
+        DZO_TRY(dzo_bfgs_batch_count_active(b, &active));
+        *all_done = active == 0 ? 1 : 0;
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev) {
+    DZO_REQUIRE(b && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DZO_HIP(hipStreamSynchronize(b->stream));
+    switch (what) {
+    case 0: *ptr_dev = b->st.x; break;
+    case 1: *ptr_dev = b->st.g; break;
+    case 2: *ptr_dev = b->st.H; break;
+    case 3: *ptr_dev = b->st.f; break;
+    case 4: *ptr_dev = b->st.has_terminated; break;
+    case 5: *ptr_dev = b->st.iteration_count; break;
+    case 6: *ptr_dev = b->st.dx; break;
+    case 7: *ptr_dev = b->st.dg; break;
+    case 8: *ptr_dev = b->st.d; break;
+    case 9: *ptr_dev = b->st.last_step_length; break;
+    case 10: *ptr_dev = b->st.last_step_type; break;
+    default: set_error("dzo_bfgs_batch_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
+    }
+    return DZO_OK;
+}
+
+}  // extern "C"

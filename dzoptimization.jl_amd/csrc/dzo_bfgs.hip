@@ -1,0 +1,635 @@
+// dzo_bfgs.hip -- dense BFGSOptimizer + step! (legacy/DZOptimization.jl:733-994) for gfx950.
+//
+// H is n x n, column-major, full storage (:746).  The rank-2 update (:878-886) keeps H exactly
+// symmetric bit for bit (t_i*d_j + d_i*t_j is commutative in IEEE arithmetic), so H*v is
+// computed as per-column dot products t_j = H[:,j].v: coalesced along the column, one
+// workgroup per group of 4 columns, no cross-workgroup reduction, deterministic.
+//
+// update_inverse_hessian! + the following mul! (:953-960) run as three launches:
+//   A  symv       t = H*dg                              reads  n^2
+//   B  scalars    overlap = d.dg, d' = d/overlap, delta = lambda*overlap + dg.t   (one block)
+//   C  update     H[:,j] += delta*(d'_i d'_j) - (t_i d'_j + d'_i t_j)  AND  d_next_j = H+[:,j].g
+//                                                       reads n^2, writes n^2
+// = 3*n^2 elements, the algorithmic floor of SURVEY.md 8(d) (the reference's pass structure
+// moves 4*n^2).  The update expression is evaluated exactly as written at :882-884 (no fma
+// contraction), so H matches the oracle bit for bit given equal scalars.
+//
+// MFMA note: the update is a rank-2 contraction H += [d' t] * [delta*d'-t, -d']^T and maps
+// onto v_mfma_f64_16x16x4_f64 with K padded 2->4, but at 0.4 flop/byte the kernel is bound by
+// HBM, not by the 2 fma per element; the VALU form below also keeps the reference's rounding
+// order, which the MFMA accumulate order would not.  See DESIGN.md.
+#include <cmath>
+#include <utility>
+
+#include "dzo_optcore.h"
+
+namespace dzo {
+
+constexpr int kColsPerBlock = 4;
+
+// t_j = H[:,j] . v for a group of columns per block
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void symv_kernel(int64_t n, const T *__restrict__ H, const T *__restrict__ v,
+                                                      T *__restrict__ out) {
+    constexpr int N = VEC ? Vec16<T>::N : 1;
+    __shared__ double lds[kWaves];
+    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t j0 = grp * kColsPerBlock;
+        double acc[kColsPerBlock];
+#pragma unroll
+        for (int c = 0; c < kColsPerBlock; ++c) acc[c] = 0;
+        for (int64_t i = (int64_t)threadIdx.x * N; i < n; i += (int64_t)kBlock * N) {
+            T vv[N];
+            if constexpr (VEC) load16(v + i, vv); else vv[0] = v[i];
+#pragma unroll
+            for (int c = 0; c < kColsPerBlock; ++c) {
+                if (j0 + c < n) {
+                    T hv[N];
+                    if constexpr (VEC) load16(H + (j0 + c) * n + i, hv); else hv[0] = H[(j0 + c) * n + i];
+#pragma unroll
+                    for (int q = 0; q < N; ++q) acc[c] = __builtin_fma((double)hv[q], (double)vv[q], acc[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kColsPerBlock; ++c) {
+            const double r = block_sum(acc[c], lds);
+            if (threadIdx.x == 0 && j0 + c < n) out[j0 + c] = (T)r;
+        }
+    }
+}
+
+// one block: overlap = d.dg (:873); d *= inv(overlap) (:874); delta = lambda*overlap + dg.t (:876)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bfgs_scalars_kernel(int64_t n, T *__restrict__ d, const T *__restrict__ dg,
+                                                              const T *__restrict__ t, T lambda,
+                                                              double *__restrict__ scalars) {
+    __shared__ double lds[kWaves];
+    __shared__ double bc[2];
+    double a = 0, b = 0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        a = __builtin_fma((double)d[i], (double)dg[i], a);
+        b = __builtin_fma((double)dg[i], (double)t[i], b);
+    }
+    const double ra = block_sum(a, lds);
+    const double rb = block_sum(b, lds);
+    if (threadIdx.x == 0) {
+        const T overlap = (T)ra;
+        const T delta = lambda * overlap + (T)rb;
+        bc[0] = (double)((T)1 / overlap);
+        scalars[0] = (double)overlap;
+        scalars[1] = (double)delta;
+    }
+    __syncthreads();
+    const T inv = (T)bc[0];
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) d[i] = d[i] * inv;
+}
+
+// H[:,j] update (:878-886) fused with d_next_j = H_new[:,j] . g (:958-960)
+template <typename T, bool VEC, bool DIRECTION>
+__global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__restrict__ H, const T *__restrict__ dp,
+                                                             const T *__restrict__ t, const double *__restrict__ scalars,
+                                                             const T *__restrict__ g, T *__restrict__ d_next) {
+    constexpr int N = VEC ? Vec16<T>::N : 1;
+    __shared__ double lds[kWaves];
+    const T delta = (T)scalars[1];
+    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t j0 = grp * kColsPerBlock;
+        T sj[kColsPerBlock], tj[kColsPerBlock];
+        double acc[kColsPerBlock];
+#pragma unroll
+        for (int c = 0; c < kColsPerBlock; ++c) {
+            const int64_t j = j0 + c < n ? j0 + c : n - 1;
+            sj[c] = dp[j];                                   // :879
+            tj[c] = t[j];                                    // :880
+            acc[c] = 0;
+        }
+        for (int64_t i = (int64_t)threadIdx.x * N; i < n; i += (int64_t)kBlock * N) {
+            T di[N], ti[N], gi[N];
+            if constexpr (VEC) { load16(dp + i, di); load16(t + i, ti); if (DIRECTION) load16(g + i, gi); }
+            else { di[0] = dp[i]; ti[0] = t[i]; if (DIRECTION) gi[0] = g[i]; }
+#pragma unroll
+            for (int c = 0; c < kColsPerBlock; ++c) {
+                if (j0 + c < n) {
+                    T *col = H + (j0 + c) * n + i;
+                    T hv[N];
+                    if constexpr (VEC) load16(col, hv); else hv[0] = col[0];
+#pragma unroll
+                    for (int q = 0; q < N; ++q) {
+                        // :882-884, evaluated in the reference's order (no contraction)
+                        hv[q] = hv[q] + (delta * (di[q] * sj[c]) - (ti[q] * sj[c] + di[q] * tj[c]));
+                        if (DIRECTION) acc[c] = __builtin_fma((double)hv[q], (double)gi[q], acc[c]);
+                    }
+                    if constexpr (VEC) store16(col, hv); else col[0] = hv[0];
+                }
+            }
+        }
+        if (DIRECTION) {
+#pragma unroll
+            for (int c = 0; c < kColsPerBlock; ++c) {
+                const double r = block_sum(acc[c], lds);
+                if (threadIdx.x == 0 && j0 + c < n) d_next[j0 + c] = (T)r;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void identity_kernel(int64_t n, T *__restrict__ H) {
+    const int64_t total = n * n;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += nthreads)
+        H[e] = (e / n == e % n) ? (T)1 : (T)0;              // :712-720
+}
+
+// scratch = fma(-t, dir, x) with the two bracket flags (:71-80):
+//   flags[0] |= any(x != new)   ("point_changed"),  flags[1] |= any(dir != 0)  ("!step_is_zero")
+template <typename T>
+__global__ __launch_bounds__(kBlock) void phi_point_kernel(int64_t n, T *__restrict__ dst, T t, const T *__restrict__ dir,
+                                                           const T *__restrict__ x, int32_t *__restrict__ flags) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    bool changed = false, nonzero = false;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        const T xi = x[i], di = dir[i];
+        const T nw = dfma(-t, di, xi);
+        dst[i] = nw;
+        changed |= (xi != nw);
+        nonzero |= (di != (T)0);
+    }
+    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+    if (__any(nonzero) && (threadIdx.x & 63) == 0) atomicOr(flags + 1, 1);
+}
+
+// move (:943-945): dx = x_old, dg = g_old (un-negated backups), x = fma(-t, dir, x)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bfgs_move_kernel(int64_t n, T *__restrict__ x, const T *dir, const T *g,
+                                                           T t, T *__restrict__ dx, T *__restrict__ dg) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        const T xo = x[i], go = g[i], di = dir[i];
+        dx[i] = xo;
+        dg[i] = go;
+        x[i] = dfma(-t, di, xo);
+    }
+}
+
+static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T> void launch_symv(hipStream_t s, int64_t n, const T *H, const T *v, T *out) {
+    DZO_TIMED("bfgs_symv", s);
+    const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(v);
+    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    const int grid = (int)(groups < 65535 ? groups : 65535);
+    if (vec) hipLaunchKernelGGL((symv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out);
+    else hipLaunchKernelGGL((symv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out);
+}
+
+// update_inverse_hessian! (:864-889) + optional next direction; all scalars stay on device
+template <typename T>
+void launch_bfgs_update(hipStream_t s, int64_t n, T *H, T lambda, T *d, const T *dg, T *scratch, const T *g,
+                        T *d_next, double *scalars_dev) {
+    launch_symv<T>(s, n, H, dg, scratch);                                                 // :875
+    {
+        DZO_TIMED("bfgs_scalars", s);
+        hipLaunchKernelGGL(bfgs_scalars_kernel<T>, dim3(1), dim3(kBlock), 0, s, n, d, dg, (const T *)scratch, lambda,
+                           scalars_dev);                                                  // :873-876
+    }
+    {
+        DZO_TIMED("bfgs_update", s);
+        const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(d) && al16(scratch) && (!g || al16(g));
+        const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+        const int grid = (int)(groups < 65535 ? groups : 65535);
+        const bool dir = g != nullptr && d_next != nullptr;
+#define L(V, D) hipLaunchKernelGGL((bfgs_update_kernel<T, V, D>), dim3(grid), dim3(kBlock), 0, s, n, H, (const T *)d, (const T *)scratch, (const double *)scalars_dev, g, d_next)
+        if (vec) { if (dir) L(true, true); else L(true, false); }
+        else { if (dir) L(false, true); else L(false, false); }
+#undef L
+    }
+}
+
+}  // namespace dzo
+
+struct dzo_bfgs_s {
+    int64_t n = 0;
+    int32_t dtype = DZO_F64;
+    hipStream_t stream = nullptr;
+    dzo_objective_fn objective = nullptr;       // :734
+    dzo_gradient_fn gradient = nullptr;         // :735
+    dzo_constraint_fn constraint = nullptr;     // :736
+    void *cb_ctx = nullptr;
+    dzo_problem_s *problem = nullptr;
+    int64_t iteration_count = 0;                // :737
+    bool has_terminated = false;                // :738
+    void *x = nullptr;                          // :739 (copy of x0, :769)
+    double f = 0;                               // :740
+    void *g = nullptr, *dx = nullptr, *dg = nullptr;   // :741-743
+    double last_step_length = 0;                // :744
+    int32_t last_step_type = DZO_STEP_NULL;     // :745
+    void *H = nullptr;                          // :746
+    void *d = nullptr;                          // :747 next_step_direction = H*g (not negated)
+    void *d_alt = nullptr;                      // second buffer the fused update writes d_next to
+    void *scratch = nullptr;                    // :748
+    void *ref_point = nullptr;                  // LineSearchEvaluator.reference_point (:17)
+    int32_t max_increases = 0;                  // QuadraticLineSearch.max_increases (:181-188)
+    int64_t evals = 0;
+    double *ws = nullptr;                       // device: partials + scalars + flags
+    double *host = nullptr;                     // pinned
+    double *partials() const { return ws; }
+    double *scalars() const { return ws + dzo::kMaxPartialBlocks + 8; }       // [overlap, delta]
+    double *result() const { return ws + dzo::kMaxPartialBlocks + 16; }       // [f]
+    int32_t *flags() const { return reinterpret_cast<int32_t *>(ws + dzo::kMaxPartialBlocks + 24); }
+};
+
+namespace dzo {
+
+static int32_t bfgs_eval(dzo_bfgs_s *o, const void *point, double *f) {
+    if (o->objective) {
+        DZO_HIP(hipStreamSynchronize(o->stream));
+        *f = round_to_dtype(o->dtype, o->objective(o->cb_ctx, point));
+        return DZO_OK;
+    }
+    DZO_TRY(problem_eval_async(o->problem, o->stream, point, o->result()));
+    DZO_HIP(hipMemcpyAsync(o->host, o->result(), sizeof(double), hipMemcpyDeviceToHost, o->stream));
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    *f = round_to_dtype(o->dtype, o->host[0]);
+    return DZO_OK;
+}
+
+static int32_t bfgs_grad(dzo_bfgs_s *o) {
+    if (o->gradient) {
+        DZO_HIP(hipStreamSynchronize(o->stream));
+        o->gradient(o->cb_ctx, o->g, o->x);
+        return DZO_OK;
+    }
+    return problem_grad_async(o->problem, o->stream, o->g, o->x);
+}
+
+static int32_t bfgs_norm(dzo_bfgs_s *o, const void *v, double *out) {
+    double ss = 0;
+    DZO_TRY(dot_blocking(o->stream, o->n, o->dtype, v, v, o->partials(), o->host, &ss));
+    *out = o->dtype == DZO_F32 ? (double)sqrtf((float)ss) : sqrt(ss);
+    return DZO_OK;
+}
+
+// scratch = x - t*dir, returns the two bracket flags
+static int32_t bfgs_point(dzo_bfgs_s *o, const void *dir, double t, bool *changed, bool *nonzero) {
+    hipStream_t s = o->stream;
+    DZO_HIP(hipMemsetAsync(o->flags(), 0, 2 * sizeof(int32_t), s));
+    {
+        DZO_TIMED("bfgs_trial_point", s);
+        const int grid = stream_grid(o->n, 1);
+        DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(phi_point_kernel<T>, dim3(grid), dim3(kBlock), 0, s, o->n, (T *)o->scratch,
+                                                  (T)t, (const T *)dir, (const T *)o->x, o->flags()));
+    }
+    DZO_HIP(hipGetLastError());
+    if (changed || nonzero) {
+        int32_t *hf = reinterpret_cast<int32_t *>(o->host + 4);
+        DZO_HIP(hipMemcpyAsync(hf, o->flags(), 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        DZO_HIP(hipStreamSynchronize(s));
+        if (changed) *changed = hf[0] != 0;
+        if (nonzero) *nonzero = hf[1] != 0;
+    }
+    return DZO_OK;
+}
+
+// f(P(scratch)) for the point already in scratch (legacy :35-44)
+static int32_t bfgs_phi_at_scratch(dzo_bfgs_s *o, double *f, bool *feasible) {
+    *feasible = true;
+    if (o->constraint) {
+        DZO_HIP(hipStreamSynchronize(o->stream));
+        if (!o->constraint(o->cb_ctx, o->scratch)) {           // :36-42
+            *feasible = false;
+            *f = o->dtype == DZO_F32 ? 3.4028234663852886e38 : 1.7976931348623157e308;   // typemax(T)
+            return DZO_OK;
+        }
+    }
+    o->evals += 1;
+    return bfgs_eval(o, o->scratch, f);
+}
+
+static int32_t bfgs_phi(dzo_bfgs_s *o, const void *dir, double t, double *f) {
+    bool feasible;
+    DZO_TRY(bfgs_point(o, dir, t, nullptr, nullptr));
+    return bfgs_phi_at_scratch(o, f, &feasible);
+}
+
+static int32_t bfgs_scratch_equals(dzo_bfgs_s *o, const void *other, bool *equal) {
+    hipStream_t s = o->stream;
+    DZO_HIP(hipMemsetAsync(o->flags(), 0, sizeof(int32_t), s));
+    DZO_DISPATCH(o->dtype, launch_isequal<T>(s, o->n, (const T *)o->scratch, (const T *)other, o->flags()));
+    int32_t *hf = reinterpret_cast<int32_t *>(o->host + 4);
+    DZO_HIP(hipMemcpyAsync(hf, o->flags(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DZO_HIP(hipStreamSynchronize(s));
+    *equal = hf[0] == 0;
+    return DZO_OK;
+}
+
+static inline bool finite_t(double v) { return std::isfinite(v); }
+
+// find_three_point_bracket (legacy/DZOptimization.jl:49-172), started at step size t0.
+// Mirrors oracle/dzo_oracle_impl.h bfgs_bracket line for line.
+static int32_t bfgs_bracket(dzo_bfgs_s *o, const void *dir, double f0, double t0, double *x1, double *f1, double *x2,
+                            double *f2) {
+    const int32_t dt = o->dtype;
+    const size_t bytes = (size_t)o->n * dtype_size(dt);
+    *x1 = 0; *f1 = f0; *x2 = 0; *f2 = f0;
+    if (!finite_t(f0)) return DZO_OK;                            // :64-66
+    if (!(t0 > 0) || !finite_t(t0)) return DZO_OK;
+    bool changed = false, nonzero = false;
+    DZO_TRY(bfgs_point(o, dir, t0, &changed, &nonzero));         // :71-80
+    if (!nonzero) return DZO_OK;                                 // :83-85
+    double step = t0;
+    bool small = false;
+    while (!changed) {                                           // :91-101
+        step = round_to_dtype(dt, step + step);
+        small = true;
+        if (!finite_t(step)) return DZO_OK;
+        DZO_TRY(bfgs_point(o, dir, step, &changed, nullptr));
+    }
+    double fa;
+    bool feasible;
+    DZO_TRY(bfgs_phi_at_scratch(o, &fa, &feasible));             // :104,:126
+    if (small) {                                                 // :107-123
+        if (!feasible) return DZO_OK;
+        bool eq;
+        DZO_TRY(bfgs_scratch_equals(o, o->x, &eq));
+        if (eq) return DZO_OK;
+    }
+    if (fa <= f0) {                                              // :130
+        int32_t increases = 0;
+        DZO_HIP(hipMemcpyAsync(o->ref_point, o->scratch, bytes, hipMemcpyDeviceToDevice, o->stream));   // :136
+        for (;;) {                                               // :143-156
+            const double dbl = round_to_dtype(dt, step + step);
+            increases += 1;
+            double fb;
+            DZO_TRY(bfgs_phi(o, dir, dbl, &fb));
+            bool stop = (o->max_increases > 0 && increases >= o->max_increases) || !finite_t(fb) || fb > fa;
+            if (!stop) {
+                bool eq;
+                DZO_TRY(bfgs_scratch_equals(o, o->ref_point, &eq));  // :150
+                stop = eq;
+            }
+            if (stop) { *x1 = step; *f1 = fa; *x2 = dbl; *f2 = fb; return DZO_OK; }   // :151
+            step = dbl;
+            fa = fb;
+            DZO_HIP(hipMemcpyAsync(o->ref_point, o->scratch, bytes, hipMemcpyDeviceToDevice, o->stream));   // :155
+        }
+    } else {                                                     // :157-171
+        for (;;) {
+            const double hs = round_to_dtype(dt, 0.5 * step);
+            double fb;
+            DZO_TRY(bfgs_phi(o, dir, hs, &fb));
+            if (fb <= f0) { *x1 = hs; *f1 = fb; *x2 = step; *f2 = fa; return DZO_OK; }   // :166
+            if (hs == 0.0) return DZO_OK;
+            step = hs;
+            fa = fb;
+        }
+    }
+}
+
+// QuadraticLineSearch (legacy/DZOptimization.jl:191-216)
+static int32_t bfgs_quadratic_search(dzo_bfgs_s *o, const void *dir, double f0, double t0, double *t_best,
+                                     double *f_best) {
+    const int32_t dt = o->dtype;
+    double x1, f1, x2, f2;
+    DZO_TRY(bfgs_bracket(o, dir, f0, t0, &x1, &f1, &x2, &f2));   // :195
+    double xb = 0, fb = f0;                                      // :196
+    if (f1 < fb) { xb = x1; fb = f1; }                           // :197-199
+    if (f2 < fb) { xb = x2; fb = f2; }                           // :200-202
+    const double d1 = round_to_dtype(dt, f0 - f1), d2 = round_to_dtype(dt, f2 - f1);
+    const double sum = round_to_dtype(dt, d1 + d2);              // :203-205
+    if (d1 >= 0 && d2 >= 0 && sum > 0) {                         // :206
+        const double num = round_to_dtype(dt, round_to_dtype(dt, d1 + d1) + sum);
+        const double ratio = round_to_dtype(dt, num / round_to_dtype(dt, sum + sum));   // :207-208
+        const double xq = round_to_dtype(dt, ratio * x1);        // :209
+        double fq;
+        DZO_TRY(bfgs_phi(o, dir, xq, &fq));                      // :210
+        if (fq < fb) { xb = xq; fb = fq; }                       // :211-213
+    }
+    *t_best = xb; *f_best = fb;
+    return DZO_OK;
+}
+
+static int32_t bfgs_identity(dzo_bfgs_s *o) {
+    DZO_TIMED("bfgs_identity", o->stream);
+    const int grid = stream_grid(o->n * o->n, 4);
+    DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(identity_kernel<T>, dim3(grid), dim3(kBlock), 0, o->stream, o->n, (T *)o->H));
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+// :943-950 / :971-978
+static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir) {
+    hipStream_t s = o->stream;
+    {
+        DZO_TIMED("bfgs_move", s);
+        const int grid = stream_grid(o->n, 1);
+        DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(bfgs_move_kernel<T>, dim3(grid), dim3(kBlock), 0, s, o->n, (T *)o->x,
+                                                  (const T *)dir, (const T *)o->g, (T)t, (T *)o->dx, (T *)o->dg));
+    }
+    DZO_HIP(hipGetLastError());
+    if (o->constraint) {                                         // :946-947
+        DZO_HIP(hipStreamSynchronize(s));
+        DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT,
+                    "@assert constraint_success (legacy/DZOptimization.jl:947)");
+    }
+    DZO_TRY(bfgs_grad(o));                                       // :948
+    // :949-950  (-x_old) + x_new == x_new - x_old exactly
+    DZO_DISPATCH(o->dtype, launch_axpby<T>(s, o->n, (T)1, (const T *)o->x, (T)-1, (T *)o->dx));
+    DZO_DISPATCH(o->dtype, launch_axpby<T>(s, o->n, (T)1, (const T *)o->g, (T)-1, (T *)o->dg));
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+static int32_t bfgs_step(dzo_bfgs_s *o) {
+    if (o->has_terminated) return DZO_OK;                        // :893
+    const int32_t dt = o->dtype;
+    const size_t bytes = (size_t)o->n * dtype_size(dt);
+    const double step_length = o->last_step_length;              // :918
+    double grad_norm, bfgs_norm_v;
+    DZO_TRY(bfgs_norm(o, o->g, &grad_norm));                     // :921
+    double t_g, f_g, t_b, f_b;
+    DZO_TRY(bfgs_quadratic_search(o, o->g, o->f, round_to_dtype(dt, step_length / grad_norm), &t_g, &f_g));   // :922-925
+    DZO_TRY(bfgs_norm(o, o->d, &bfgs_norm_v));                   // :928
+    DZO_TRY(bfgs_quadratic_search(o, o->d, o->f, round_to_dtype(dt, step_length / bfgs_norm_v), &t_b, &f_b)); // :929-932
+    if (f_b < o->f && !(f_b > f_g)) {                            // :934
+        o->f = f_b;                                              // :937
+        o->last_step_length = round_to_dtype(dt, t_b * bfgs_norm_v);   // :938
+        o->last_step_type = DZO_STEP_BFGS;                       // :939
+        o->iteration_count += 1;                                 // :940
+        DZO_TRY(bfgs_move(o, t_b, o->d));                        // :943-950
+        // :953-960 update_inverse_hessian!(H, -t_b, d, dg, scratch) fused with d = H*g
+        DZO_DISPATCH(dt, launch_bfgs_update<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (T *)o->d, (const T *)o->dg,
+                                               (T *)o->scratch, (const T *)o->g, (T *)o->d_alt, o->scalars()));
+        DZO_HIP(hipGetLastError());
+        std::swap(o->d, o->d_alt);
+    } else if (f_g < o->f) {                                     // :962
+        o->f = f_g;                                              // :965
+        o->last_step_length = round_to_dtype(dt, t_g * grad_norm);   // :966
+        o->last_step_type = DZO_STEP_GRADIENT_DESCENT;           // :967
+        o->iteration_count += 1;                                 // :968
+        DZO_TRY(bfgs_move(o, t_g, o->g));                        // :971-978
+        DZO_TRY(bfgs_identity(o));                               // :981
+        DZO_HIP(hipMemcpyAsync(o->d, o->g, bytes, hipMemcpyDeviceToDevice, o->stream));   // :984-986
+    } else {
+        o->has_terminated = true;                                // :989
+    }
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    return DZO_OK;
+}
+
+static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double initial_step_length) {
+    const size_t es = dtype_size(o->dtype);
+    const size_t vbytes = (size_t)((o->n + 63) / 64 * 64) * es;
+    DZO_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+    void **vecs[] = {&o->x, &o->g, &o->dx, &o->dg, &o->d, &o->d_alt, &o->scratch, &o->ref_point};
+    for (void **v : vecs) {
+        hipError_t e = hipMalloc(v, vbytes);
+        if (e != hipSuccess) { set_error("out of device memory allocating BFGS vectors"); return DZO_ERR_NOMEM; }
+        DZO_HIP(hipMemset(*v, 0, vbytes));                      // :777-778 zero deltas
+    }
+    {
+        hipError_t e = hipMalloc(&o->H, (size_t)o->n * (size_t)o->n * es);
+        if (e != hipSuccess) {
+            set_error("out of device memory allocating the %lld x %lld inverse Hessian", (long long)o->n, (long long)o->n);
+            return DZO_ERR_NOMEM;
+        }
+    }
+    DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 32)));
+    DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 32)));
+    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocDefault));
+    DZO_HIP(hipMemcpy(o->x, x0_dev, (size_t)o->n * es, hipMemcpyDeviceToDevice));   // :769 copy
+    if (o->constraint)
+        DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT, "@assert constraint_success (legacy/DZOptimization.jl:770-771)");
+    DZO_TRY(bfgs_eval(o, o->x, &o->f));                          // :772
+    DZO_REQUIRE(!(o->f != o->f), DZO_ERR_ASSERT, "@assert !isnan(initial_objective_value) (legacy/DZOptimization.jl:773)");
+    DZO_TRY(bfgs_grad(o));                                       // :775-776
+    o->last_step_length = round_to_dtype(o->dtype, initial_step_length);   // :779
+    o->last_step_type = DZO_STEP_NULL;                           // :780
+    DZO_TRY(bfgs_identity(o));                                   // :781-783
+    DZO_HIP(hipMemcpyAsync(o->d, o->g, (size_t)o->n * es, hipMemcpyDeviceToDevice, o->stream));   // :784
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    return DZO_OK;
+}
+
+}  // namespace dzo
+
+using namespace dzo;
+
+extern "C" {
+
+int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
+    if (!o) return DZO_OK;
+    if (o->stream) (void)hipStreamSynchronize(o->stream);
+    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->H, o->ws};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (o->host) (void)hipHostFree(o->host);
+    if (o->stream) (void)hipStreamDestroy(o->stream);
+    delete o;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_create_callbacks(dzo_objective_fn objective, dzo_gradient_fn gradient, dzo_constraint_fn constraint,
+                                  void *cb_ctx, int64_t n, int32_t dtype, const void *x0_dev, double initial_step_length,
+                                  dzo_bfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(objective && gradient && x0_dev && out && n >= 1, DZO_ERR_INVALID, "bad argument");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    dzo_bfgs_s *o = new dzo_bfgs_s();
+    o->n = n; o->dtype = dtype; o->objective = objective; o->gradient = gradient; o->constraint = constraint;
+    o->cb_ctx = cb_ctx;
+    int32_t rc = bfgs_create_common(o, x0_dev, initial_step_length);
+    if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_create_problem(dzo_problem_t problem, const void *x0_dev, double initial_step_length, dzo_bfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(problem && x0_dev && out, DZO_ERR_INVALID, "null argument");
+    dzo_bfgs_s *o = new dzo_bfgs_s();
+    o->n = problem->n; o->dtype = problem->dtype; o->problem = problem;
+    int32_t rc = bfgs_create_common(o, x0_dev, initial_step_length);
+    if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_step(dzo_bfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    return bfgs_step(o);
+}
+
+int32_t dzo_bfgs_update(int64_t n, int32_t dtype, void *H_dev, double step_length, void *d_dev, const void *dg_dev,
+                        void *scratch_dev, const void *g_dev, void *d_next_dev) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(n >= 1 && H_dev && d_dev && dg_dev && scratch_dev, DZO_ERR_INVALID, "bad argument");
+    DZO_REQUIRE((g_dev == nullptr) == (d_next_dev == nullptr), DZO_ERR_INVALID, "g and d_next must be given together");
+    DZO_REQUIRE(d_next_dev != d_dev || !d_next_dev, DZO_ERR_INVALID, "d_next must not alias d");
+    hipStream_t s = ctx().stream;
+    DZO_DISPATCH(dtype, launch_bfgs_update<T>(s, n, (T *)H_dev, (T)step_length, (T *)d_dev, (const T *)dg_dev,
+                                              (T *)scratch_dev, (const T *)g_dev, (T *)d_next_dev, ctx().scratch + kMaxPartialBlocks));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(s));
+    return DZO_OK;
+}
+
+int32_t dzo_symv(int64_t n, int32_t dtype, const void *H_dev, const void *v_dev, void *out_dev) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(n >= 1 && H_dev && v_dev && out_dev, DZO_ERR_INVALID, "bad argument");
+    DZO_DISPATCH(dtype, launch_symv<T>(ctx().stream, n, (const T *)H_dev, (const T *)v_dev, (T *)out_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_line_search(dzo_bfgs_t o, int32_t use_gradient_direction, double t0, double *t_best, double *f_best) {
+    DZO_REQUIRE(o && t_best && f_best, DZO_ERR_INVALID, "null argument");
+    return bfgs_quadratic_search(o, use_gradient_direction ? o->g : o->d, o->f, t0, t_best, f_best);
+}
+
+int32_t dzo_bfgs_set_max_increases(dzo_bfgs_t o, int32_t max_increases) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    o->max_increases = max_increases;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_get_i(dzo_bfgs_t o, int32_t what, int64_t *value) {
+    DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
+    switch (what) {
+    case 0: *value = o->has_terminated ? 1 : 0; break;
+    case 1: *value = o->iteration_count; break;
+    case 2: *value = o->n; break;
+    case 3: *value = o->last_step_type; break;
+    case 4: *value = o->evals; break;
+    default: set_error("dzo_bfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_get_s(dzo_bfgs_t o, int32_t what, double *value) {
+    DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(what == 0 || what == 1, DZO_ERR_INVALID, "unknown field %d", what);
+    *value = what == 0 ? o->f : o->last_step_length;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_get_ptr(dzo_bfgs_t o, int32_t what, void **ptr_dev) {
+    DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    switch (what) {
+    case 0: *ptr_dev = o->x; break;
+    case 1: *ptr_dev = o->dx; break;
+    case 2: *ptr_dev = o->g; break;
+    case 3: *ptr_dev = o->dg; break;
+    case 4: *ptr_dev = o->d; break;
+    case 5: *ptr_dev = o->H; break;
+    case 6: *ptr_dev = o->scratch; break;
+    default: set_error("dzo_bfgs_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
+    }
+    return DZO_OK;
+}
+
+}  // extern "C"

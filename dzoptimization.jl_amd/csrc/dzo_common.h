@@ -1,0 +1,206 @@
+// dzo_common.h -- shared device helpers and host-side plumbing for libdzo_hip.so (gfx950).
+//
+// Design rules:
+//   * every hot path here is HBM-bound BLAS-1 style work: 16-byte-per-lane coalesced loads,
+//     wave64 shuffle reductions, LDS only for the 4-wave block combine;
+//   * reductions are deterministic: fixed grid, per-block partials in HBM, a fixed-order
+//     second stage.  No floating-point atomics anywhere;
+//   * accumulation is always in fp64, also for fp32 vectors (VALU is idle on these kernels);
+//   * elementwise arithmetic uses explicit fma so results are bit-identical to the oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dzo.h"
+
+namespace dzo {
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxPartialBlocks = 2048;  // upper bound on the grid of any reducing kernel
+constexpr int kMaxHistory = 64;      // recurrence kernel runs one lane per pair
+
+// ------------------------------------------------------------------------------ errors
+void set_error(const char *fmt, ...);
+int32_t hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define DZO_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return ::dzo::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define DZO_TRY(call)                        \
+    do {                                     \
+        int32_t rc__ = (call);               \
+        if (rc__ != DZO_OK) return rc__;     \
+    } while (0)
+
+#define DZO_REQUIRE(cond, code, ...)         \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::dzo::set_error(__VA_ARGS__);   \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------ context
+struct Context {
+    bool ready = false;
+    int device = -1;
+    int cus = 256;
+    int64_t hbm_bytes = 0;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;       // default stream for handle-less primitives
+    double *scratch = nullptr;          // device: partial sums for handle-less reductions
+    double *host_scalar = nullptr;      // pinned host: results of blocking reductions
+};
+Context &ctx();
+int32_t require_init();
+
+// streaming-kernel grid: enough blocks to fill 256 CUs x 8, grid-stride the rest
+inline int stream_grid(int64_t n, int elems_per_thread) {
+    int64_t per_block = (int64_t)kBlock * elems_per_thread;
+    int64_t blocks = (n + per_block - 1) / per_block;
+    int64_t cap = (int64_t)ctx().cus * 8;
+    if (cap > kMaxPartialBlocks) cap = kMaxPartialBlocks;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ------------------------------------------------------------------------------ profiling
+// HIP-event pairs recorded on the launching stream around each kernel (bench roofline leg).
+struct ProfileEntry {
+    std::string name;
+    int64_t launches = 0;
+    double total_ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+bool profiling_on();
+void profile_begin(const char *name, hipStream_t s, hipEvent_t *stop_out);
+void profile_end(hipEvent_t stop, hipStream_t s);
+
+struct ScopedKernelTimer {
+    hipEvent_t stop = nullptr;
+    hipStream_t s;
+    ScopedKernelTimer(const char *name, hipStream_t stream) : s(stream) {
+        if (profiling_on()) profile_begin(name, s, &stop);
+    }
+    ~ScopedKernelTimer() {
+        if (stop) profile_end(stop, s);
+    }
+};
+#define DZO_TIMED(name, stream) ::dzo::ScopedKernelTimer timer__(name, stream)
+
+// ------------------------------------------------------------------------------ device side
+template <typename T> struct Vec16;   // 16-byte vector of T
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+template <> struct Vec16<float>  { using type = float4;  static constexpr int N = 4; };
+
+template <typename T> __device__ __forceinline__ T dfma(T a, T b, T c);
+template <> __device__ __forceinline__ double dfma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float dfma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T> __device__ __forceinline__ void load16(const T *p, T (&v)[Vec16<T>::N]) {
+    using V = typename Vec16<T>::type;
+    V t = *reinterpret_cast<const V *>(p);
+    if constexpr (Vec16<T>::N == 2) { v[0] = t.x; v[1] = t.y; }
+    else { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+template <typename T> __device__ __forceinline__ void store16(T *p, const T (&v)[Vec16<T>::N]) {
+    using V = typename Vec16<T>::type;
+    V t;
+    if constexpr (Vec16<T>::N == 2) { t.x = v[0]; t.y = v[1]; }
+    else { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
+    *reinterpret_cast<V *>(p) = t;
+}
+
+// wave64 sum, result valid in lane 0 (fixed order -> deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+// wave64 sum, result in every lane
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block sum for kBlock threads; `lds` holds kWaves doubles.  Result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *lds) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) r += lds[w];
+    }
+    __syncthreads();
+    return r;
+}
+
+// Every thread of every block obtains the same sum of `count` per-block partials, read in
+// a fixed order (the second stage of the two-stage reductions).  `lds` holds kWaves doubles.
+__device__ __forceinline__ double reduce_partials_all(const double *__restrict__ partials,
+                                                      int count, double *lds) {
+    double v = 0;
+    for (int i = threadIdx.x; i < count; i += kBlock) v += partials[i];
+    v = wave_sum_all(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) r += lds[w];
+    __syncthreads();
+    return r;
+}
+
+// Base.isequal for floats: bitwise equal, except that every NaN equals every NaN.
+__device__ __forceinline__ bool is_equal(double a, double b) {
+    return (__double_as_longlong(a) == __double_as_longlong(b)) || (a != a && b != b);
+}
+__device__ __forceinline__ bool is_equal(float a, float b) {
+    return (__float_as_int(a) == __float_as_int(b)) || (a != a && b != b);
+}
+
+// host-side dtype dispatch
+#define DZO_DISPATCH(dtype, ...)                                   \
+    do {                                                           \
+        if ((dtype) == DZO_F64) { using T = double; __VA_ARGS__; } \
+        else if ((dtype) == DZO_F32) { using T = float; __VA_ARGS__; } \
+        else { ::dzo::set_error("bad dtype %d", (int)(dtype)); return DZO_ERR_INVALID; } \
+    } while (0)
+
+inline size_t dtype_size(int32_t dtype) { return dtype == DZO_F64 ? 8 : 4; }
+
+// ------------------------------------------------------------------------------ shared launchers
+// (defined in dzo_vec.hip; used by the optimizers)
+template <typename T> void launch_axpy(hipStream_t s, int64_t n, T a, const T *x, T *y);
+template <typename T> void launch_axpy_oop(hipStream_t s, int64_t n, T *dst, T a, const T *x, const T *y);
+template <typename T> void launch_axpby(hipStream_t s, int64_t n, T a, const T *x, T b, T *y);
+template <typename T> void launch_scal(hipStream_t s, int64_t n, T a, T *x);
+template <typename T> void launch_scal_oop(hipStream_t s, int64_t n, T *dst, T a, const T *x);
+template <typename T> void launch_fill(hipStream_t s, int64_t n, T a, T *x);
+// two-stage dot: writes the final sum to result_dev[0]; partials_dev needs kMaxPartialBlocks doubles
+template <typename T> void launch_dot(hipStream_t s, int64_t n, const T *x, const T *y,
+                                      double *partials_dev, double *result_dev);
+template <typename T> void launch_isequal(hipStream_t s, int64_t n, const T *a, const T *b, int32_t *differs_dev);
+
+// blocking scalar helpers on a stream: run dot and copy the result to the host
+int32_t dot_blocking(hipStream_t s, int64_t n, int32_t dtype, const void *x, const void *y,
+                     double *partials_dev, double *host_pinned, double *out);
+
+}  // namespace dzo

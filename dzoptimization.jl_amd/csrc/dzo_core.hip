@@ -1,0 +1,227 @@
+// dzo_core.hip -- library context, error reporting, device memory and kernel timing.
+#include <cstdarg>
+#include <map>
+
+#include "dzo_common.h"
+
+namespace dzo {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int32_t hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return DZO_ERR_HIP;
+}
+
+Context &ctx() {
+    static Context c;
+    return c;
+}
+
+int32_t require_init() {
+    if (!ctx().ready) {
+        set_error("dzo_init() has not been called (or no HIP device is available)");
+        return DZO_ERR_STATE;
+    }
+    return DZO_OK;
+}
+
+// ---------------------------------------------------------------------------- profiling
+static bool g_profile = false;
+static std::mutex g_profile_mu;
+static std::vector<ProfileEntry> g_entries;
+static std::map<std::string, int> g_index;
+static thread_local int g_current = -1;
+static thread_local hipEvent_t g_current_start = nullptr;
+
+bool profiling_on() { return g_profile; }
+
+void profile_begin(const char *name, hipStream_t s, hipEvent_t *stop_out) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    {
+        std::lock_guard<std::mutex> lk(g_profile_mu);
+        auto it = g_index.find(name);
+        if (it == g_index.end()) {
+            g_index[name] = (int)g_entries.size();
+            g_entries.emplace_back();
+            g_entries.back().name = name;
+            g_current = (int)g_entries.size() - 1;
+        } else {
+            g_current = it->second;
+        }
+    }
+    g_current_start = a;
+    (void)hipEventRecord(a, s);
+    *stop_out = b;
+}
+
+void profile_end(hipEvent_t stop, hipStream_t s) {
+    (void)hipEventRecord(stop, s);
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    if (g_current >= 0) g_entries[g_current].pending.emplace_back(g_current_start, stop);
+}
+
+static void profile_drain() {
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    for (auto &e : g_entries) {
+        for (auto &p : e.pending) {
+            (void)hipEventSynchronize(p.second);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                e.total_ms += ms;
+                e.launches += 1;
+            }
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        e.pending.clear();
+    }
+}
+
+}  // namespace dzo
+
+using namespace dzo;
+
+extern "C" {
+
+int32_t dzo_version(void) { return DZO_VERSION; }
+
+const char *dzo_last_error(void) { return g_error; }
+
+int32_t dzo_init(int32_t device) {
+    Context &c = ctx();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (hipGetDeviceCount: %s); this library has no CPU path",
+                  hipGetErrorString(e));
+        return DZO_ERR_HIP;
+    }
+    DZO_REQUIRE(device >= 0 && device < count, DZO_ERR_INVALID, "device %d out of range [0,%d)",
+                device, count);
+    DZO_HIP(hipSetDevice(device));
+    if (c.ready && c.device == device) return DZO_OK;
+    hipDeviceProp_t prop;
+    DZO_HIP(hipGetDeviceProperties(&prop, device));
+    c.device = device;
+    c.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c.hbm_bytes = (int64_t)prop.totalGlobalMem;
+    snprintf(c.name, sizeof(c.name), "%s (%s)", prop.name, prop.gcnArchName);
+    DZO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    DZO_HIP(hipMalloc((void **)&c.scratch, sizeof(double) * (kMaxPartialBlocks + 8)));
+    DZO_HIP(hipHostMalloc((void **)&c.host_scalar, sizeof(double) * 8, hipHostMallocDefault));
+    c.ready = true;
+    return DZO_OK;
+}
+
+int32_t dzo_shutdown(void) {
+    Context &c = ctx();
+    if (!c.ready) return DZO_OK;
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipFree(c.scratch);
+    (void)hipHostFree(c.host_scalar);
+    (void)hipStreamDestroy(c.stream);
+    c = Context();
+    return DZO_OK;
+}
+
+int32_t dzo_device_info(char *name, int32_t name_len, int32_t *compute_units, int64_t *hbm_bytes) {
+    DZO_TRY(require_init());
+    if (name && name_len > 0) {
+        strncpy(name, ctx().name, (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = ctx().cus;
+    if (hbm_bytes) *hbm_bytes = ctx().hbm_bytes;
+    return DZO_OK;
+}
+
+int32_t dzo_synchronize(void) {
+    DZO_TRY(require_init());
+    DZO_HIP(hipDeviceSynchronize());
+    return DZO_OK;
+}
+
+int32_t dzo_profile_enable(int32_t on) {
+    g_profile = on != 0;
+    return DZO_OK;
+}
+
+int32_t dzo_profile_reset(void) {
+    profile_drain();
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    for (auto &e : g_entries) {
+        e.launches = 0;
+        e.total_ms = 0;
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_profile_count(int32_t *count) {
+    profile_drain();
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    *count = (int32_t)g_entries.size();
+    return DZO_OK;
+}
+
+int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launches, double *total_ms) {
+    profile_drain();
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    DZO_REQUIRE(i >= 0 && i < (int32_t)g_entries.size(), DZO_ERR_INVALID, "profile index %d", i);
+    if (name && name_len > 0) {
+        strncpy(name, g_entries[i].name.c_str(), (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (launches) *launches = g_entries[i].launches;
+    if (total_ms) *total_ms = g_entries[i].total_ms;
+    return DZO_OK;
+}
+
+int32_t dzo_malloc(void **ptr_dev, int64_t bytes) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(ptr_dev && bytes >= 0, DZO_ERR_INVALID, "dzo_malloc: bad arguments");
+    hipError_t e = hipMalloc(ptr_dev, (size_t)(bytes > 0 ? bytes : 16));
+    if (e == hipErrorOutOfMemory) {
+        set_error("hipMalloc(%lld bytes): out of device memory", (long long)bytes);
+        return DZO_ERR_NOMEM;
+    }
+    DZO_HIP(e);
+    return DZO_OK;
+}
+
+int32_t dzo_free(void *ptr_dev) {
+    DZO_TRY(require_init());
+    if (ptr_dev) DZO_HIP(hipFree(ptr_dev));
+    return DZO_OK;
+}
+
+int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes) {
+    DZO_TRY(require_init());
+    if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    return DZO_OK;
+}
+
+int32_t dzo_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes) {
+    DZO_TRY(require_init());
+    // every library stream is non-blocking w.r.t. the null stream: drain the device first
+    DZO_HIP(hipDeviceSynchronize());
+    if (bytes > 0) DZO_HIP(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return DZO_OK;
+}
+
+int32_t dzo_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes) {
+    DZO_TRY(require_init());
+    DZO_HIP(hipDeviceSynchronize());
+    if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice));
+    return DZO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1044 @@
+// dzo_lbfgs.hip -- LBFGSOptimizer + step! (src/DZOptimization.jl:321-509) for gfx950.
+//
+// HBM layout
+//   S, Y      two slabs of (m+1) slots x `stride` elements; slot stride is n rounded up to
+//             64 elements so every slot starts 256/512-byte aligned for 16-B-per-lane loads.
+//             The reference's Vector{A} newest-first order (:339-340, pushfirst! :483,:491) is
+//             a ring: logical pair i lives in slot (newest - i) mod (m+1).  The extra slot is
+//             the "spare": delta_point / delta_gradient ARE the spare slots of S / Y, so the
+//             history push (:482-496) is an index rotation, not two copies.
+//   rho       fp64 per slot, device-resident (s.y itself, not its inverse, :505).
+//   Gyy, Gsy  (m+1)^2 fp64 Gram caches indexed by slot (GRAM mode).
+//
+// compute_lbfgs_step_direction! (:430-451) has two device implementations:
+//   CHAIN  2k+1 launches, each a fused "axpy_i + dot_{i+1}" pass in the reference's exact
+//          operation order; coefficients stay on the device (no host sync inside).  Moves
+//          (8k+2)*n elements.
+//   GRAM   one pass that streams every s_i, y_i once and accumulates s_i.g, y_i.g and the
+//          new row/column of Y'Y and S'Y; an O(k^2) single-wave recurrence that reproduces
+//          alpha_i and beta_i from those dot products; one combine pass that applies the
+//          2k+1 coefficients per element IN THE REFERENCE'S ELEMENTWISE ORDER (fma chain,
+//          then the rmul! scale, then the second fma chain).  Moves (4k+3)*n elements --
+//          the algorithmic floor of SURVEY.md 8(d) plus one re-read of g.
+#include <type_traits>
+#include <utility>
+
+#include "dzo_optcore.h"
+
+namespace dzo {
+
+constexpr int kGramValues = 5;  // per pair: s.g, y.g, y.y_p, y.s_p, s.y_p  (p = pivot pair)
+
+struct SlotMap {
+    uint8_t slot[kMaxHistory];
+};
+
+}  // namespace dzo
+
+struct dzo_lbfgs_s {
+    dzo::OptCore core;
+    int32_t m = 0;                  // :338 history_length
+    int32_t k = 0;                  // length(delta_point_history)
+    int32_t newest = 0;             // slot of pair 0
+    int64_t stride = 0;             // elements between slots
+    void *S = nullptr, *Y = nullptr;
+    void *d = nullptr;              // :337 step_direction
+    int32_t mode = DZO_TWOLOOP_GRAM;
+    int32_t n_alpha = 0;            // length(alpha_history) (:498-500)
+    int32_t gram_stale = 0;         // pushes since the last Gram pass (>1 => rebuild)
+    bool gram_rebuild = false;      // history installed from outside
+    // device fp64 scalars
+    double *rho = nullptr;          // [m+1] by slot
+    double *alpha = nullptr;        // [kMaxHistory] logical order (newest first)
+    double *coef = nullptr;         // [kMaxHistory] alpha_i + beta_i
+    double *scale = nullptr;        // [1] -rho_1 / (y_1.y_1)   (:444)
+    double *Gyy = nullptr, *Gsy = nullptr;  // [(m+1)^2]
+    double *sg = nullptr, *yg = nullptr;    // [kMaxHistory]
+    double *gram_partials = nullptr;        // [kGramValues*kMaxHistory][gram_grid]
+    double *link_partials = nullptr;        // [4][kMaxPartialBlocks] ping-pong + yy
+    int gram_grid = 0;
+
+    int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
+    int spare() const { return (newest + 1) % (m + 1); }
+    template <typename T> T *s_slot(int slot) const { return (T *)S + (int64_t)slot * stride; }
+    template <typename T> T *y_slot(int slot) const { return (T *)Y + (int64_t)slot * stride; }
+    void *s_slot_v(int slot) const { return (char *)S + (size_t)slot * stride * dzo::dtype_size(core.dtype); }
+    void *y_slot_v(int slot) const { return (char *)Y + (size_t)slot * stride * dzo::dtype_size(core.dtype); }
+    void refresh_delta_ptrs() { core.dx = s_slot_v(spare()); core.dg = y_slot_v(spare()); }
+};
+
+namespace dzo {
+
+template <typename T, bool VEC> struct Ld {
+    static constexpr int N = VEC ? Vec16<T>::N : 1;
+    static __device__ __forceinline__ void load(const T *p, T (&v)[N]) {
+        if constexpr (VEC) load16(p, v); else v[0] = p[0];
+    }
+    static __device__ __forceinline__ void store(T *p, const T (&v)[N]) {
+        if constexpr (VEC) store16(p, v); else p[0] = v[0];
+    }
+};
+
+// ============================================================================ CHAIN mode
+// One link of the two-loop recursion: out = post * fma(coef, v, in), with
+//   first loop  (:440-441)  a = dot/rho,  coef = -a,            alpha[i] = a
+//   second loop (:447-448)  b = dot/rho,  coef = -(alpha[i]+b), coef_out = alpha[i]+b
+// `dot` is the fixed-order sum of the previous launch's per-block partials; the link also
+// accumulates the NEXT link's dot (w . out) and, on request, v.v for the :444 scale.
+struct LinkParams {
+    int64_t n;
+    const void *in;
+    void *out;
+    const void *v;
+    const void *w;              // may be null
+    const double *prev;         // partials of the dot feeding this link
+    int prev_count;
+    const double *rho;          // rho of this pair
+    double *alpha;              // &alpha[i]
+    double *coef_out;           // &coef[i] (second loop) or null
+    int second_loop;
+    const double *yy;           // partials of y_1.y_1 (when this link applies the :444 scale)
+    int yy_count;
+    const double *rho0;
+    double *scale_out;
+    double *dot_out;            // partials of w.out
+    double *yy_out;             // partials of v.v, may be null
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void chain_link_kernel(LinkParams p) {
+    using L = Ld<T, VEC>;
+    constexpr int N = L::N;
+    __shared__ double lds[kWaves];
+    const double dot = reduce_partials_all(p.prev, p.prev_count, lds);
+    const double q = dot / p.rho[0];
+    double c;
+    if (p.second_loop) {
+        c = p.alpha[0] + q;
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.coef_out[0] = c;
+    } else {
+        c = q;
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.alpha[0] = q;
+    }
+    const T coef = (T)(-c);
+    const bool has_post = p.yy != nullptr;
+    T post = (T)1;
+    if (has_post) {
+        const double yy = reduce_partials_all(p.yy, p.yy_count, lds);
+        const double sc = -p.rho0[0] / yy;                       // :444
+        post = (T)sc;
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.scale_out[0] = sc;
+    }
+    const T *in = (const T *)p.in;
+    T *out = (T *)p.out;
+    const T *v = (const T *)p.v;
+    const T *w = (const T *)p.w;
+    double acc_w = 0, acc_v = 0;
+    const int64_t nvec = p.n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    auto body = [&](int64_t i, auto tag) {
+        constexpr int M = decltype(tag)::value;
+        T qv[M], vv[M], wv[M];
+        if constexpr (M == N && VEC) { load16(in + i, qv); load16(v + i, vv); if (w) load16(w + i, wv); }
+        else { qv[0] = in[i]; vv[0] = v[i]; if (w) wv[0] = w[i]; }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            T r = dfma(coef, vv[j], qv[j]);
+            if (has_post) r = post * r;
+            qv[j] = r;
+            if (w) acc_w = __builtin_fma((double)wv[j], (double)r, acc_w);
+            if (p.yy_out) acc_v = __builtin_fma((double)vv[j], (double)vv[j], acc_v);
+        }
+        if constexpr (M == N && VEC) store16(out + i, qv); else out[i] = qv[0];
+    };
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * 2; base < nvec; base += nthreads * 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
+            if (vi < nvec) body(vi * N, std::integral_constant<int, N>{});
+        }
+    }
+    if constexpr (VEC) {
+        const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < p.n) body(i, std::integral_constant<int, 1>{});
+    }
+    if (p.dot_out) {
+        double r = block_sum(acc_w, lds);
+        if (threadIdx.x == 0) p.dot_out[blockIdx.x] = r;
+    }
+    if (p.yy_out) {
+        double r = block_sum(acc_v, lds);
+        if (threadIdx.x == 0) p.yy_out[blockIdx.x] = r;
+    }
+}
+
+// first launch of the chain: partials of s_1.g and (k == 1 only) y_1.y_1
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void chain_head_kernel(int64_t n, const T *__restrict__ s, const T *__restrict__ g,
+                                                            const T *__restrict__ y, double *__restrict__ dot_out,
+                                                            double *__restrict__ yy_out) {
+    using L = Ld<T, VEC>;
+    constexpr int N = L::N;
+    __shared__ double lds[kWaves];
+    double a = 0, b = 0;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t vi = (int64_t)blockIdx.x * kBlock + threadIdx.x; vi < nvec; vi += nthreads) {
+        T sv[N], gv[N], yv[N];
+        L::load(s + vi * N, sv);
+        L::load(g + vi * N, gv);
+        if (yy_out) L::load(y + vi * N, yv);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            a = __builtin_fma((double)sv[j], (double)gv[j], a);
+            if (yy_out) b = __builtin_fma((double)yv[j], (double)yv[j], b);
+        }
+    }
+    if constexpr (VEC) {
+        const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < n) {
+            a = __builtin_fma((double)s[i], (double)g[i], a);
+            if (yy_out) b = __builtin_fma((double)y[i], (double)y[i], b);
+        }
+    }
+    double r = block_sum(a, lds);
+    if (threadIdx.x == 0) dot_out[blockIdx.x] = r;
+    if (yy_out) {
+        r = block_sum(b, lds);
+        if (threadIdx.x == 0) yy_out[blockIdx.x] = r;
+    }
+}
+
+// ============================================================================ GRAM mode
+template <typename T> struct GramParams {
+    int64_t n;
+    const T *g;
+    const T *S;
+    const T *Y;
+    int64_t stride;
+    int k;
+    int pivot_slot;             // slot of the pair whose Gram row/column is (re)computed
+    SlotMap map;                // logical pair -> slot
+    double *partials;           // [kGramValues * k][gridDim.x]
+};
+
+// Each block walks tiles of 64 lanes x U 16-B vectors; its 4 waves all read the tile of
+// g, s_p, y_p (L1 hits after the first wave) and split the k pairs between them, so a lane
+// carries 5*PPW fp64 accumulators instead of 5*k.
+template <typename T, int PPW, bool VEC>
+__global__ __launch_bounds__(kBlock) void gram_pass_kernel(GramParams<T> p) {
+    using L = Ld<T, VEC>;
+    constexpr int N = L::N;
+    constexpr int U = 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double acc[PPW][kGramValues];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q)
+#pragma unroll
+        for (int c = 0; c < kGramValues; ++c) acc[q][c] = 0;
+
+    const T *sp = p.S + (int64_t)p.pivot_slot * p.stride;
+    const T *yp = p.Y + (int64_t)p.pivot_slot * p.stride;
+    const int64_t nvec = p.n / N;
+    const int64_t tile = 64 * U;                       // vectors per block-iteration
+    for (int64_t base = (int64_t)blockIdx.x * tile; base < nvec; base += (int64_t)gridDim.x * tile) {
+        T gv[U][N], spv[U][N], ypv[U][N];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t vi = base + u * 64 + lane;
+            ok[u] = vi < nvec;
+            if (ok[u]) {
+                L::load(p.g + vi * N, gv[u]);
+                L::load(sp + vi * N, spv[u]);
+                L::load(yp + vi * N, ypv[u]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int i = wave + kWaves * q;
+            if (i < p.k) {
+                const int slot = p.map.slot[i];
+                const T *si = p.S + (int64_t)slot * p.stride;
+                const T *yi = p.Y + (int64_t)slot * p.stride;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) continue;
+                    const int64_t vi = base + u * 64 + lane;
+                    T sv[N], yv[N];
+                    L::load(si + vi * N, sv);
+                    L::load(yi + vi * N, yv);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        const double s = (double)sv[j], y = (double)yv[j];
+                        acc[q][0] = __builtin_fma(s, (double)gv[u][j], acc[q][0]);
+                        acc[q][1] = __builtin_fma(y, (double)gv[u][j], acc[q][1]);
+                        acc[q][2] = __builtin_fma(y, (double)ypv[u][j], acc[q][2]);
+                        acc[q][3] = __builtin_fma(y, (double)spv[u][j], acc[q][3]);
+                        acc[q][4] = __builtin_fma(s, (double)ypv[u][j], acc[q][4]);
+                    }
+                }
+            }
+        }
+    }
+    // scalar tail (n not a multiple of the vector width): block 0 only, lane 0 of each wave
+    if (VEC && blockIdx.x == 0 && lane == 0) {
+        for (int64_t e = nvec * N; e < p.n; ++e) {
+            const double ge = (double)p.g[e], spe = (double)sp[e], ype = (double)yp[e];
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+                const int i = wave + kWaves * q;
+                if (i < p.k) {
+                    const int slot = p.map.slot[i];
+                    const double s = (double)p.S[(int64_t)slot * p.stride + e];
+                    const double y = (double)p.Y[(int64_t)slot * p.stride + e];
+                    acc[q][0] = __builtin_fma(s, ge, acc[q][0]);
+                    acc[q][1] = __builtin_fma(y, ge, acc[q][1]);
+                    acc[q][2] = __builtin_fma(y, ype, acc[q][2]);
+                    acc[q][3] = __builtin_fma(y, spe, acc[q][3]);
+                    acc[q][4] = __builtin_fma(s, ype, acc[q][4]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int i = wave + kWaves * q;
+        if (i < p.k) {
+#pragma unroll
+            for (int c = 0; c < kGramValues; ++c) {
+                const double r = wave_sum(acc[q][c]);
+                if (lane == 0) p.partials[(int64_t)(i * kGramValues + c) * gridDim.x + blockIdx.x] = r;
+            }
+        }
+    }
+}
+
+struct GramFinishParams {
+    int k;
+    int m1;                     // m + 1 (leading dimension of the slot-indexed Gram caches)
+    int pivot;                  // logical index of the pivot pair
+    int grid;                   // blocks of the Gram pass
+    int do_recurrence;
+    SlotMap map;
+    const double *partials;
+    const double *rho;          // by slot
+    double *Gyy, *Gsy;
+    double *sg, *yg;
+    double *alpha, *coef, *scale;
+};
+
+// One block.  (1) fixed-order reduction of the per-block partials, (2) refresh of the pivot
+// row/column of the slot-indexed Gram caches, (3) the two-loop recursion on SCALARS by one
+// wave, lane i owning pair i:
+//     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
+//     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
+__global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p) {
+    __shared__ double vals[kGramValues * kMaxHistory];
+    __shared__ double yy[kMaxHistory][kMaxHistory + 1];
+    __shared__ double sy[kMaxHistory][kMaxHistory + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = p.k;
+    for (int v = wave; v < kGramValues * k; v += kWaves) {
+        double a = 0;
+        const double *src = p.partials + (int64_t)v * p.grid;
+        for (int b = lane; b < p.grid; b += 64) a += src[b];
+        a = wave_sum_all(a);
+        if (lane == 0) vals[v] = a;
+    }
+    // logical k x k views of the caches (entries of non-pivot pairs were computed by the
+    // passes in which THEY were the pivot)
+    for (int e = threadIdx.x; e < k * k; e += kBlock) {
+        const int i = e / k, j = e % k;
+        yy[i][j] = p.Gyy[p.map.slot[i] * p.m1 + p.map.slot[j]];
+        sy[i][j] = p.Gsy[p.map.slot[i] * p.m1 + p.map.slot[j]];
+    }
+    __syncthreads();
+    const int pv = p.pivot, ps = p.map.slot[pv];
+    if (threadIdx.x < k) {
+        const int i = threadIdx.x, si = p.map.slot[i];
+        const double *v = vals + i * kGramValues;
+        p.sg[i] = v[0];
+        p.yg[i] = v[1];
+        yy[i][pv] = v[2]; yy[pv][i] = v[2];
+        p.Gyy[si * p.m1 + ps] = v[2]; p.Gyy[ps * p.m1 + si] = v[2];
+        sy[pv][i] = v[3];                       // s_p . y_i
+        p.Gsy[ps * p.m1 + si] = v[3];
+        sy[i][pv] = v[4];                       // s_i . y_p
+        p.Gsy[si * p.m1 + ps] = v[4];
+    }
+    __syncthreads();
+    if (!p.do_recurrence || wave != 0) return;
+
+    const bool on = lane < k;
+    const double rho_i = on ? p.rho[p.map.slot[lane]] : 1.0;
+    double acc = on ? vals[lane * kGramValues + 0] : 0.0;          // s_i.g
+    double alpha_i = 0;
+    for (int j = 0; j < k; ++j) {                                  // :439 newest -> oldest
+        const double cand = acc / rho_i;                           // :440 (lane j's value counts)
+        const double aj = __shfl(cand, j, 64);
+        if (lane == j) alpha_i = cand;
+        if (on && lane > j) acc = __builtin_fma(-aj, sy[lane][j], acc);
+    }
+    if (on) p.alpha[lane] = alpha_i;
+    const double scale = -p.rho[p.map.slot[0]] / yy[0][0];         // :444
+    if (lane == 0) p.scale[0] = scale;
+    // y_i.q_k with q_k = g - sum_j alpha_j y_j
+    double base = on ? vals[lane * kGramValues + 1] : 0.0;         // y_i.g
+    for (int j = 0; j < k; ++j) {
+        const double aj = __shfl(alpha_i, j, 64);
+        if (on) base = __builtin_fma(-aj, yy[lane][j], base);
+    }
+    acc = scale * base;
+    double c_i = 0;
+    for (int l = k - 1; l >= 0; --l) {                             // :446 oldest -> newest
+        const double cand = alpha_i + acc / rho_i;                 // :447-448
+        const double cl = __shfl(cand, l, 64);
+        if (lane == l) c_i = cand;
+        if (on && lane < l) acc = __builtin_fma(-cl, sy[l][lane], acc);
+    }
+    if (on) p.coef[lane] = c_i;
+}
+
+template <typename T> struct CombineParams {
+    int64_t n;
+    const T *g;
+    T *d;
+    const T *S;
+    const T *Y;
+    int64_t stride;
+    int k;
+    SlotMap map;
+    const double *alpha, *coef, *scale;
+};
+
+// d[e] = the reference's elementwise recurrence (:438-449) with the scalars already known:
+//   q = g[e]; q = fma(-alpha_i, y_i[e], q) (i = 1..k); q *= scale; q = fma(-c_i, s_i[e], q)
+//   (i = k..1).  Given equal scalars this is bit-identical to the reference's d.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
+    using L = Ld<T, VEC>;
+    constexpr int N = L::N;
+    constexpr int U = 2;
+    const int64_t nvec = p.n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    const int k = p.k;
+    const T scale = (T)p.scale[0];
+    auto run = [&](int64_t e0, int64_t e1, bool two, auto tag) {
+        constexpr int M = decltype(tag)::value;
+        T q0[M], q1[M];
+        if constexpr (M > 1) { load16(p.g + e0, q0); if (two) load16(p.g + e1, q1); }
+        else { q0[0] = p.g[e0]; }
+#pragma unroll 4
+        for (int i = 0; i < k; ++i) {
+            const T a = (T)(-p.alpha[i]);
+            const T *yi = p.Y + (int64_t)p.map.slot[i] * p.stride;
+            T v0[M], v1[M];
+            if constexpr (M > 1) { load16(yi + e0, v0); if (two) load16(yi + e1, v1); }
+            else { v0[0] = yi[e0]; }
+#pragma unroll
+            for (int j = 0; j < M; ++j) { q0[j] = dfma(a, v0[j], q0[j]); if (M > 1 && two) q1[j] = dfma(a, v1[j], q1[j]); }
+        }
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) { q0[j] = scale * q0[j]; if (M > 1 && two) q1[j] = scale * q1[j]; }
+        }
+#pragma unroll 4
+        for (int i = k - 1; i >= 0; --i) {
+            const T c = (T)(-p.coef[i]);
+            const T *si = p.S + (int64_t)p.map.slot[i] * p.stride;
+            T v0[M], v1[M];
+            if constexpr (M > 1) { load16(si + e0, v0); if (two) load16(si + e1, v1); }
+            else { v0[0] = si[e0]; }
+#pragma unroll
+            for (int j = 0; j < M; ++j) { q0[j] = dfma(c, v0[j], q0[j]); if (M > 1 && two) q1[j] = dfma(c, v1[j], q1[j]); }
+        }
+        if constexpr (M > 1) { store16(p.d + e0, q0); if (two) store16(p.d + e1, q1); }
+        else { p.d[e0] = q0[0]; }
+    };
+    if constexpr (VEC) {
+        for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
+            const int64_t v0 = base + threadIdx.x, v1 = base + kBlock + threadIdx.x;
+            if (v0 < nvec) run(v0 * N, v1 * N, v1 < nvec, std::integral_constant<int, N>{});
+        }
+        const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < p.n) run(i, i, false, std::integral_constant<int, 1>{});
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += nthreads)
+            run(i, i, false, std::integral_constant<int, 1>{});
+    }
+}
+
+// ============================================================================ post-gradient
+// :480 delta_gradient = g - delta_gradient, fused with the partials of
+// rho = dot(delta_point, delta_gradient) (:505).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void delta_rho_kernel(int64_t n, const T *__restrict__ g, T *__restrict__ dg,
+                                                           const T *__restrict__ dx, double *__restrict__ partials) {
+    using L = Ld<T, VEC>;
+    constexpr int N = L::N;
+    __shared__ double lds[kWaves];
+    double acc = 0;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * 2; base < nvec; base += nthreads * 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
+            if (vi >= nvec) continue;
+            T gv[N], ov[N], xv[N];
+            L::load(g + vi * N, gv);
+            L::load(dg + vi * N, ov);
+            L::load(dx + vi * N, xv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                ov[j] = gv[j] - ov[j];
+                acc = __builtin_fma((double)xv[j], (double)ov[j], acc);
+            }
+            L::store(dg + vi * N, ov);
+        }
+    }
+    if constexpr (VEC) {
+        const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < n) {
+            const T o = g[i] - dg[i];
+            dg[i] = o;
+            acc = __builtin_fma((double)dx[i], (double)o, acc);
+        }
+    }
+    double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void finish_to_kernel(const double *__restrict__ partials, int count,
+                                                           double *__restrict__ dst, int to_f32) {
+    __shared__ double lds[kWaves];
+    double r = reduce_partials_all(partials, count, lds);
+    if (threadIdx.x == 0) dst[0] = to_f32 ? (double)(float)r : r;
+}
+
+static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static SlotMap make_map(const dzo_lbfgs_s *o) {
+    SlotMap mp;
+    memset(&mp, 0, sizeof(mp));
+    for (int i = 0; i < o->k; ++i) mp.slot[i] = (uint8_t)o->slot_of(i);
+    return mp;
+}
+
+// ---------------------------------------------------------------------------- CHAIN driver
+template <typename T> static int32_t direction_chain(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int64_t n = c.n;
+    const int k = o->k;
+    const T *g = (const T *)c.g;
+    T *d = (T *)o->d;
+    const bool vec = al16(g);  // every other operand is library-allocated and aligned
+    const int grid = stream_grid(n, (vec ? Vec16<T>::N : 1) * 2);
+    double *bufA = o->link_partials, *bufB = o->link_partials + kMaxPartialBlocks;
+    double *yyP = o->link_partials + 2 * kMaxPartialBlocks;
+    {
+        DZO_TIMED("lbfgs_chain_head", s);
+        const T *s0 = o->s_slot<T>(o->slot_of(0));
+        const T *y0 = o->y_slot<T>(o->slot_of(0));
+        if (vec) hipLaunchKernelGGL((chain_head_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, s0, g, y0, bufA, k == 1 ? yyP : (double *)nullptr);
+        else hipLaunchKernelGGL((chain_head_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, s0, g, y0, bufA, k == 1 ? yyP : (double *)nullptr);
+    }
+    auto launch = [&](const LinkParams &lp) {
+        DZO_TIMED("lbfgs_chain_link", s);
+        if (vec) hipLaunchKernelGGL((chain_link_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, lp);
+        else hipLaunchKernelGGL((chain_link_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, lp);
+    };
+    double *prev = bufA, *next = bufB;
+    for (int i = 0; i < k; ++i) {                         // :439-442
+        LinkParams lp;
+        memset(&lp, 0, sizeof(lp));
+        lp.n = n;
+        lp.in = (i == 0) ? (const void *)g : (const void *)d;
+        lp.out = d;
+        lp.v = o->y_slot<T>(o->slot_of(i));
+        lp.w = (i < k - 1) ? (const void *)o->s_slot<T>(o->slot_of(i + 1)) : (const void *)o->y_slot<T>(o->slot_of(k - 1));
+        lp.prev = prev; lp.prev_count = grid;
+        lp.rho = o->rho + o->slot_of(i);
+        lp.alpha = o->alpha + i;
+        lp.second_loop = 0;
+        if (i == k - 1) { lp.yy = yyP; lp.yy_count = grid; lp.rho0 = o->rho + o->slot_of(0); lp.scale_out = o->scale; }  // :443-445
+        lp.dot_out = next;
+        lp.yy_out = (i == 0 && k > 1) ? yyP : nullptr;
+        launch(lp);
+        std::swap(prev, next);
+    }
+    for (int i = k - 1; i >= 0; --i) {                    // :446-449
+        LinkParams lp;
+        memset(&lp, 0, sizeof(lp));
+        lp.n = n;
+        lp.in = d; lp.out = d;
+        lp.v = o->s_slot<T>(o->slot_of(i));
+        lp.w = (i > 0) ? (const void *)o->y_slot<T>(o->slot_of(i - 1)) : nullptr;
+        lp.prev = prev; lp.prev_count = grid;
+        lp.rho = o->rho + o->slot_of(i);
+        lp.alpha = o->alpha + i;
+        lp.coef_out = o->coef + i;
+        lp.second_loop = 1;
+        lp.dot_out = (i > 0) ? next : nullptr;
+        launch(lp);
+        std::swap(prev, next);
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+// ---------------------------------------------------------------------------- GRAM driver
+template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool recurrence) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int k = o->k;
+    GramParams<T> gp;
+    gp.n = c.n; gp.g = (const T *)c.g; gp.S = (const T *)o->S; gp.Y = (const T *)o->Y;
+    gp.stride = o->stride; gp.k = k; gp.pivot_slot = o->slot_of(pivot); gp.map = make_map(o);
+    gp.partials = o->gram_partials;
+    const bool vec = al16(c.g);
+    const int ppw = (k + kWaves - 1) / kWaves;
+    const int grid = o->gram_grid;
+    {
+        DZO_TIMED("lbfgs_gram_pass", s);
+#define GP(P)                                                                                              \
+    do {                                                                                                   \
+        if (vec) hipLaunchKernelGGL((gram_pass_kernel<T, P, true>), dim3(grid), dim3(kBlock), 0, s, gp);   \
+        else hipLaunchKernelGGL((gram_pass_kernel<T, P, false>), dim3(grid), dim3(kBlock), 0, s, gp);      \
+    } while (0)
+        if (ppw <= 1) GP(1);
+        else if (ppw <= 2) GP(2);
+        else if (ppw <= 3) GP(3);
+        else if (ppw <= 4) GP(4);
+        else if (ppw <= 5) GP(5);
+        else if (ppw <= 6) GP(6);
+        else if (ppw <= 8) GP(8);
+        else if (ppw <= 12) GP(12);
+        else GP(16);
+#undef GP
+    }
+    GramFinishParams fp;
+    fp.k = k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = grid; fp.do_recurrence = recurrence ? 1 : 0;
+    fp.map = gp.map; fp.partials = o->gram_partials; fp.rho = o->rho;
+    fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
+    fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
+    {
+        DZO_TIMED("lbfgs_gram_finish", s);
+        hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(kBlock), 0, s, fp);
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int k = o->k;
+    if (o->gram_rebuild || o->gram_stale > 1) {
+        // history installed from outside (or pushes without a direction in between): rebuild
+        // every row/column of the caches, oldest pivot first, newest last
+        for (int pv = k - 1; pv >= 1; --pv) DZO_TRY(gram_pass<T>(o, pv, false));
+    }
+    DZO_TRY(gram_pass<T>(o, 0, true));
+    o->gram_rebuild = false;
+    o->gram_stale = 0;
+    CombineParams<T> cp;
+    cp.n = c.n; cp.g = (const T *)c.g; cp.d = (T *)o->d; cp.S = (const T *)o->S; cp.Y = (const T *)o->Y;
+    cp.stride = o->stride; cp.k = k; cp.map = make_map(o);
+    cp.alpha = o->alpha; cp.coef = o->coef; cp.scale = o->scale;
+    const bool vec = al16(c.g);
+    const int grid = stream_grid(c.n, (vec ? Vec16<T>::N : 1) * 2);
+    {
+        DZO_TIMED("lbfgs_combine", s);
+        if (vec) hipLaunchKernelGGL((combine_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, cp);
+        else hipLaunchKernelGGL((combine_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, cp);
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+static int32_t lbfgs_direction(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    if (o->k == 0) {                                      // :438 then the :443 guard
+        DZO_HIP(hipMemcpyAsync(o->d, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
+        return DZO_OK;
+    }
+    if (o->mode == DZO_TWOLOOP_CHAIN) DZO_DISPATCH(c.dtype, return direction_chain<T>(o));
+    DZO_DISPATCH(c.dtype, return direction_gram<T>(o));
+    return DZO_OK;
+}
+
+static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int sp = o->spare();
+    {
+        DZO_TIMED("lbfgs_delta_rho", s);
+        const bool vec = al16(c.g);
+        const int grid = stream_grid(c.n, (vec ? 16 / (int)dtype_size(c.dtype) : 1) * 2);
+        if (c.dtype == DZO_F64) {
+            if (vec) hipLaunchKernelGGL((delta_rho_kernel<double, true>), dim3(grid), dim3(kBlock), 0, s, c.n, (const double *)c.g, (double *)c.dg, (const double *)c.dx, c.partials());
+            else hipLaunchKernelGGL((delta_rho_kernel<double, false>), dim3(grid), dim3(kBlock), 0, s, c.n, (const double *)c.g, (double *)c.dg, (const double *)c.dx, c.partials());
+        } else {
+            if (vec) hipLaunchKernelGGL((delta_rho_kernel<float, true>), dim3(grid), dim3(kBlock), 0, s, c.n, (const float *)c.g, (float *)c.dg, (const float *)c.dx, c.partials());
+            else hipLaunchKernelGGL((delta_rho_kernel<float, false>), dim3(grid), dim3(kBlock), 0, s, c.n, (const float *)c.g, (float *)c.dg, (const float *)c.dx, c.partials());
+        }
+        // :505  rho of the pair being pushed, stored by slot (rounded to T like the reference's dot)
+        hipLaunchKernelGGL(finish_to_kernel, dim3(1), dim3(kBlock), 0, s, c.partials(), grid, o->rho + sp,
+                           c.dtype == DZO_F32 ? 1 : 0);
+    }
+    DZO_HIP(hipGetLastError());
+    // :482-496  pushfirst!: the spare slots (= delta_point, delta_gradient) become pair 0
+    o->newest = sp;
+    if (o->k < o->m) o->k += 1;
+    if (o->n_alpha < o->m) o->n_alpha += 1;               // :498-500
+    o->gram_stale += 1;
+    // delta_point / delta_gradient keep pointing at the pushed pair until the next search
+    // begins, exactly as the reference's fields hold the last step's deltas
+    c.iteration_count += 1;                               // :507
+    return DZO_OK;
+}
+
+static int32_t lbfgs_step(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    if (c.is_stuck) return DZO_OK;                        // :456-458
+    DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
+                "step! needs objective and gradient (callbacks or a built-in problem)");
+    if (c.iteration_count > 0) DZO_TRY(lbfgs_direction(o));   // :463-471
+    o->refresh_delta_ptrs();                              // deltas move to the spare slots
+    DZO_TRY(core_backtracking_step(c, 1.0, o->d));        // :473
+    if (c.is_stuck) return DZO_OK;                        // :474-476
+    DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
+    DZO_TRY(core_gradient(c));                            // :479
+    return lbfgs_post_gradient(o);                        // :480-507
+}
+
+}  // namespace dzo
+
+using namespace dzo;
+
+// ============================================================================ C ABI
+extern "C" {
+
+int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void *x_dev, void *g_dev,
+                         double initial_objective_value, double initial_step_length, dzo_lbfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(out, DZO_ERR_INVALID, "null out");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    DZO_REQUIRE(n >= 1 && x_dev && g_dev, DZO_ERR_INVALID, "n must be >= 1 and x/g non-null");
+    DZO_REQUIRE(history_length >= 1 && history_length <= kMaxHistory, DZO_ERR_INVALID,
+                "history_length must be in 1..%d", kMaxHistory);
+    DZO_REQUIRE(initial_step_length > 0, DZO_ERR_ASSERT, "@assert initial_step_length > 0 (src/DZOptimization.jl:380)");
+    dzo_lbfgs_s *o = new dzo_lbfgs_s();
+    OptCore &c = o->core;
+    c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
+    c.f = round_to_dtype(dtype, initial_objective_value);
+    o->m = history_length;
+    const size_t es = dtype_size(dtype);
+    o->stride = (n + 63) / 64 * 64;
+    int32_t rc = core_alloc(c);
+    if (rc != DZO_OK) { delete o; return rc; }
+    const int m1 = o->m + 1;
+    const size_t slab = (size_t)m1 * (size_t)o->stride * es;
+    hipError_t e;
+#define ALLOC(ptr, bytes)                                                                          \
+    e = hipMalloc((void **)&(ptr), (bytes));                                                       \
+    if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    ALLOC(o->S, slab);
+    ALLOC(o->Y, slab);
+    ALLOC(o->d, (size_t)o->stride * es);
+    o->gram_grid = ctx().cus * 4;
+    if (o->gram_grid > kMaxPartialBlocks) o->gram_grid = kMaxPartialBlocks;
+    {
+        const int64_t tiles = (n / (16 / (int64_t)es) + 127) / 128;
+        if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
+    }
+    const size_t nscal = (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory +
+                         (size_t)kGramValues * kMaxHistory * o->gram_grid + 4 * (size_t)kMaxPartialBlocks;
+    double *base = nullptr;
+    ALLOC(base, nscal * sizeof(double));
+#undef ALLOC
+    (void)hipMemset(base, 0, nscal * sizeof(double));
+    o->rho = base; base += m1;
+    o->alpha = base; base += kMaxHistory;
+    o->coef = base; base += kMaxHistory;
+    o->scale = base; base += 8;
+    o->Gyy = base; base += (size_t)m1 * m1;
+    o->Gsy = base; base += (size_t)m1 * m1;
+    o->sg = base; base += kMaxHistory;
+    o->yg = base; base += kMaxHistory;
+    o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * o->gram_grid;
+    o->link_partials = base;
+    // :366-374 zero-filled deltas: the whole ring starts zeroed
+    DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
+    DZO_HIP(hipMemsetAsync(o->Y, 0, slab, c.stream));
+    o->k = 0; o->newest = o->m;   // spare() == 0
+    o->refresh_delta_ptrs();
+    // :381-388
+    double gnorm = 0;
+    rc = dot_blocking(c.stream, n, dtype, g_dev, g_dev, c.partials(), c.host, &gnorm);
+    if (rc != DZO_OK) { dzo_lbfgs_destroy(o); return rc; }
+    gnorm = dtype == DZO_F32 ? (double)sqrtf((float)gnorm) : sqrt(gnorm);
+    c.is_stuck = (gnorm == 0.0);                          // :382 iszero
+    if (c.is_stuck) {
+        DZO_HIP(hipMemsetAsync(o->d, 0, (size_t)o->stride * es, c.stream));   // :384
+    } else {
+        const double sc = round_to_dtype(dtype, -initial_step_length / gnorm);
+        DZO_DISPATCH(dtype, launch_scal_oop<T>(c.stream, n, (T *)o->d, (T)sc, (const T *)g_dev));  // :386-387
+    }
+    DZO_HIP(hipStreamSynchronize(c.stream));
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
+    if (!o) return DZO_OK;
+    if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
+    if (o->S) (void)hipFree(o->S);
+    if (o->Y) (void)hipFree(o->Y);
+    if (o->d) (void)hipFree(o->d);
+    if (o->rho) (void)hipFree(o->rho);
+    core_free(o->core);
+    delete o;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_create_callbacks(dzo_constraint_fn constraint, dzo_objective_fn objective, dzo_gradient_fn gradient,
+                                   void *cb_ctx, int64_t n, int32_t history_length, int32_t dtype, void *x_dev,
+                                   double initial_step_length, dzo_lbfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(objective && gradient && x_dev && out, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    if (constraint) DZO_REQUIRE(constraint(cb_ctx, x_dev) != 0, DZO_ERR_ASSERT,
+                                "@assert constraint_function!(initial_point) (src/DZOptimization.jl:412-414)");
+    const double f0 = objective(cb_ctx, x_dev);           // :416
+    void *g = nullptr;
+    DZO_HIP(hipMalloc(&g, (size_t)((n + 63) / 64 * 64) * dtype_size(dtype)));   // :418 similar(x0)
+    gradient(cb_ctx, g, x_dev);                           // :421
+    int32_t rc = dzo_lbfgs_create(n, history_length, dtype, x_dev, g, f0, initial_step_length, out);
+    if (rc != DZO_OK) { (void)hipFree(g); return rc; }
+    (*out)->core.owns_g = true;
+    return dzo_lbfgs_set_callbacks(*out, constraint, objective, gradient, cb_ctx);
+}
+
+int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, void *x_dev,
+                                 double initial_step_length, dzo_lbfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(problem && x_dev && out, DZO_ERR_INVALID, "null argument");
+    double f0 = 0;
+    DZO_TRY(dzo_problem_eval(problem, x_dev, &f0));       // :416
+    void *g = nullptr;
+    DZO_HIP(hipMalloc(&g, (size_t)((problem->n + 63) / 64 * 64) * dtype_size(problem->dtype)));
+    int32_t rc = dzo_problem_grad(problem, g, x_dev);     // :421
+    if (rc == DZO_OK) rc = dzo_lbfgs_create(problem->n, history_length, problem->dtype, x_dev, g, f0, initial_step_length, out);
+    if (rc != DZO_OK) { (void)hipFree(g); return rc; }
+    (*out)->core.owns_g = true;
+    (*out)->core.problem = problem;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_callbacks(dzo_lbfgs_t o, dzo_constraint_fn constraint, dzo_objective_fn objective,
+                                dzo_gradient_fn gradient, void *cb_ctx) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    o->core.constraint = constraint; o->core.objective = objective; o->core.gradient = gradient;
+    o->core.cb_ctx = cb_ctx;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t o, dzo_problem_t problem) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(!problem || (problem->n == o->core.n && problem->dtype == o->core.dtype), DZO_ERR_INVALID,
+                "problem size/dtype does not match the optimizer");
+    o->core.problem = problem;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t o, int32_t mode) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(mode == DZO_TWOLOOP_CHAIN || mode == DZO_TWOLOOP_GRAM, DZO_ERR_INVALID, "bad two-loop mode %d", mode);
+    if (mode == DZO_TWOLOOP_GRAM && o->mode != DZO_TWOLOOP_GRAM) o->gram_rebuild = true;
+    o->mode = mode;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t o, int64_t max_halvings) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    o->core.max_halvings = max_halvings;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_step(dzo_lbfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    return lbfgs_step(o);
+}
+
+int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_TRY(lbfgs_direction(o));
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    o->refresh_delta_ptrs();
+    return core_begin_search(o->core);
+}
+
+int32_t dzo_lbfgs_trial(dzo_lbfgs_t o, double step_size, int32_t *changed) {
+    DZO_REQUIRE(o && changed, DZO_ERR_INVALID, "null argument");
+    return core_trial(o->core, step_size, o->d, false, changed, nullptr, nullptr);
+}
+
+int32_t dzo_lbfgs_accept(dzo_lbfgs_t o, double next_objective_value) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_TRY(core_accept(o->core, round_to_dtype(o->core.dtype, next_objective_value)));
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_reject(dzo_lbfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_TRY(core_reject(o->core));
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_pre_gradient(dzo_lbfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    OptCore &c = o->core;
+    DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
+    DZO_HIP(hipStreamSynchronize(c.stream));
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_post_gradient(dzo_lbfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_TRY(lbfgs_post_gradient(o));
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
+    DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
+    switch (what) {
+    case 0: *value = o->core.is_stuck ? 1 : 0; break;
+    case 1: *value = o->core.iteration_count; break;
+    case 2: *value = o->core.n; break;
+    case 3: *value = o->m; break;
+    case 4: *value = o->k; break;
+    case 5: *value = o->core.last_trials; break;
+    case 6: *value = o->mode; break;
+    case 7: *value = o->core.dtype; break;
+    default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_get_s(dzo_lbfgs_t o, int32_t what, double *value) {
+    DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(what == 0 || what == 1, DZO_ERR_INVALID, "unknown field %d", what);
+    *value = what == 0 ? o->core.f : o->core.df;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_s(dzo_lbfgs_t o, int32_t what, double value) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(what == 0 || what == 1, DZO_ERR_INVALID, "unknown field %d", what);
+    (what == 0 ? o->core.f : o->core.df) = round_to_dtype(o->core.dtype, value);
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t o, int32_t is_stuck) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    o->core.is_stuck = is_stuck != 0;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_dev) {
+    DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    switch (what) {
+    case 0: *ptr_dev = o->core.x; break;
+    case 1: *ptr_dev = o->core.dx; break;
+    case 2: *ptr_dev = o->core.g; break;
+    case 3: *ptr_dev = o->core.dg; break;
+    case 4: *ptr_dev = o->d; break;
+    case 5:
+    case 6:
+        DZO_REQUIRE(idx >= 0 && idx < o->k, DZO_ERR_INVALID, "history index %d out of range [0,%d)", idx, o->k);
+        *ptr_dev = what == 5 ? o->s_slot_v(o->slot_of(idx)) : o->y_slot_v(o->slot_of(idx));
+        break;
+    default: set_error("dzo_lbfgs_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t *count) {
+    DZO_REQUIRE(o && count, DZO_ERR_INVALID, "null argument");
+    *count = o->k;
+    if (!out) return DZO_OK;
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    double tmp[kMaxHistory + 1];
+    DZO_HIP(hipMemcpy(tmp, o->rho, sizeof(double) * (o->m + 1), hipMemcpyDeviceToHost));
+    for (int i = 0; i < o->k && i < capacity; ++i) out[i] = tmp[o->slot_of(i)];
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_get_alpha(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t *count) {
+    DZO_REQUIRE(o && count, DZO_ERR_INVALID, "null argument");
+    *count = o->n_alpha;
+    if (!out) return DZO_OK;
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    double tmp[kMaxHistory];
+    DZO_HIP(hipMemcpy(tmp, o->alpha, sizeof(double) * kMaxHistory, hipMemcpyDeviceToHost));
+    for (int i = 0; i < o->n_alpha && i < capacity; ++i) out[i] = tmp[i];
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const void *Y_dev, const double *rho_or_null,
+                              int64_t iteration_count) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
+    DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const size_t es = dtype_size(c.dtype);
+    // pair i -> slot (k-1-i): newest = k-1 (or m when empty)
+    o->k = k; o->n_alpha = k;
+    o->newest = k > 0 ? k - 1 : o->m;
+    double rho_host[kMaxHistory + 1] = {0};
+    for (int i = 0; i < k; ++i) {
+        const int slot = o->slot_of(i);
+        DZO_HIP(hipMemcpyAsync(o->s_slot_v(slot), (const char *)S_dev + (size_t)i * c.n * es, (size_t)c.n * es, hipMemcpyDeviceToDevice, s));
+        DZO_HIP(hipMemcpyAsync(o->y_slot_v(slot), (const char *)Y_dev + (size_t)i * c.n * es, (size_t)c.n * es, hipMemcpyDeviceToDevice, s));
+        if (rho_or_null) {
+            rho_host[slot] = rho_or_null[i];
+        } else {
+            double r = 0;
+            DZO_TRY(dot_blocking(s, c.n, c.dtype, o->s_slot_v(slot), o->y_slot_v(slot), c.partials(), c.host, &r));
+            rho_host[slot] = round_to_dtype(c.dtype, r);
+        }
+    }
+    DZO_HIP(hipStreamSynchronize(s));
+    DZO_HIP(hipMemcpy(o->rho, rho_host, sizeof(double) * (o->m + 1), hipMemcpyHostToDevice));
+    // the spare slots hold delta_point / delta_gradient: zero them like a fresh optimizer (:366-374)
+    o->refresh_delta_ptrs();
+    DZO_HIP(hipMemset(c.dx, 0, (size_t)o->stride * es));
+    DZO_HIP(hipMemset(c.dg, 0, (size_t)o->stride * es));
+    c.iteration_count = iteration_count;
+    o->gram_rebuild = true;
+    o->gram_stale = 0;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_stream(dzo_lbfgs_t o, void **hip_stream) {
+    DZO_REQUIRE(o && hip_stream, DZO_ERR_INVALID, "null argument");
+    *hip_stream = (void *)o->core.stream;
+    return DZO_OK;
+}
+
+}  // extern "C"

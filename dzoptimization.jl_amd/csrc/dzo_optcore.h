@@ -1,0 +1,68 @@
+// dzo_optcore.h -- state and kernels shared by the optimizers that use
+// take_backtracking_step! (src/DZOptimization.jl:107-154): L-BFGS and AdGD.
+#pragma once
+#include "dzo_common.h"
+#include "dzo_problems.h"
+
+namespace dzo {
+
+// The fields take_backtracking_step! touches (:118-152) plus the callback triple.
+struct OptCore {
+    int64_t n = 0;
+    int32_t dtype = DZO_F64;
+    hipStream_t stream = nullptr;
+
+    dzo_constraint_fn constraint = nullptr;   // :323  (NULL = `nothing`)
+    dzo_objective_fn objective = nullptr;     // :324
+    dzo_gradient_fn gradient = nullptr;       // :325
+    void *cb_ctx = nullptr;
+    dzo_problem_s *problem = nullptr;         // built-in objective; used when callbacks are NULL
+
+    bool is_stuck = false;                    // :327
+    int64_t iteration_count = 0;              // :328
+    void *x = nullptr;                        // :330 current_point (aliased)
+    void *dx = nullptr;                       // :331 delta_point
+    double f = 0;                             // :332
+    double df = 0;                            // :333
+    void *g = nullptr;                        // :334 current_gradient (aliased unless owns_g)
+    void *dg = nullptr;                       // :335 delta_gradient
+    bool owns_g = false;
+
+    double *ws = nullptr;         // device workspace: [partials 2*kMaxPartialBlocks][result 8]
+    double *host = nullptr;       // pinned host mirror of result[8]
+    int64_t max_halvings = 4096;  // build-added escape from the NaN loop
+    int64_t last_trials = 0;
+    bool search_open = false;     // begin_search called, first trial not yet taken
+
+    double *partials() const { return ws; }
+    double *result() const { return ws + 2 * kMaxPartialBlocks; }          // [0]=f_new [1]=misc
+    int32_t *flag() const { return reinterpret_cast<int32_t *>(ws + 2 * kMaxPartialBlocks + 4); }
+    bool has_objective() const { return objective != nullptr || problem != nullptr; }
+    bool has_gradient() const { return gradient != nullptr || problem != nullptr; }
+};
+
+int32_t core_alloc(OptCore &c);
+void core_free(OptCore &c);
+
+// value rounded to the element type, as the reference's objective returns T
+inline double round_to_dtype(int32_t dtype, double v) { return dtype == DZO_F32 ? (double)(float)v : v; }
+
+// :118  (deferred: the first trial writes the backup while it reads x)
+int32_t core_begin_search(OptCore &c);
+// :124 + :128   x = fma(t, dir, x_old), *changed = !isequal(x, x_old).  If `fuse_objective`
+// and the objective is a built-in problem with no constraint, f(x) is evaluated in the same
+// stream submission and returned in *f_new with a single host sync.
+int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, int32_t *changed,
+                   double *f_new, bool *f_valid);
+// :142-145
+int32_t core_accept(OptCore &c, double f_new);
+// :151
+int32_t core_reject(OptCore &c);
+// :134-138 through callbacks or the built-in problem (blocking)
+int32_t core_objective(OptCore &c, double *f_new);
+int32_t core_constraint(OptCore &c, bool *feasible);
+int32_t core_gradient(OptCore &c);
+// take_backtracking_step!(opt, step_size, dir)  :107-154
+int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir);
+
+}  // namespace dzo

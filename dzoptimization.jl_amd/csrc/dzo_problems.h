@@ -1,0 +1,22 @@
+// dzo_problems.h -- internal interface of the built-in objectives (see dzo_problems.hip).
+#pragma once
+#include "dzo_common.h"
+
+struct dzo_problem_s {
+    int32_t kind = 0;
+    int64_t n = 0;
+    int32_t dtype = DZO_F64;
+    const void *A = nullptr;   // QUADRATIC: n x n column-major symmetric, device
+    const void *c = nullptr;   // LSE: centre, device
+    double lambda = 0;
+    double *scratch = nullptr; // device partials
+    double *result = nullptr;  // device: [f, ...] inside scratch
+    double *host = nullptr;    // pinned host scalars
+};
+
+namespace dzo {
+// Enqueue f(x) on `s`; result_dev[0] receives the value (fp64, rounded to T by the caller).
+int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev);
+// Enqueue g = grad f(x) on `s`.
+int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
+}  // namespace dzo

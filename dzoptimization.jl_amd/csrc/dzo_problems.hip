@@ -1,0 +1,373 @@
+// dzo_problems.hip -- device-side synthetic objectives (K12).
+//
+// These are the *user's* callbacks in the reference (objective_function / gradient_function!,
+// src/DZOptimization.jl:324-325); the reference ships only the 2-D Rosenbrock pair
+// (legacy/ExampleFunctions.jl:10-24, README.md:25-31).  Elementwise expressions are the same
+// explicit-fma expressions as oracle/dzo_oracle_impl.h so values agree bit-for-bit per term;
+// only the (deterministic, two-stage) reduction order differs.
+#include "dzo_problems.h"
+
+namespace dzo {
+
+// ------------------------------------------------------------------ 2-D Rosenbrock (config 1)
+template <typename T>
+__global__ void rosen2d_eval_kernel(const T *__restrict__ x, double *__restrict__ result) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        T t1 = (T)1 - x[0];
+        T t2 = x[1] - x[0] * x[0];
+        result[0] = (double)(t1 * t1 + (T)100 * (t2 * t2));
+    }
+}
+template <typename T>
+__global__ void rosen2d_grad_kernel(T *__restrict__ g, const T *__restrict__ x) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        T t1 = (T)1 - x[0];
+        T t2 = x[1] - x[0] * x[0];
+        g[0] = (T)-2 * t1 - (T)400 * x[0] * t2;
+        g[1] = (T)200 * t2;
+    }
+}
+
+// ------------------------------------------------------------------ chained Rosenbrock (config 3)
+template <typename T> __device__ __forceinline__ double rosen_term(T xi, T xn) {
+    T t1 = (T)1 - xi;
+    T t2 = dfma(-xi, xi, xn);
+    return (double)dfma((T)100 * t2, t2, t1 * t1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rosen_chain_eval_kernel(int64_t n, const T *__restrict__ x,
+                                                                  double *__restrict__ partials) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[kWaves];
+    double acc = 0;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += nthreads) {
+        const int64_t i = v * N;
+        T xv[N];
+        load16(x + i, xv);
+        const T xnext = (i + N < n) ? x[i + N] : (T)0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T xn = (j + 1 < N) ? xv[(j + 1) % N] : xnext;
+            if (i + j + 1 < n) acc += rosen_term<T>(xv[j], xn);
+        }
+    }
+    const int64_t t = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t + 1 < n) acc += rosen_term<T>(x[t], x[t + 1]);
+    double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+template <typename T> __device__ __forceinline__ T rosen_grad_elem(int64_t i, int64_t n, T xp, T xi, T xn) {
+    T gi = (T)0;
+    if (i + 1 < n) {
+        T t2 = dfma(-xi, xi, xn);
+        T t1 = (T)1 - xi;
+        gi = dfma((T)-400 * xi, t2, (T)-2 * t1);
+    }
+    if (i > 0) {
+        T t2p = dfma(-xp, xp, xi);
+        gi = dfma((T)200, t2p, gi);
+    }
+    return gi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rosen_chain_grad_kernel(int64_t n, T *__restrict__ g,
+                                                                  const T *__restrict__ x) {
+    constexpr int N = Vec16<T>::N;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += nthreads) {
+        const int64_t i = v * N;
+        T xv[N], gv[N];
+        load16(x + i, xv);
+        const T xprev = (i > 0) ? x[i - 1] : (T)0;
+        const T xnext = (i + N < n) ? x[i + N] : (T)0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T xp = (j > 0) ? xv[(j + N - 1) % N] : xprev;
+            const T xn = (j + 1 < N) ? xv[(j + 1) % N] : xnext;
+            gv[j] = rosen_grad_elem<T>(i + j, n, xp, xv[j], xn);
+        }
+        store16(g + i, gv);
+    }
+    const int64_t t = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) g[t] = rosen_grad_elem<T>(t, n, t > 0 ? x[t - 1] : (T)0, x[t], t + 1 < n ? x[t + 1] : (T)0);
+}
+
+// ------------------------------------------------------------------ dense quadratic (config 2)
+// One block per column j of the column-major symmetric A: c_j = A[:,j].x (coalesced along
+// the column), g_j = c_j, and the objective partial is x_j*c_j.  No cross-block reduction.
+template <typename T, bool WRITE_G>
+__global__ __launch_bounds__(kBlock) void quadratic_kernel(int64_t n, const T *__restrict__ A,
+                                                           const T *__restrict__ x, T *__restrict__ g,
+                                                           double *__restrict__ partials) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[kWaves];
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const T *col = A + j * n;
+        double acc = 0;
+        const bool vec = ((n % N) == 0);  // column starts stay 16-B aligned
+        if (vec) {
+            for (int64_t i = (int64_t)threadIdx.x * N; i < n; i += (int64_t)kBlock * N) {
+                T av[N], xv[N];
+                load16(col + i, av);
+                load16(x + i, xv);
+#pragma unroll
+                for (int q = 0; q < N; ++q) acc = __builtin_fma((double)av[q], (double)xv[q], acc);
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < n; i += kBlock) acc = __builtin_fma((double)col[i], (double)x[i], acc);
+        }
+        double c = block_sum(acc, lds);
+        if (threadIdx.x == 0) {
+            if (WRITE_G) g[j] = (T)c;
+            else partials[j] = c * (double)x[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void finish_scaled_sum_kernel(const double *__restrict__ partials, int64_t count,
+                                                                   double scale, double *__restrict__ result) {
+    __shared__ double lds[kWaves];
+    double v = 0;
+    for (int64_t i = threadIdx.x; i < count; i += kBlock) v += partials[i];
+    double r = block_sum(v, lds);
+    if (threadIdx.x == 0) result[0] = scale * r;
+}
+
+// ------------------------------------------------------------------ log-sum-exp (config 4)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lse_max_kernel(int64_t n, const T *__restrict__ x,
+                                                         double *__restrict__ partials) {
+    __shared__ double lds[kWaves];
+    double mx = -1.7976931348623157e308;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) mx = fmax(mx, (double)x[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int w = 1; w < kWaves; ++w) r = fmax(r, lds[w]);
+        partials[blockIdx.x] = r;
+    }
+}
+__global__ __launch_bounds__(kBlock) void lse_finish_max_kernel(const double *__restrict__ partials, int count,
+                                                                double *__restrict__ result) {
+    __shared__ double lds[kWaves];
+    double mx = -1.7976931348623157e308;
+    for (int i = threadIdx.x; i < count; i += kBlock) mx = fmax(mx, partials[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int w = 1; w < kWaves; ++w) r = fmax(r, lds[w]);
+        result[0] = r;
+    }
+}
+// partials[b] = sum exp(x - mx), partials[grid + b] = sum (x - c)^2
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lse_sums_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ c,
+                                                          const double *__restrict__ mx_dev,
+                                                          double *__restrict__ partials) {
+    __shared__ double lds[kWaves];
+    const T mx = (T)mx_dev[0];
+    double se = 0, sq = 0;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        se += exp((double)(x[i] - mx));
+        const T dlt = x[i] - c[i];
+        sq = __builtin_fma((double)dlt, (double)dlt, sq);
+    }
+    double r1 = block_sum(se, lds);
+    double r2 = block_sum(sq, lds);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = r1;
+        partials[gridDim.x + blockIdx.x] = r2;
+    }
+}
+// result[0] = mx + log(se) + lambda/2 * sq ; result[1] = se
+__global__ __launch_bounds__(kBlock) void lse_finish_kernel(const double *__restrict__ partials, int count,
+                                                            const double *__restrict__ mx_dev, double lambda,
+                                                            double *__restrict__ result) {
+    __shared__ double lds[kWaves];
+    double se = reduce_partials_all(partials, count, lds);
+    double sq = reduce_partials_all(partials + count, count, lds);
+    if (threadIdx.x == 0) {
+        result[1] = se;
+        result[0] = mx_dev[0] + log(se) + 0.5 * lambda * sq;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lse_grad_kernel(int64_t n, T *__restrict__ g, const T *__restrict__ x,
+                                                          const T *__restrict__ c, const double *__restrict__ mx_dev,
+                                                          const double *__restrict__ se_dev, double lambda) {
+    const T mx = (T)mx_dev[0];
+    const double se = se_dev[0];
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        const double sm = exp((double)(x[i] - mx)) / se;
+        g[i] = (T)(sm + lambda * (double)(x[i] - c[i]));
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <typename T> static int32_t eval_async_t(dzo_problem_s *p, hipStream_t s, const T *x, double *result_dev) {
+    const int64_t n = p->n;
+    switch (p->kind) {
+    case DZO_PROBLEM_ROSENBROCK2D: {
+        DZO_TIMED("objective_rosenbrock2d", s);
+        hipLaunchKernelGGL(rosen2d_eval_kernel<T>, dim3(1), dim3(64), 0, s, x, result_dev);
+        break;
+    }
+    case DZO_PROBLEM_ROSENBROCK_CHAIN: {
+        DZO_TIMED("objective_rosenbrock_chain", s);
+        const int grid = stream_grid(n, Vec16<T>::N * 2);
+        hipLaunchKernelGGL(rosen_chain_eval_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, x, p->scratch);
+        hipLaunchKernelGGL(finish_scaled_sum_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, (int64_t)grid, 1.0,
+                           result_dev);
+        break;
+    }
+    case DZO_PROBLEM_QUADRATIC: {
+        DZO_TIMED("objective_quadratic", s);
+        const int grid = (int)(n < 65535 ? n : 65535);
+        hipLaunchKernelGGL((quadratic_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x,
+                           (T *)nullptr, p->scratch);
+        hipLaunchKernelGGL(finish_scaled_sum_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, n, 0.5, result_dev);
+        break;
+    }
+    case DZO_PROBLEM_LSE: {
+        DZO_TIMED("objective_lse", s);
+        const int grid = stream_grid(n, 4);
+        double *mx = p->scratch + 2 * kMaxPartialBlocks;       // [mx]
+        double *res = p->scratch + 2 * kMaxPartialBlocks + 2;   // [f, se]
+        hipLaunchKernelGGL(lse_max_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, x, p->scratch);
+        hipLaunchKernelGGL(lse_finish_max_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, grid, mx);
+        hipLaunchKernelGGL(lse_sums_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, x, (const T *)p->c, mx, p->scratch);
+        hipLaunchKernelGGL(lse_finish_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, grid, mx, p->lambda, res);
+        DZO_HIP(hipMemcpyAsync(result_dev, res, sizeof(double), hipMemcpyDeviceToDevice, s));
+        break;
+    }
+    default:
+        set_error("unknown problem kind %d", p->kind);
+        return DZO_ERR_INVALID;
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+template <typename T> static int32_t grad_async_t(dzo_problem_s *p, hipStream_t s, T *g, const T *x) {
+    const int64_t n = p->n;
+    switch (p->kind) {
+    case DZO_PROBLEM_ROSENBROCK2D: {
+        DZO_TIMED("gradient_rosenbrock2d", s);
+        hipLaunchKernelGGL(rosen2d_grad_kernel<T>, dim3(1), dim3(64), 0, s, g, x);
+        break;
+    }
+    case DZO_PROBLEM_ROSENBROCK_CHAIN: {
+        DZO_TIMED("gradient_rosenbrock_chain", s);
+        hipLaunchKernelGGL(rosen_chain_grad_kernel<T>, dim3(stream_grid(n, Vec16<T>::N * 2)), dim3(kBlock), 0, s, n,
+                           g, x);
+        break;
+    }
+    case DZO_PROBLEM_QUADRATIC: {
+        DZO_TIMED("gradient_quadratic", s);
+        const int grid = (int)(n < 65535 ? n : 65535);
+        hipLaunchKernelGGL((quadratic_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x, g,
+                           (double *)nullptr);
+        break;
+    }
+    case DZO_PROBLEM_LSE: {
+        DZO_TIMED("gradient_lse", s);
+        const int grid = stream_grid(n, 4);
+        double *mx = p->scratch + 2 * kMaxPartialBlocks;
+        double *res = p->scratch + 2 * kMaxPartialBlocks + 2;
+        hipLaunchKernelGGL(lse_max_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, x, p->scratch);
+        hipLaunchKernelGGL(lse_finish_max_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, grid, mx);
+        hipLaunchKernelGGL(lse_sums_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, x, (const T *)p->c, mx, p->scratch);
+        hipLaunchKernelGGL(lse_finish_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, grid, mx, p->lambda, res);
+        hipLaunchKernelGGL(lse_grad_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, g, x, (const T *)p->c, mx, res + 1,
+                           p->lambda);
+        break;
+    }
+    default:
+        set_error("unknown problem kind %d", p->kind);
+        return DZO_ERR_INVALID;
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev) {
+    DZO_DISPATCH(p->dtype, return eval_async_t<T>(p, s, (const T *)x, result_dev));
+    return DZO_OK;
+}
+int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x) {
+    DZO_DISPATCH(p->dtype, return grad_async_t<T>(p, s, (T *)g, (const T *)x));
+    return DZO_OK;
+}
+
+}  // namespace dzo
+
+using namespace dzo;
+
+extern "C" {
+
+int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A_dev, const void *c_dev,
+                           double lambda, dzo_problem_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(out, DZO_ERR_INVALID, "null out");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    DZO_REQUIRE(kind >= 0 && kind <= DZO_PROBLEM_LSE, DZO_ERR_INVALID, "unknown problem kind %d", kind);
+    DZO_REQUIRE(n >= 1, DZO_ERR_INVALID, "n must be >= 1");
+    DZO_REQUIRE(kind != DZO_PROBLEM_ROSENBROCK2D || n == 2, DZO_ERR_INVALID, "2-D Rosenbrock needs n == 2");
+    DZO_REQUIRE(kind != DZO_PROBLEM_QUADRATIC || A_dev, DZO_ERR_INVALID, "quadratic problem needs A");
+    DZO_REQUIRE(kind != DZO_PROBLEM_LSE || c_dev, DZO_ERR_INVALID, "LSE problem needs c");
+    dzo_problem_s *p = new dzo_problem_s();
+    p->kind = kind; p->n = n; p->dtype = dtype; p->A = A_dev; p->c = c_dev; p->lambda = lambda;
+    const int64_t scratch = (kind == DZO_PROBLEM_QUADRATIC ? (n > 2 * kMaxPartialBlocks ? n : 2 * kMaxPartialBlocks)
+                                                           : 2 * kMaxPartialBlocks) + 16;
+    hipError_t e = hipMalloc((void **)&p->scratch, sizeof(double) * (size_t)scratch);
+    if (e != hipSuccess) { delete p; return hip_fail(e, "hipMalloc(problem scratch)", __FILE__, __LINE__); }
+    e = hipHostMalloc((void **)&p->host, sizeof(double) * 4, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipFree(p->scratch); delete p; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+    p->result = p->scratch + scratch - 8;
+    *out = p;
+    return DZO_OK;
+}
+
+int32_t dzo_problem_destroy(dzo_problem_t p) {
+    if (!p) return DZO_OK;
+    (void)hipFree(p->scratch);
+    (void)hipHostFree(p->host);
+    delete p;
+    return DZO_OK;
+}
+
+int32_t dzo_problem_eval(dzo_problem_t p, const void *x_dev, double *f) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(p && x_dev && f, DZO_ERR_INVALID, "null argument");
+    hipStream_t s = ctx().stream;
+    DZO_TRY(problem_eval_async(p, s, x_dev, p->result));
+    DZO_HIP(hipMemcpyAsync(p->host, p->result, sizeof(double), hipMemcpyDeviceToHost, s));
+    DZO_HIP(hipStreamSynchronize(s));
+    *f = p->dtype == DZO_F32 ? (double)(float)p->host[0] : p->host[0];
+    return DZO_OK;
+}
+
+int32_t dzo_problem_grad(dzo_problem_t p, void *g_dev, const void *x_dev) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(p && x_dev && g_dev, DZO_ERR_INVALID, "null argument");
+    DZO_TRY(problem_grad_async(p, ctx().stream, g_dev, x_dev));
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,336 @@
+// dzo_vec.hip -- L1 vector primitives for gfx950.
+//
+// Each kernel is one HBM pass: 16-byte-per-lane coalesced loads (1 KiB per wave
+// instruction), 4 independent vectors in flight per thread, grid capped at 8 blocks per CU
+// with a grid-stride loop.  Reductions are two-stage and deterministic.
+#include "dzo_common.h"
+
+namespace dzo {
+
+constexpr int kUnroll = 4;  // independent 16-B vectors in flight per thread and per stream
+
+template <typename T> inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Iterate this thread's share of [0, n): vector body on N-element groups, scalar body on the
+// tail (and on everything when the operands are not 16-byte aligned, VEC = false).
+template <typename T, bool VEC, typename VecBody, typename ScalarBody>
+__device__ __forceinline__ void stream_loop(int64_t n, VecBody vec_body, ScalarBody scalar_body) {
+    constexpr int N = Vec16<T>::N;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    if constexpr (VEC) {
+        const int64_t nvec = n / N;
+        // block-cyclic with kUnroll vectors per thread per trip: consecutive lanes touch
+        // consecutive 16-B chunks, consecutive blocks touch consecutive 4-KiB spans
+        for (int64_t base = (int64_t)blockIdx.x * kBlock * kUnroll; base < nvec;
+             base += nthreads * kUnroll) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
+                if (v < nvec) vec_body(v * N);
+            }
+        }
+        const int64_t t = nvec * N + tid;
+        if (t < n) scalar_body(t);
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) scalar_body(i);
+    }
+}
+
+// ---------------------------------------------------------------------------- elementwise
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void axpy_kernel(int64_t n, T a, const T *__restrict__ x, T *__restrict__ y) {
+    constexpr int N = Vec16<T>::N;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T xv[N], yv[N];
+            load16(x + i, xv);
+            load16(y + i, yv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) yv[j] = dfma(a, xv[j], yv[j]);
+            store16(y + i, yv);
+        },
+        [&](int64_t i) { y[i] = dfma(a, x[i], y[i]); });
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void axpy_oop_kernel(int64_t n, T *__restrict__ dst, T a, const T *__restrict__ x,
+                                                          const T *__restrict__ y) {
+    constexpr int N = Vec16<T>::N;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T xv[N], yv[N];
+            load16(x + i, xv);
+            load16(y + i, yv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) yv[j] = dfma(a, xv[j], yv[j]);
+            store16(dst + i, yv);
+        },
+        [&](int64_t i) { dst[i] = dfma(a, x[i], y[i]); });
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void axpby_kernel(int64_t n, T a, const T *__restrict__ x, T b, T *__restrict__ y) {
+    constexpr int N = Vec16<T>::N;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T xv[N], yv[N];
+            load16(x + i, xv);
+            load16(y + i, yv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) yv[j] = dfma(a, xv[j], b * yv[j]);
+            store16(y + i, yv);
+        },
+        [&](int64_t i) { y[i] = dfma(a, x[i], b * y[i]); });
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void scal_oop_kernel(int64_t n, T *dst, T a, const T *x) {
+    constexpr int N = Vec16<T>::N;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T xv[N];
+            load16(x + i, xv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) xv[j] = a * xv[j];
+            store16(dst + i, xv);
+        },
+        [&](int64_t i) { dst[i] = a * x[i]; });
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void fill_kernel(int64_t n, T a, T *x) {
+    constexpr int N = Vec16<T>::N;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T xv[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) xv[j] = a;
+            store16(x + i, xv);
+        },
+        [&](int64_t i) { x[i] = a; });
+}
+
+// ---------------------------------------------------------------------------- reductions
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void dot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y,
+                                                     double *__restrict__ partials) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[kWaves];
+    double acc = 0;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T xv[N], yv[N];
+            load16(x + i, xv);
+            load16(y + i, yv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = __builtin_fma((double)xv[j], (double)yv[j], acc);
+        },
+        [&](int64_t i) { acc = __builtin_fma((double)x[i], (double)y[i], acc); });
+    double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// second stage: one block sums `count` partials in a fixed order
+__global__ __launch_bounds__(kBlock) void finish_sum_kernel(const double *__restrict__ partials, int count,
+                                                            double *__restrict__ result) {
+    __shared__ double lds[kWaves];
+    double r = reduce_partials_all(partials, count, lds);
+    if (threadIdx.x == 0) result[0] = r;
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void isequal_kernel(int64_t n, const T *__restrict__ a, const T *__restrict__ b,
+                                                         int32_t *__restrict__ differs) {
+    constexpr int N = Vec16<T>::N;
+    bool diff = false;
+    stream_loop<T, VEC>(
+        n,
+        [&](int64_t i) {
+            T av[N], bv[N];
+            load16(a + i, av);
+            load16(b + i, bv);
+#pragma unroll
+            for (int j = 0; j < N; ++j) diff |= !is_equal(av[j], bv[j]);
+        },
+        [&](int64_t i) { diff |= !is_equal(a[i], b[i]); });
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(differs, 1);  // boolean: order-free
+}
+
+// ---------------------------------------------------------------------------- launchers
+#define DZO_LAUNCH_VEC(kernel, T, vec_ok, grid, stream, ...)                              \
+    do {                                                                                  \
+        if (vec_ok) hipLaunchKernelGGL((kernel<T, true>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<T, false>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__);       \
+    } while (0)
+
+template <typename T> void launch_axpy(hipStream_t s, int64_t n, T a, const T *x, T *y) {
+    if (n <= 0) return;
+    DZO_TIMED("axpy", s);
+    const bool v = aligned16<T>(x) && aligned16<T>(y);
+    DZO_LAUNCH_VEC(axpy_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, a, x, y);
+}
+template <typename T> void launch_axpy_oop(hipStream_t s, int64_t n, T *dst, T a, const T *x, const T *y) {
+    if (n <= 0) return;
+    DZO_TIMED("trial_point", s);
+    const bool v = aligned16<T>(x) && aligned16<T>(y) && aligned16<T>(dst);
+    DZO_LAUNCH_VEC(axpy_oop_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, dst, a, x, y);
+}
+template <typename T> void launch_axpby(hipStream_t s, int64_t n, T a, const T *x, T b, T *y) {
+    if (n <= 0) return;
+    DZO_TIMED("axpby", s);
+    const bool v = aligned16<T>(x) && aligned16<T>(y);
+    DZO_LAUNCH_VEC(axpby_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, a, x, b, y);
+}
+template <typename T> void launch_scal_oop(hipStream_t s, int64_t n, T *dst, T a, const T *x) {
+    if (n <= 0) return;
+    DZO_TIMED("scal", s);
+    const bool v = aligned16<T>(x) && aligned16<T>(dst);
+    DZO_LAUNCH_VEC(scal_oop_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, dst, a, x);
+}
+template <typename T> void launch_scal(hipStream_t s, int64_t n, T a, T *x) { launch_scal_oop<T>(s, n, x, a, x); }
+template <typename T> void launch_fill(hipStream_t s, int64_t n, T a, T *x) {
+    if (n <= 0) return;
+    DZO_TIMED("fill", s);
+    const bool v = aligned16<T>(x);
+    DZO_LAUNCH_VEC(fill_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, a, x);
+}
+template <typename T>
+void launch_dot(hipStream_t s, int64_t n, const T *x, const T *y, double *partials_dev, double *result_dev) {
+    DZO_TIMED("dot", s);
+    const int grid = stream_grid(n > 0 ? n : 1, Vec16<T>::N * kUnroll);
+    const bool v = aligned16<T>(x) && aligned16<T>(y);
+    DZO_LAUNCH_VEC(dot_kernel, T, v, grid, s, n, x, y, partials_dev);
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(kBlock), 0, s, partials_dev, grid, result_dev);
+}
+template <typename T>
+void launch_isequal(hipStream_t s, int64_t n, const T *a, const T *b, int32_t *differs_dev) {
+    if (n <= 0) return;
+    DZO_TIMED("isequal", s);
+    const bool v = aligned16<T>(a) && aligned16<T>(b);
+    DZO_LAUNCH_VEC(isequal_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, a, b, differs_dev);
+}
+
+#define DZO_INSTANTIATE(T)                                                                   \
+    template void launch_axpy<T>(hipStream_t, int64_t, T, const T *, T *);                   \
+    template void launch_axpy_oop<T>(hipStream_t, int64_t, T *, T, const T *, const T *);    \
+    template void launch_axpby<T>(hipStream_t, int64_t, T, const T *, T, T *);               \
+    template void launch_scal<T>(hipStream_t, int64_t, T, T *);                              \
+    template void launch_scal_oop<T>(hipStream_t, int64_t, T *, T, const T *);               \
+    template void launch_fill<T>(hipStream_t, int64_t, T, T *);                              \
+    template void launch_dot<T>(hipStream_t, int64_t, const T *, const T *, double *, double *); \
+    template void launch_isequal<T>(hipStream_t, int64_t, const T *, const T *, int32_t *);
+DZO_INSTANTIATE(double)
+DZO_INSTANTIATE(float)
+
+int32_t dot_blocking(hipStream_t s, int64_t n, int32_t dtype, const void *x, const void *y,
+                     double *partials_dev, double *host_pinned, double *out) {
+    DZO_DISPATCH(dtype, launch_dot<T>(s, n, (const T *)x, (const T *)y, partials_dev, partials_dev + kMaxPartialBlocks));
+    DZO_HIP(hipMemcpyAsync(host_pinned, partials_dev + kMaxPartialBlocks, sizeof(double), hipMemcpyDeviceToHost, s));
+    DZO_HIP(hipStreamSynchronize(s));
+    *out = *host_pinned;
+    return DZO_OK;
+}
+
+}  // namespace dzo
+
+using namespace dzo;
+
+// ---------------------------------------------------------------------------- C ABI
+extern "C" {
+
+#define DZO_CHECK_VEC(n, ...)                                              \
+    DZO_TRY(require_init());                                               \
+    DZO_REQUIRE((n) >= 0, DZO_ERR_INVALID, "negative length");             \
+    {                                                                      \
+        const void *ptrs__[] = {__VA_ARGS__};                              \
+        for (const void *p__ : ptrs__)                                     \
+            DZO_REQUIRE(p__ != nullptr || (n) == 0, DZO_ERR_INVALID, "null device pointer"); \
+    }
+
+int32_t dzo_axpy(int64_t n, int32_t dtype, double alpha, const void *x_dev, void *y_dev) {
+    DZO_CHECK_VEC(n, x_dev, y_dev);
+    DZO_DISPATCH(dtype, launch_axpy<T>(ctx().stream, n, (T)alpha, (const T *)x_dev, (T *)y_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+int32_t dzo_axpby(int64_t n, int32_t dtype, double alpha, const void *x_dev, double beta, void *y_dev) {
+    DZO_CHECK_VEC(n, x_dev, y_dev);
+    DZO_DISPATCH(dtype, launch_axpby<T>(ctx().stream, n, (T)alpha, (const T *)x_dev, (T)beta, (T *)y_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+int32_t dzo_scal(int64_t n, int32_t dtype, double alpha, void *x_dev) {
+    DZO_CHECK_VEC(n, x_dev);
+    DZO_DISPATCH(dtype, launch_scal<T>(ctx().stream, n, (T)alpha, (T *)x_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+int32_t dzo_copy(int64_t n, int32_t dtype, const void *src_dev, void *dst_dev) {
+    DZO_CHECK_VEC(n, src_dev, dst_dev);
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    if (n > 0) {
+        DZO_HIP(hipMemcpyAsync(dst_dev, src_dev, (size_t)n * dtype_size(dtype), hipMemcpyDeviceToDevice, ctx().stream));
+        DZO_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_fill(int64_t n, int32_t dtype, double value, void *x_dev) {
+    DZO_CHECK_VEC(n, x_dev);
+    DZO_DISPATCH(dtype, launch_fill<T>(ctx().stream, n, (T)value, (T *)x_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+int32_t dzo_dot(int64_t n, int32_t dtype, const void *x_dev, const void *y_dev, double *result) {
+    DZO_CHECK_VEC(n, x_dev, y_dev);
+    DZO_REQUIRE(result, DZO_ERR_INVALID, "null result");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    return dot_blocking(ctx().stream, n, dtype, x_dev, y_dev, ctx().scratch, ctx().host_scalar, result);
+}
+
+int32_t dzo_nrm2(int64_t n, int32_t dtype, const void *x_dev, double *result) {
+    double ss = 0;
+    DZO_TRY(dzo_dot(n, dtype, x_dev, x_dev, &ss));
+    // sqrt of the fp64 sum of squares, rounded to T as LinearAlgebra.norm returns T
+    *result = dtype == DZO_F32 ? (double)sqrtf((float)ss) : sqrt(ss);
+    return DZO_OK;
+}
+
+int32_t dzo_isequal(int64_t n, int32_t dtype, const void *a_dev, const void *b_dev, int32_t *result) {
+    DZO_CHECK_VEC(n, a_dev, b_dev);
+    DZO_REQUIRE(result, DZO_ERR_INVALID, "null result");
+    int32_t *flag = reinterpret_cast<int32_t *>(ctx().scratch);
+    DZO_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), ctx().stream));
+    DZO_DISPATCH(dtype, launch_isequal<T>(ctx().stream, n, (const T *)a_dev, (const T *)b_dev, flag));
+    DZO_HIP(hipGetLastError());
+    int32_t *host = reinterpret_cast<int32_t *>(ctx().host_scalar);
+    DZO_HIP(hipMemcpyAsync(host, flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx().stream));
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    *result = (*host == 0) ? 1 : 0;
+    return DZO_OK;
+}
+
+int32_t dzo_trial_point(int64_t n, int32_t dtype, void *dst_dev, double t, const void *d_dev, const void *x_dev) {
+    DZO_CHECK_VEC(n, dst_dev, d_dev, x_dev);
+    DZO_DISPATCH(dtype, launch_axpy_oop<T>(ctx().stream, n, (T *)dst_dev, (T)t, (const T *)d_dev, (const T *)x_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+/*
+ * dzo.h -- C ABI of the MI355X-native BFGS / L-BFGS step!() hot path.
+ *
+ * This is the drop-in boundary for dzhang314/DZOptimization.jl's in-place quasi-Newton
+ * step.  The reference has NO FFI: its boundary is Julia multiple
+ * dispatch on the array type parameter A<:AbstractArray{T} plus three user callbacks
+ * (src/DZOptimization.jl:321-325,347-356).  A Julia host reaches this library with `ccall`
+ * (dzoptimization.jl_amd/julia/DZOptimizationAMD.jl; INTEGRATION.md shows the binding); the
+ * Python mirror used by the tests binds the same symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns int32_t: 0 = DZO_OK, otherwise a DZO_ERR_* code;
+ *     dzo_last_error() gives the message of the calling thread's last failure.  The
+ *     reference signals only through @assert (AssertionError); those map to DZO_ERR_ASSERT.
+ *   - plain pointers and sizes only.  `*_dev` pointers are device (HBM) addresses, everything
+ *     else is host memory.  dtype is DZO_F32 or DZO_F64; scalars cross the ABI as double.
+ *   - vectors are dense, contiguous, length n (N-d Julia arrays are treated linearly, as the
+ *     reference does); matrices are n x n column-major (legacy/DZOptimization.jl:746).
+ *   - one HIP stream per optimizer handle; calls on one handle must be serialised by the
+ *     caller, different handles may be driven from different host threads (the reference's
+ *     "independent optimizers" model, README.md:12).
+ *   - there is no CPU fallback: every entry point needs the HIP device selected by dzo_init.
+ *
+ * All citations are file:line in the reference snapshot (2025-09-05).
+ */
+#ifndef DZO_H
+#define DZO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DZO_VERSION 100 /* 0.1.0 */
+
+/* element types (type parameter T of the reference's optimizers) */
+#define DZO_F32 0
+#define DZO_F64 1
+
+/* status codes */
+#define DZO_OK 0
+#define DZO_ERR_INVALID 1     /* bad argument */
+#define DZO_ERR_HIP 2         /* a HIP runtime call failed */
+#define DZO_ERR_ASSERT 3      /* a reference @assert would have fired */
+#define DZO_ERR_NOMEM 4
+#define DZO_ERR_UNSUPPORTED 5
+#define DZO_ERR_STATE 6       /* entry point called out of sequence */
+
+/* built-in synthetic objectives; the reference's user callbacks */
+#define DZO_PROBLEM_ROSENBROCK2D 0      /* legacy/ExampleFunctions.jl:10-24, README.md:25-31 */
+#define DZO_PROBLEM_ROSENBROCK_CHAIN 1  /* sum 100(x[i+1]-x[i]^2)^2 + (1-x[i])^2 */
+#define DZO_PROBLEM_QUADRATIC 2         /* 1/2 x'Ax, dense symmetric A */
+#define DZO_PROBLEM_LSE 3               /* log sum exp(x) + lambda/2 |x-c|^2 */
+
+/* how compute_lbfgs_step_direction! is executed on the device */
+#define DZO_TWOLOOP_CHAIN 0 /* 2k+1 fused axpy+dot links in the reference's op order */
+#define DZO_TWOLOOP_GRAM 1  /* one Gram pass + O(k^2) scalar recurrence + one combine pass */
+
+/* dense BFGS last_step_type (legacy/DZOptimization.jl:727-731) */
+#define DZO_STEP_NULL 0
+#define DZO_STEP_GRADIENT_DESCENT 1
+#define DZO_STEP_BFGS 2
+
+typedef struct dzo_problem_s *dzo_problem_t;
+typedef struct dzo_lbfgs_s *dzo_lbfgs_t;
+typedef struct dzo_adgd_s *dzo_adgd_t;
+typedef struct dzo_bfgs_s *dzo_bfgs_t;
+typedef struct dzo_bfgs_batch_s *dzo_bfgs_batch_t;
+
+/* User callbacks, in the reference's order constraint / objective / gradient
+ * (src/DZOptimization.jl:323-325).  They receive DEVICE pointers and must enqueue their
+ * work on the stream returned by dzo_*_stream() or synchronise themselves.
+ *   constraint_function!(x)::Bool  (:71-72,134-135)  -> nonzero = feasible; NULL = `nothing`
+ *   objective_function(x)::T       (:80,138)         -> value as double
+ *   gradient_function!(g, x)       (:87,479)         -> return ignored */
+typedef int32_t (*dzo_constraint_fn)(void *ctx, void *x_dev);
+typedef double (*dzo_objective_fn)(void *ctx, const void *x_dev);
+typedef void (*dzo_gradient_fn)(void *ctx, void *g_dev, const void *x_dev);
+
+/* ---------------------------------------------------------------------------------------
+ * lifecycle
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_init(int32_t device);
+int32_t dzo_shutdown(void);
+int32_t dzo_version(void);
+const char *dzo_last_error(void);
+int32_t dzo_device_info(char *name, int32_t name_len, int32_t *compute_units, int64_t *hbm_bytes);
+int32_t dzo_synchronize(void);
+
+/* Per-kernel HIP-event timing on the launching stream (bench.py's roofline leg).
+ * Entry i of the table is one kernel name with its launch count and total milliseconds. */
+int32_t dzo_profile_enable(int32_t on);
+int32_t dzo_profile_reset(void);
+int32_t dzo_profile_count(int32_t *count);
+int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launches, double *total_ms);
+
+/* ---------------------------------------------------------------------------------------
+ * device memory (what `similar` / `copy` / `Array(x)` do for a GPU array type A)
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_malloc(void **ptr_dev, int64_t bytes);
+int32_t dzo_free(void *ptr_dev);
+int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes);
+int32_t dzo_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes);
+int32_t dzo_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes);
+
+/* ---------------------------------------------------------------------------------------
+ * L1 vector primitives: the method set a Julia `HipVector{T}` needs so the
+ * reference's generic code runs unmodified.  Blocking where they return a host scalar.
+ * ------------------------------------------------------------------------------------- */
+/* y += alpha*x            LinearAlgebra.axpy!  src/DZOptimization.jl:70,124,441,448 */
+int32_t dzo_axpy(int64_t n, int32_t dtype, double alpha, const void *x_dev, void *y_dev);
+/* y = alpha*x + beta*y    LinearAlgebra.axpby! src/DZOptimization.jl:145,308,480 */
+int32_t dzo_axpby(int64_t n, int32_t dtype, double alpha, const void *x_dev, double beta, void *y_dev);
+/* x *= alpha              LinearAlgebra.rmul!  src/DZOptimization.jl:387,444 */
+int32_t dzo_scal(int64_t n, int32_t dtype, double alpha, void *x_dev);
+/* dst = src               Base.copy!           src/DZOptimization.jl:69,118,151,306,386,438,478 */
+int32_t dzo_copy(int64_t n, int32_t dtype, const void *src_dev, void *dst_dev);
+/* x .= value              Base.fill!           src/DZOptimization.jl:222,227,369,374,384 */
+int32_t dzo_fill(int64_t n, int32_t dtype, double value, void *x_dev);
+/* x.y                     LinearAlgebra.dot    src/DZOptimization.jl:88,440,444,447,505 */
+int32_t dzo_dot(int64_t n, int32_t dtype, const void *x_dev, const void *y_dev, double *result);
+/* |x|_2                   LinearAlgebra.norm   src/DZOptimization.jl:230,292,294,381 */
+int32_t dzo_nrm2(int64_t n, int32_t dtype, const void *x_dev, double *result);
+/* isequal(a, b)           Base.isequal         src/DZOptimization.jl:128 (NaN==NaN, -0.0!=0.0) */
+int32_t dzo_isequal(int64_t n, int32_t dtype, const void *a_dev, const void *b_dev, int32_t *result);
+/* dst = t*d + x           out-of-place trial point, legacy/Kernels.jl:127-135,
+ *                         legacy/DZOptimization.jl:33, src/DZOptimization.jl:69-70 */
+int32_t dzo_trial_point(int64_t n, int32_t dtype, void *dst_dev, double t, const void *d_dev,
+                        const void *x_dev);
+
+/* ---------------------------------------------------------------------------------------
+ * built-in objectives (device-side twins of the user's callbacks)
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A_dev,
+                           const void *c_dev, double lambda, dzo_problem_t *out);
+int32_t dzo_problem_destroy(dzo_problem_t p);
+int32_t dzo_problem_eval(dzo_problem_t p, const void *x_dev, double *f);
+int32_t dzo_problem_grad(dzo_problem_t p, void *g_dev, const void *x_dev);
+
+/* ---------------------------------------------------------------------------------------
+ * LBFGSOptimizer  (src/DZOptimization.jl:321-509)
+ * ------------------------------------------------------------------------------------- */
+/* Full constructor (:347-397).  ALIASES x_dev and g_dev as current_point / current_gradient
+ * exactly as the reference aliases initial_point / initial_gradient (:393,:395); allocates
+ * delta_point, delta_gradient (zero-filled), step_direction = -step*g/|g| and the (s, y)
+ * ring.  initial_step_length <= 0 -> DZO_ERR_ASSERT (:380).  history_length must be 1..64. */
+int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void *x_dev,
+                         void *g_dev, double initial_objective_value,
+                         double initial_step_length, dzo_lbfgs_t *out);
+/* Convenience constructor (:400-427): checks the constraint, evaluates f0 and g0 through the
+ * callbacks into a library-owned gradient vector, then calls the full constructor. */
+int32_t dzo_lbfgs_create_callbacks(dzo_constraint_fn constraint, dzo_objective_fn objective,
+                                   dzo_gradient_fn gradient, void *ctx, int64_t n,
+                                   int32_t history_length, int32_t dtype, void *x_dev,
+                                   double initial_step_length, dzo_lbfgs_t *out);
+/* Same with a built-in problem as the callback triple (constraint = nothing). */
+int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, void *x_dev,
+                                 double initial_step_length, dzo_lbfgs_t *out);
+int32_t dzo_lbfgs_destroy(dzo_lbfgs_t opt);
+int32_t dzo_lbfgs_set_callbacks(dzo_lbfgs_t opt, dzo_constraint_fn constraint,
+                                dzo_objective_fn objective, dzo_gradient_fn gradient, void *ctx);
+int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t opt, dzo_problem_t problem);
+int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t opt, int32_t mode);
+int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
+
+/* step!(opt) (:454-509) -- the whole step, callbacks invoked from inside. */
+int32_t dzo_lbfgs_step(dzo_lbfgs_t opt);
+
+/* Split entry points for hosts that drive the loop themselves (the objective / gradient
+ * callbacks run between them, :138 and :479):
+ *   direction      compute_lbfgs_step_direction! (:430-451), K1
+ *   begin_search   copy!(delta_point, current_point) (:118)
+ *   trial          axpy!(t, d, x) from the saved point + isequal test (:124,:128), K2
+ *   accept         delta_f, f, delta_point = x - x_old (:142-145), K3
+ *   reject         copy!(x, delta_point) (:151), K4
+ *   pre_gradient   copy!(delta_gradient, g) (:478)
+ *   post_gradient  delta_gradient = g - delta_gradient, ring push, rho, count (:480-507), K5+K6 */
+int32_t dzo_lbfgs_direction(dzo_lbfgs_t opt);
+int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t opt);
+int32_t dzo_lbfgs_trial(dzo_lbfgs_t opt, double step_size, int32_t *changed);
+int32_t dzo_lbfgs_accept(dzo_lbfgs_t opt, double next_objective_value);
+int32_t dzo_lbfgs_reject(dzo_lbfgs_t opt);
+int32_t dzo_lbfgs_pre_gradient(dzo_lbfgs_t opt);
+int32_t dzo_lbfgs_post_gradient(dzo_lbfgs_t opt);
+
+/* State (all of it is public in the reference, README.md:11).
+ * get_i:   0 is_stuck  1 iteration_count  2 n  3 history_length  4 length(history)
+ *          5 objective evaluations in the last step  6 two-loop mode  7 dtype
+ * get_s:   0 current_objective_value  1 delta_objective_value
+ * get_ptr: 0 current_point  1 delta_point  2 current_gradient  3 delta_gradient
+ *          4 step_direction  5 delta_point_history[idx]  6 delta_gradient_history[idx]
+ *          (idx 0 = newest, the reference's index 1) */
+int32_t dzo_lbfgs_get_i(dzo_lbfgs_t opt, int32_t what, int64_t *value);
+int32_t dzo_lbfgs_get_s(dzo_lbfgs_t opt, int32_t what, double *value);
+int32_t dzo_lbfgs_set_s(dzo_lbfgs_t opt, int32_t what, double value);
+int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t opt, int32_t is_stuck);
+int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t opt, int32_t what, int32_t idx, void **ptr_dev);
+/* rho_history / alpha_history (:341-342), newest first; *count receives the length */
+int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t opt, double *out, int32_t capacity, int32_t *count);
+int32_t dzo_lbfgs_get_alpha(dzo_lbfgs_t opt, double *out, int32_t capacity, int32_t *count);
+/* Install k pairs (rows of S_dev / Y_dev, k x n row-major, row 0 newest) and, optionally,
+ * their rho = s.y values; used for checkpoint/resume and frozen-state parity tests. */
+int32_t dzo_lbfgs_set_history(dzo_lbfgs_t opt, int32_t k, const void *S_dev, const void *Y_dev,
+                              const double *rho_or_null, int64_t iteration_count);
+int32_t dzo_lbfgs_stream(dzo_lbfgs_t opt, void **hip_stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LineSearchEvaluator call (src/DZOptimization.jl:65-92): trial point x + t*d, objective,
+ * Armijo quotient (:84) and, optionally, trial gradient + curvature quotient (:85-90).
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_line_search_eval(dzo_constraint_fn constraint, dzo_objective_fn objective,
+                             dzo_gradient_fn gradient, void *ctx, int64_t n, int32_t dtype,
+                             const void *x_dev, double current_objective_value,
+                             const void *d_dev, double overlap, double step_size,
+                             int32_t compute_gradient, void *trial_point_dev,
+                             void *trial_gradient_dev, double *trial_objective_value,
+                             double *improvement_ratio, double *slope_ratio);
+
+/* ---------------------------------------------------------------------------------------
+ * AdGDOptimizer (src/DZOptimization.jl:179-312) -- SURVEY.md 8(f) rank 1
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev,
+                        double initial_objective_value, double initial_step_length,
+                        dzo_adgd_t *out);
+int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initial_step_length,
+                                dzo_adgd_t *out);
+int32_t dzo_adgd_destroy(dzo_adgd_t opt);
+int32_t dzo_adgd_set_callbacks(dzo_adgd_t opt, dzo_constraint_fn constraint,
+                               dzo_objective_fn objective, dzo_gradient_fn gradient, void *ctx);
+int32_t dzo_adgd_step(dzo_adgd_t opt);
+/* get_i: 0 is_stuck 1 iteration_count 2 n;  get_s: 0 f 1 delta_f 2 current_step_size
+ * 3 previous_step_size;  get_ptr: 0 x 1 delta_point 2 g 3 delta_gradient */
+int32_t dzo_adgd_get_i(dzo_adgd_t opt, int32_t what, int64_t *value);
+int32_t dzo_adgd_get_s(dzo_adgd_t opt, int32_t what, double *value);
+int32_t dzo_adgd_get_ptr(dzo_adgd_t opt, int32_t what, void **ptr_dev);
+
+/* ---------------------------------------------------------------------------------------
+ * BFGSOptimizer (legacy/DZOptimization.jl:733-994; README.md:33-41)
+ * ------------------------------------------------------------------------------------- */
+/* Constructor (:762-810): COPIES x0 (:769), evaluates f0 / g0, H0 = I (:783), d0 = g (:784),
+ * last_step_length = initial_step_length (:779).  Argument order objective, gradient,
+ * constraint follows :762-766.  constraint may be NULL (NULL_CONSTRAINT, :759). */
+int32_t dzo_bfgs_create_callbacks(dzo_objective_fn objective, dzo_gradient_fn gradient,
+                                  dzo_constraint_fn constraint, void *ctx, int64_t n,
+                                  int32_t dtype, const void *x0_dev, double initial_step_length,
+                                  dzo_bfgs_t *out);
+int32_t dzo_bfgs_create_problem(dzo_problem_t problem, const void *x0_dev,
+                                double initial_step_length, dzo_bfgs_t *out);
+int32_t dzo_bfgs_destroy(dzo_bfgs_t opt);
+/* step!(opt) (:891-994): competitive quadratic line searches, accept / reset / terminate. */
+int32_t dzo_bfgs_step(dzo_bfgs_t opt);
+/* update_inverse_hessian! (:864-889) on raw device arrays: rescales d in place (:874),
+ * t = H*dg into scratch (:875), rank-2 update of H (:878-886).  If g_dev and d_next_dev are
+ * non-NULL the next direction d_next = H_new*g (:958-960) is produced in the same pass. */
+int32_t dzo_bfgs_update(int64_t n, int32_t dtype, void *H_dev, double step_length, void *d_dev,
+                        const void *dg_dev, void *scratch_dev, const void *g_dev,
+                        void *d_next_dev);
+/* out = H*v for symmetric H (mul!, :875,:958-960) */
+int32_t dzo_symv(int64_t n, int32_t dtype, const void *H_dev, const void *v_dev, void *out_dev);
+/* quadratic_line_search(functor, f0, t0) as defined in DESIGN.md from
+ * find_three_point_bracket (:49-172) + QuadraticLineSearch (:191-216); direction 0 = -g, 1 = -d */
+int32_t dzo_bfgs_line_search(dzo_bfgs_t opt, int32_t use_gradient_direction, double t0,
+                             double *t_best, double *f_best);
+int32_t dzo_bfgs_set_max_increases(dzo_bfgs_t opt, int32_t max_increases);
+/* get_i: 0 has_terminated (== has_converged, README.md:38) 1 iteration_count 2 n
+ *        3 last_step_type 4 objective evaluations so far
+ * get_s: 0 current_objective_value 1 last_step_length
+ * get_ptr: 0 current_point 1 delta_point 2 current_gradient 3 delta_gradient
+ *          4 next_step_direction 5 approximate_inverse_hessian 6 scratch */
+int32_t dzo_bfgs_get_i(dzo_bfgs_t opt, int32_t what, int64_t *value);
+int32_t dzo_bfgs_get_s(dzo_bfgs_t opt, int32_t what, double *value);
+int32_t dzo_bfgs_get_ptr(dzo_bfgs_t opt, int32_t what, void **ptr_dev);
+
+/* ---------------------------------------------------------------------------------------
+ * Batched dense BFGS: B independent BFGSOptimizer instances on one device, one workgroup per
+ * instance, the whole step (both line searches included) on the device.  "run multiple
+ * optimizers in parallel" (README.md:12); sharding across GPUs is one process per GPU with
+ * the convergence flag all-reduced by the host over RCCL (DESIGN.md section e).
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype,
+                              const void *x0_dev /* batch x n row-major */,
+                              double initial_step_length, dzo_bfgs_batch_t *out);
+int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b);
+/* runs `steps` synchronous step! calls on every live instance; *all_done = 1 when every
+ * instance has_terminated.  Does not block unless all_done is non-NULL. */
+int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done);
+/* get_ptr: 0 x (B x n) 1 g 2 H (B x n x n col-major) 3 f (B doubles) 4 has_terminated (B int32)
+ *          5 iteration_count (B int64) 6 delta_point 7 delta_gradient 8 d 9 last_step_length
+ *          10 last_step_type (B int32) */
+int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev);
+int32_t dzo_bfgs_batch_count_active(dzo_bfgs_batch_t b, int64_t *active);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DZO_H */

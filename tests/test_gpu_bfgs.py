@@ -1,0 +1,235 @@
+"""GPU parity tests for dense BFGS (config 1, config 2), AdGD and the batched mode (config 5),
+through the C ABI.  The rank-2 update is evaluated in the reference's rounding order, so H is
+compared tightly; H stays EXACTLY symmetric (checked bitwise)."""
+import numpy as np
+import pytest
+
+from dzo_loader import dzo
+from oracle import mp_twoloop, oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _spd(n, seed):
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, n))
+    H = M @ M.T / n + np.eye(n)
+    return 0.5 * (H + H.T)
+
+
+# ------------------------------------------------------------------------------ K8 / K9
+@pytest.mark.parametrize("n", [2, 3, 8, 63, 64, 257, 1024])
+def test_update_inverse_hessian_matches_oracle(n):
+    rng = np.random.default_rng(n)
+    H0 = _spd(n, n)
+    d, y, g = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    lam = -0.37 if d @ y < 0 else 0.37
+    H_ref, d_ref = np.asfortranarray(H0.copy()), d.copy()
+    t_ref = orc.bfgs_update(H_ref, lam, d_ref, y.copy())
+    Hd, dd, yd, gd = (dzo.DeviceArray.from_host(a) for a in (H0, d, y, g))   # H0 symmetric: layouts coincide
+    scratch, dnext = dzo.DeviceArray(n), dzo.DeviceArray(n)
+    dzo.update_inverse_hessian_(Hd, lam, dd, yd, scratch, gd, dnext)
+    H_gpu = Hd.to_host()
+    assert np.array_equal(H_gpu, H_gpu.T)                           # exact symmetry
+    assert rel(H_gpu, np.ascontiguousarray(H_ref)) <= 1e-13
+    assert rel(dd.to_host(), d_ref) <= 1e-14                        # :874 side effect
+    assert rel(scratch.to_host(), t_ref) <= 1e-13                   # t = H*dg
+    assert rel(dnext.to_host(), H_gpu @ g) <= 1e-13                 # fused next direction (:958-960)
+    s = lam * d
+    assert np.allclose(H_gpu @ y, s, rtol=1e-9, atol=1e-11)         # secant equation
+    # symv on its own
+    out = dzo.symv_(dzo.DeviceArray(n), Hd, gd).to_host()
+    assert rel(out, H_gpu @ g) <= 1e-13
+
+
+def test_update_against_mpmath_arbiter():
+    n = 12
+    rng = np.random.default_rng(5)
+    H0 = _spd(n, 5)
+    d, y = rng.standard_normal(n), rng.standard_normal(n)
+    lam = 0.5 if d @ y > 0 else -0.5
+    H_mp = mp_twoloop.bfgs_update(H0.copy(), lam, d, y)
+    Hd = dzo.DeviceArray.from_host(H0)
+    dzo.update_inverse_hessian_(Hd, lam, dzo.DeviceArray.from_host(d), dzo.DeviceArray.from_host(y), dzo.DeviceArray(n))
+    assert rel(Hd.to_host(), H_mp) <= 1e-13
+
+
+def test_update_fp32():
+    n = 128
+    rng = np.random.default_rng(9)
+    H0 = _spd(n, 9).astype(np.float32)
+    d, y = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    lam = 0.25 if float(d @ y) > 0 else -0.25
+    H_ref, d_ref = np.asfortranarray(H0.copy()), d.copy()
+    orc.bfgs_update(H_ref, lam, d_ref, y.copy())
+    Hd = dzo.DeviceArray.from_host(H0)
+    dzo.update_inverse_hessian_(Hd, lam, dzo.DeviceArray.from_host(d), dzo.DeviceArray.from_host(y),
+                                dzo.DeviceArray(n, np.float32))
+    assert rel(Hd.to_host().astype(np.float64), np.ascontiguousarray(H_ref).astype(np.float64)) <= 5e-6
+
+
+# ------------------------------------------------------------------------------ step!
+def test_config1_readme_example_bfgs_rosenbrock2d():
+    """BASELINE config 1 / README.md:33-41: BFGSOptimizer on 2-D Rosenbrock, rand(2) start."""
+    x0 = orc.pcg_fill(2, 1)
+    ref = orc.BFGS(orc.Problem(orc.ROSENBROCK2D, 2), x0, 1.0)
+    opt = dzo.BFGSOptimizer(dzo.Problem(dzo.ROSENBROCK2D, 2), None, dzo.DeviceArray.from_host(x0), 1.0)
+    steps = 0
+    while not opt.has_converged and steps < 500:
+        opt.step(); ref.step(); steps += 1
+        assert opt.has_converged == ref.has_converged
+        assert opt.iteration_count == ref.iteration_count and opt.last_step_type == ref.last_step_type
+        assert np.allclose(opt.current_point.to_host(), ref.current_point, rtol=1e-9, atol=1e-12)
+        assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-9, abs=1e-25)
+    assert opt.has_converged and steps < 200
+    assert np.allclose(opt.current_point.to_host(), [1.0, 1.0], atol=1e-6)
+    H = opt.approximate_inverse_hessian.to_host()
+    assert np.array_equal(H, H.T)
+
+
+@pytest.mark.parametrize("n", [16, 200])
+def test_bfgs_quadratic_trajectory_and_invariants(n):
+    A = orc.quadratic_matrix(n)
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    ref_p = orc.Problem(orc.QUADRATIC, n, A=A)
+    ref = orc.BFGS(ref_p, x0, 1.0)
+    opt = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+    assert np.array_equal(opt.approximate_inverse_hessian.to_host(), np.eye(n))      # :783
+    assert rel(opt.next_step_direction.to_host(), ref.next_step_direction) <= 1e-14  # :784
+    prev_x, prev_g = opt.current_point.to_host(), opt.current_gradient.to_host()
+    for it in range(25):
+        opt.step(); ref.step()
+        if ref.has_terminated or opt.has_terminated:
+            break
+        x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
+        assert opt.last_step_type == ref.last_step_type and opt.iteration_count == ref.iteration_count
+        assert rel(x, ref.current_point) <= 1e-9
+        assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-9)
+        assert np.array_equal(x - prev_x, opt.delta_point.to_host())          # run_and_test! :1035-1039
+        assert np.array_equal(g - prev_g, opt.delta_gradient.to_host())       # :1042-1046
+        H = opt.approximate_inverse_hessian.to_host()
+        assert np.array_equal(H, H.T)
+        assert rel(opt.next_step_direction.to_host(), H @ g) <= 1e-12         # d = H*g (:958-960)
+        assert rel(H, np.ascontiguousarray(ref.approximate_inverse_hessian)) <= 1e-8
+        prev_x, prev_g = x, g
+    assert opt.current_objective_value < 1e-3 * ref_p.eval(x0)
+
+
+def test_bfgs_line_search_vertex_and_callbacks():
+    n = 6
+    A = orc.quadratic_matrix(n)
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    ref_p = orc.Problem(orc.QUADRATIC, n, A=A)
+    opt = dzo.BFGSOptimizer(lambda x: ref_p.eval(x.to_host()), lambda g, x: g.upload(ref_p.grad(x.to_host())),
+                            dzo.DeviceArray.from_host(x0), 1.0)
+    g = opt.current_gradient.to_host()
+    t_star = (g @ g) / (g @ A @ g)
+    t, f = opt.line_search(True, 1.0 / np.linalg.norm(g))
+    ref = orc.BFGS(ref_p, x0, 1.0)
+    t_ref, f_ref = ref.line_search(True, 1.0 / np.linalg.norm(g))
+    assert t == pytest.approx(t_ref, rel=1e-12) and f == pytest.approx(f_ref, rel=1e-12)
+    assert abs(t - t_star) <= 1e-9 * t_star
+    for _ in range(5):
+        opt.step(); ref.step()
+    assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-9
+
+
+def test_full_size_config2_update_properties_n4096():
+    """BASELINE config 2 size (n = 4096, H = 128 MiB): size-independent properties."""
+    n = 4096
+    rng = np.random.default_rng(0)
+    Hd = dzo.DeviceArray.from_host(np.eye(n))
+    g = rng.standard_normal(n)
+    for it in range(3):
+        d, y = rng.standard_normal(n), rng.standard_normal(n)
+        lam = 0.1 if d @ y > 0 else -0.1
+        dd, yd, gd = (dzo.DeviceArray.from_host(a) for a in (d, y, g))
+        scratch, dnext = dzo.DeviceArray(n), dzo.DeviceArray(n)
+        dzo.update_inverse_hessian_(Hd, lam, dd, yd, scratch, gd, dnext)
+        H = Hd.to_host()
+        assert np.array_equal(H, H.T)
+        assert np.allclose(H @ y, lam * d, rtol=1e-9, atol=1e-10)
+        assert rel(dnext.to_host(), H @ g) <= 1e-12
+        assert rel(dzo.symv_(dzo.DeviceArray(n), Hd, gd).to_host(), H @ g) <= 1e-12
+
+
+# ------------------------------------------------------------------------------ AdGD
+def test_adgd_matches_oracle():
+    n = 300
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 0.1)
+    opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 0.1)
+    for it in range(40):
+        opt.step(); ref.step()
+        assert opt.is_stuck == ref.is_stuck and opt.iteration_count == ref.iteration_count
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-10
+        assert opt.current_step_size == pytest.approx(ref.current_step_size, rel=1e-9)
+        assert opt.previous_step_size == pytest.approx(ref.previous_step_size, rel=1e-9)
+
+
+# ------------------------------------------------------------------------------ batched (K11)
+@pytest.mark.parametrize("n,B", [(2, 5), (16, 7), (256, 3)])
+def test_batched_bfgs_matches_single_instance_oracle(n, B):
+    X0 = np.stack([orc.pcg_fill(n, 1000 + b) for b in range(B)])
+    batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
+    refs = [orc.BFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), X0[b].copy(), 1.0) for b in range(B)]
+    f0 = batch.current_objective_value.to_host()
+    for b in range(B):
+        assert f0[b] == pytest.approx(refs[b].current_objective_value, rel=1e-13)
+    for it in range(6):
+        batch.step(1, poll=False)
+        for r in refs:
+            r.step()
+        X, F = batch.current_point.to_host(), batch.current_objective_value.to_host()
+        its, types = batch.iteration_count.to_host(), batch.last_step_type.to_host()
+        H = batch.approximate_inverse_hessian.to_host()
+        for b in range(B):
+            assert its[b] == refs[b].iteration_count and types[b] == refs[b].last_step_type, (it, b)
+            assert rel(X[b], refs[b].current_point) <= 1e-8, (it, b)
+            assert F[b] == pytest.approx(refs[b].current_objective_value, rel=1e-8)
+            assert np.array_equal(H[b], H[b].T)
+            assert rel(H[b], np.ascontiguousarray(refs[b].approximate_inverse_hessian)) <= 1e-6
+
+
+def test_batched_bfgs_runs_to_termination_and_counts():
+    n, B = 8, 64
+    X0 = np.stack([orc.pcg_fill(n, 1000 + b) for b in range(B)])
+    batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
+    assert batch.count_active() == B
+    done, rounds = False, 0
+    while not done and rounds < 200:
+        done = batch.step(8)
+        rounds += 1
+    assert done and batch.count_active() == 0
+    F = batch.current_objective_value.to_host()
+    assert (F < 1e-12).mean() > 0.9            # Rosenbrock-8 has a second local minimum near x1 = -1
+    assert batch.has_terminated.to_host().all()
+    it_before = batch.iteration_count.to_host().copy()
+    batch.step(3)
+    assert np.array_equal(batch.iteration_count.to_host(), it_before)   # terminated instances never move
+
+
+def test_full_size_config5_shard_properties():
+    """One GPU's shard of config 5: 1024 instances of n = 256 (512 MiB of H)."""
+    n, B = 256, 1024
+    X0 = np.stack([orc.pcg_fill(n, 1000 + b) for b in range(B)])
+    batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
+    f0 = batch.current_objective_value.to_host().copy()
+    batch.step(5, poll=False)
+    f1 = batch.current_objective_value.to_host()
+    assert (f1 < f0).all()
+    H = batch.approximate_inverse_hessian.to_host()
+    for b in (0, 17, 1023):
+        assert np.array_equal(H[b], H[b].T)
+    g, d = batch.current_gradient.to_host(), batch.next_step_direction.to_host()
+    for b in (0, 511):
+        assert rel(d[b], H[b] @ g[b]) <= 1e-11
+    # one instance against the oracle
+    ref = orc.BFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), X0[3].copy(), 1.0)
+    for _ in range(5):
+        ref.step()
+    assert rel(batch.current_point.to_host()[3], ref.current_point) <= 1e-7

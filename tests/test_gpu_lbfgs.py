@@ -1,0 +1,368 @@
+"""GPU parity tests for the L-BFGS hot path, through the C ABI (include/dzo.h).
+
+Bars: elementwise work (trial point, delta_point, delta_gradient, gradient kernel) is
+BIT-EXACT against the oracle; reductions (dot products, objective sums) are fp64 and checked
+to a stated relative tolerance, because the reference's own reduction order (BLAS) is not
+defined; the two-loop direction is within 1e-10 relative L2 of the CPU oracle on identical
+inputs (BASELINE.json north_star), for both device implementations (CHAIN and GRAM).
+"""
+import numpy as np
+import pytest
+
+from dzo_loader import dzo
+from oracle import mp_twoloop, oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_DIRECTION = 1e-10      # north_star: per-step output within 1e-10 relative of the CPU reference
+TOL_DOT = 1e-13            # fp64 two-stage tree vs sequential sum, relative to sum |a_i b_i|
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _frozen(n, k, m, dtype=np.float64, mode=dzo.TWOLOOP_GRAM):
+    """Optimizer whose state is the SURVEY 8(d) frozen two-loop inputs."""
+    g, S, Y = orc.frozen_two_loop_state(n, k, dtype)
+    x = dzo.DeviceArray.from_host(np.zeros(n, dtype))
+    gd = dzo.DeviceArray.from_host(g if n else g)
+    opt = dzo.LBFGSOptimizer(None, lambda x: 0.0, lambda g_, x_: None, x, 0.0, gd, 1.0, m)
+    opt.set_two_loop_mode(mode)
+    if k:
+        rho = np.array([orc.dot(S[i].copy(), Y[i].copy()) for i in range(k)])
+        opt.set_history(S, Y, rho)
+    else:
+        rho = np.zeros(0)
+    return opt, g, S, Y, rho, (x, gd)
+
+
+# ------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1_000_001])
+def test_primitives_match_oracle(n, dtype):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n).astype(dtype), rng.standard_normal(n).astype(dtype)
+    dx, dy = dzo.DeviceArray.from_host(x), dzo.DeviceArray.from_host(y)
+    a = dtype(0.37)
+    # axpy / axpby / rmul / trial point: elementwise, bit-exact
+    want = y.copy(); orc.axpy(float(a), x, want)
+    assert np.array_equal(dzo.axpy_(float(a), dx, dy).to_host(), want)
+    want2 = want.copy(); orc.axpby(1.0, x, -1.0, want2)
+    assert np.array_equal(dzo.axpby_(1.0, dx, -1.0, dy).to_host(), want2)
+    want3 = want2.copy(); orc.scal(want3, float(a))
+    assert np.array_equal(dzo.rmul_(dy, float(a)).to_host(), want3)
+    dst = dzo.DeviceArray(n, dtype)
+    assert np.array_equal(dzo.trial_point_(dst, float(a), dx, dy).to_host(), _fma(a, x, want3, dtype))
+    # reductions: fp64 accumulation on the device
+    exact = float(np.dot(x.astype(np.longdouble), want3.astype(np.longdouble)))
+    scale = float(np.abs(x.astype(np.float64) * want3.astype(np.float64)).sum())
+    assert abs(dzo.dot(dx, dy) - exact) <= TOL_DOT * scale
+    assert abs(dzo.norm(dx) - np.sqrt(float(np.dot(x.astype(np.longdouble), x.astype(np.longdouble))))) <= \
+        (1e-6 if dtype == np.float32 else 1e-14) * np.linalg.norm(x.astype(np.float64))
+    assert dzo.isequal(dx, dx.copy())
+    assert np.array_equal(dzo.fill_(dst, 2.5).to_host(), np.full(n, 2.5, dtype))
+
+
+def _fma(a, x, y, dtype):
+    out = y.copy()
+    orc.axpy(float(a), x, out)     # oracle axpy IS fma(a, x, y)
+    return out
+
+
+def test_isequal_semantics_and_unaligned_views():
+    a = np.array([1.0, np.nan, 0.0, 5.0, 7.0])
+    da = dzo.DeviceArray.from_host(a)
+    assert dzo.isequal(da, da.copy())                        # NaN equals NaN
+    b = a.copy(); b[2] = -0.0
+    assert not dzo.isequal(da, dzo.DeviceArray.from_host(b))  # -0.0 differs from +0.0
+    # views that start 8 bytes into an allocation exercise the scalar (non 16-B) paths
+    n = 1001
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(n + 1), rng.standard_normal(n + 1)
+    dx, dy = dzo.DeviceArray.from_host(x), dzo.DeviceArray.from_host(y)
+    vx, vy = dx.view(1, n), dy.view(1, n)
+    want = y[1:].copy(); orc.axpy(0.5, x[1:].copy(), want)
+    assert np.array_equal(dzo.axpy_(0.5, vx, vy).to_host(), want)
+    assert abs(dzo.dot(vx, vy) - float(np.dot(x[1:], want))) <= 1e-12 * np.abs(x[1:] * want).sum()
+
+
+# ------------------------------------------------------------------------------ problems (K12)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [2, 3, 64, 65, 1000, 100_003])
+def test_rosenbrock_chain_kernels(n, dtype):
+    x = orc.rosenbrock_chain_x0(n, dtype)
+    ref = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype)
+    p = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype)
+    dx = dzo.DeviceArray.from_host(x)
+    g = p.gradient_(dzo.DeviceArray(n, dtype), dx).to_host()
+    assert np.array_equal(g, ref.grad(x))                     # elementwise: bit-exact
+    f_ref = ref.eval(x)
+    assert abs(p(dx) - f_ref) <= (1e-6 if dtype == np.float32 else 1e-13) * abs(f_ref)
+
+
+def test_rosenbrock2d_quadratic_lse_kernels():
+    x = orc.pcg_fill(2, 1)
+    p2, r2 = dzo.Problem(dzo.ROSENBROCK2D, 2), orc.Problem(orc.ROSENBROCK2D, 2)
+    dx = dzo.DeviceArray.from_host(x)
+    assert p2(dx) == r2.eval(x)
+    assert np.array_equal(p2.gradient_(dzo.DeviceArray(2), dx).to_host(), r2.grad(x))
+    for n in (8, 63, 256):
+        A = orc.quadratic_matrix(n)
+        x = orc.pcg_fill(n, 4) - 0.5
+        pq, rq = dzo.Problem(dzo.QUADRATIC, n, A=A), orc.Problem(orc.QUADRATIC, n, A=A)
+        dx = dzo.DeviceArray.from_host(x)
+        assert abs(pq(dx) - rq.eval(x)) <= 1e-13 * abs(rq.eval(x))
+        assert rel(pq.gradient_(dzo.DeviceArray(n), dx).to_host(), rq.grad(x)) <= 1e-14
+    n = 5000
+    c = orc.pcg_fill(n, 6) - 0.5
+    x = (orc.pcg_fill(n, 8) - 0.5) * 3
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 2e-6)):
+        pl = dzo.Problem(dzo.LSE, n, dtype, c=c.astype(dtype), lam=1e-2)
+        rl = orc.Problem(orc.LSE, n, dtype, c=c.astype(dtype), lam=1e-2)
+        dx = dzo.DeviceArray.from_host(x.astype(dtype))
+        assert abs(pl(dx) - rl.eval(x.astype(dtype))) <= tol * abs(rl.eval(x.astype(dtype)))
+        assert rel(pl.gradient_(dzo.DeviceArray(n, dtype), dx).to_host().astype(np.float64),
+                   rl.grad(x.astype(dtype)).astype(np.float64)) <= tol * 10
+
+
+# ------------------------------------------------------------------------------ two-loop (K1)
+@pytest.mark.parametrize("mode", [dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM], ids=["chain", "gram"])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 100_003])
+@pytest.mark.parametrize("k,m", [(0, 4), (1, 4), (3, 4), (4, 4), (20, 20)])
+def test_two_loop_direction_matches_oracle(n, k, m, mode):
+    opt, g, S, Y, rho, _keep = _frozen(n, k, m, mode=mode)
+    d_gpu = opt.compute_step_direction().to_host()
+    d_ref, alpha_ref = orc.lbfgs_direction(g, S, Y, rho)
+    if k == 0:
+        assert np.array_equal(d_gpu, g)                       # :438 plain copy, no scaling (:443)
+        return
+    assert rel(d_gpu, d_ref) <= TOL_DIRECTION
+    assert np.allclose(opt.alpha_history[:k], alpha_ref, rtol=1e-9, atol=1e-13 * np.abs(alpha_ref).max())
+    # and against the wide-accumulator oracle (closest to the exact value)
+    orc.set_dot_mode(orc.DOT_WIDE)
+    try:
+        d_wide, _ = orc.lbfgs_direction(g, S, Y, rho)
+    finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+    assert rel(d_gpu, d_wide) <= TOL_DIRECTION
+
+
+@pytest.mark.parametrize("mode", [dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM], ids=["chain", "gram"])
+def test_two_loop_against_mpmath_arbiter(mode):
+    n, k = 257, 6
+    opt, g, S, Y, rho, _keep = _frozen(n, k, 8, mode=mode)
+    d_gpu = opt.compute_step_direction().to_host()
+    d_mp, _ = mp_twoloop.two_loop(g, S, Y, rho)
+    d_ref, _ = orc.lbfgs_direction(g, S, Y, rho)
+    assert rel(d_gpu, d_mp) <= 1e-12
+    assert rel(d_ref, d_mp) <= 1e-12
+
+
+@pytest.mark.parametrize("mode", [dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM], ids=["chain", "gram"])
+def test_two_loop_fp32_against_fp64_oracle(mode):
+    n, k = 10_001, 10
+    opt, g, S, Y, rho, _keep = _frozen(n, k, 10, dtype=np.float32, mode=mode)
+    d_gpu = opt.compute_step_direction().to_host().astype(np.float64)
+    d64, _ = orc.lbfgs_direction(g.astype(np.float64), S.astype(np.float64), Y.astype(np.float64),
+                                 rho.astype(np.float64))
+    # mixed-precision tolerance (config 4): elementwise fp32 fma chain of 2k+1 terms
+    assert rel(d_gpu, d64) <= 2e-6 * np.sqrt(2 * k + 1)
+
+
+def test_two_loop_is_deterministic_and_modes_agree():
+    n, k = 50_001, 7
+    outs = []
+    for mode in (dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM):
+        opt, *_ , _keep = _frozen(n, k, 8, mode=mode)
+        a = opt.compute_step_direction().to_host()
+        b = opt.compute_step_direction().to_host()
+        assert np.array_equal(a, b)                           # run-twice bitwise equality
+        outs.append(a)
+    assert rel(outs[0], outs[1]) <= 1e-12
+
+
+# ------------------------------------------------------------------------------ step! (K2-K7)
+def _gpu_and_oracle(n, m, dtype=np.float64, mode=dzo.TWOLOOP_GRAM):
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), 1.0, m)
+    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype)
+    opt = dzo.LBFGSOptimizer(None, prob, None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    opt.set_two_loop_mode(mode)
+    return opt, ref, prob
+
+
+def test_constructor_state_matches_reference_init():
+    n, m = 1000, 5
+    opt, ref, _ = _gpu_and_oracle(n, m)
+    assert np.array_equal(opt.current_gradient.to_host(), ref.current_gradient)
+    assert abs(opt.current_objective_value - ref.current_objective_value) <= 1e-13 * ref.current_objective_value
+    assert rel(opt.step_direction.to_host(), ref.step_direction) <= 1e-15     # -step*g/|g| (:386-387)
+    assert not opt.delta_point.to_host().any() and not opt.delta_gradient.to_host().any()
+    assert opt.history_count == 0 and opt.iteration_count == 0 and not opt.is_stuck
+    assert opt.current_point.ptr == opt.current_point_array.ptr               # aliasing (:393)
+    with pytest.raises(AssertionError):                                       # :380 @assert
+        dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, 8), None,
+                           dzo.DeviceArray.from_host(orc.rosenbrock_chain_x0(8)), -1.0, 3)
+
+
+@pytest.mark.parametrize("mode", [dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM], ids=["chain", "gram"])
+@pytest.mark.parametrize("n,m,steps", [(2, 3, 40), (1000, 5, 60), (4099, 20, 60)])
+def test_step_trajectory_matches_oracle(n, m, steps, mode):
+    opt, ref, _ = _gpu_and_oracle(n, m, mode=mode)
+    for it in range(steps):
+        opt.step(); ref.step()
+        assert opt.is_stuck == ref.is_stuck and opt.iteration_count == ref.iteration_count
+        if ref.is_stuck:
+            break
+        assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-11, it
+        assert abs(opt.current_objective_value - ref.current_objective_value) <= 1e-10 * abs(ref.current_objective_value)
+        assert opt.last_trials == ref.last_trials
+        assert opt.history_count == ref.history_count
+        assert np.allclose(opt.rho_history, ref.rho_history, rtol=1e-9)
+
+
+def test_run_and_test_invariants_on_device():
+    """legacy/DZOptimization.jl:998-1049 -- exact equalities hold on the GPU path too."""
+    n, m = 515, 6
+    opt, _, prob = _gpu_and_oracle(n, m)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    prev_x, prev_g = opt.current_point.to_host(), opt.current_gradient.to_host()
+    for it in range(400):
+        opt.step()
+        x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
+        if opt.is_stuck:
+            assert np.array_equal(x, prev_x) and np.array_equal(g, prev_g)      # :1039,:1046
+            break
+        assert opt.iteration_count == it + 1                                     # :1013-1015
+        assert np.array_equal(x - prev_x, opt.delta_point.to_host())            # :1035-1039 exact
+        assert np.array_equal(g - prev_g, opt.delta_gradient.to_host())         # :1042-1046 exact
+        assert np.array_equal(ref_p.grad(x), g)                                  # :1025-1032 exact
+        assert abs(ref_p.eval(x) - opt.current_objective_value) <= 1e-13 * abs(opt.current_objective_value)
+        # newest history pair IS the last deltas (:483,:491), rho[1] = s.y (:505)
+        assert np.array_equal(opt.delta_point_history[0].to_host(), x - prev_x)
+        assert np.array_equal(opt.delta_gradient_history[0].to_host(), g - prev_g)
+        s, y = x - prev_x, g - prev_g
+        assert abs(opt.rho_history[0] - float(np.dot(s, y))) <= 1e-12 * np.abs(s * y).sum()
+        prev_x, prev_g = x, g
+    assert opt.is_stuck and opt.current_objective_value < 1e-10
+    assert opt.history_count == m
+
+
+def test_callback_path_equals_builtin_path():
+    """objective / gradient supplied as host callbacks (the reference's plugin boundary)."""
+    n, m = 300, 4
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    calls = {"f": 0, "g": 0, "c": 0}
+
+    def objective(x):
+        calls["f"] += 1
+        return ref_p.eval(x.to_host())
+
+    def gradient(g, x):
+        calls["g"] += 1
+        g.upload(ref_p.grad(x.to_host()))
+
+    def constraint(x):
+        calls["c"] += 1
+        return True
+
+    a = dzo.LBFGSOptimizer(constraint, objective, gradient, dzo.DeviceArray.from_host(x0), 1.0, m)
+    ref = orc.LBFGS(ref_p, x0.copy(), 1.0, m)
+    for it in range(25):
+        a.step(); ref.step()
+        assert rel(a.current_point.to_host(), ref.current_point) <= 1e-12
+        assert a.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-12)
+        assert np.array_equal(a.current_gradient.to_host(), ref_p.grad(a.current_point.to_host()))
+    assert calls["f"] >= 26 and calls["g"] == 26 and calls["c"] >= 26
+
+
+def test_split_entry_points_reproduce_step():
+    n, m = 257, 3
+    opt_a, _, prob = _gpu_and_oracle(n, m)
+    opt_b, _, prob_b = _gpu_and_oracle(n, m)
+    for _ in range(8):
+        opt_a.step()
+        # the same step driven from the host (what the Julia module does around its callbacks)
+        if opt_b.iteration_count > 0:
+            opt_b.compute_step_direction()
+        opt_b.begin_search()
+        t = 1.0
+        while True:
+            assert opt_b.trial(t)
+            f_new = prob_b(opt_b.current_point)
+            if f_new < opt_b.current_objective_value:
+                opt_b.accept(f_new)
+                break
+            t *= 0.5
+        opt_b.pre_gradient()
+        prob_b.gradient_(opt_b.current_gradient, opt_b.current_point)
+        opt_b.post_gradient()
+        assert np.array_equal(opt_a.current_point.to_host(), opt_b.current_point.to_host())
+        assert np.array_equal(opt_a.delta_gradient.to_host(), opt_b.delta_gradient.to_host())
+        assert opt_a.current_objective_value == opt_b.current_objective_value
+    assert np.array_equal(opt_a.rho_history, opt_b.rho_history)
+
+
+def test_stuck_semantics():
+    n = 64
+    p = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+    opt = dzo.LBFGSOptimizer(None, p, None, dzo.DeviceArray.from_host(np.ones(n)), 1.0, 3)
+    assert opt.is_stuck and opt.has_terminated and opt.has_converged          # :382, three names
+    assert not opt.step_direction.to_host().any()                             # :384
+    opt.step()
+    assert opt.iteration_count == 0
+    # NaN direction: the reference would loop forever; bounded escape restores x
+    opt2, _, _ = _gpu_and_oracle(100, 3)
+    opt2.step_direction.upload(np.full(100, np.nan))
+    opt2.set_max_halvings(6)
+    x_before = opt2.current_point.to_host()
+    opt2.step()
+    assert opt2.is_stuck and np.array_equal(opt2.current_point.to_host(), x_before)
+
+
+def test_fp32_lse_tolerance_study_config4_small():
+    """Config 4 at reduced n: L-BFGS m=10 on log-sum-exp, fp32 on the GPU vs the fp64 oracle
+    on the same trajectory start; reports the observed mixed-precision error."""
+    n, m = 20_000, 10
+    c = orc.pcg_fill(n, 6) - 0.5
+    ref = orc.LBFGS(orc.Problem(orc.LSE, n, np.float64, c=c, lam=1e-2), np.zeros(n), 1.0, m)
+    p32 = dzo.Problem(dzo.LSE, n, np.float32, c=c.astype(np.float32), lam=1e-2)
+    opt = dzo.LBFGSOptimizer(None, p32, None, dzo.DeviceArray.from_host(np.zeros(n, np.float32)), 1.0, m)
+    worst = 0.0
+    for it in range(12):
+        opt.step(); ref.step()
+        if ref.is_stuck or opt.is_stuck:
+            break
+        ef = abs(opt.current_objective_value - ref.current_objective_value) / abs(ref.current_objective_value)
+        worst = max(worst, ef)
+    assert worst <= 5e-6, worst
+
+
+# ------------------------------------------------------------------------------ full size (C3)
+def test_full_size_two_loop_n1e7_m20():
+    """BASELINE config 3 at full size: frozen synthetic state, n = 10^7, m = k = 20, fp64.
+    Size-independent properties plus the oracle itself (a few seconds of CPU)."""
+    n, k = 10_000_000, 20
+    opt, g, S, Y, rho, _keep = _frozen(n, k, k, mode=dzo.TWOLOOP_GRAM)
+    d_gram = opt.compute_step_direction().to_host()
+    assert np.array_equal(d_gram, opt.compute_step_direction().to_host())      # deterministic
+    opt.set_two_loop_mode(dzo.TWOLOOP_CHAIN)
+    d_chain = opt.compute_step_direction().to_host()
+    assert rel(d_gram, d_chain) <= TOL_DIRECTION
+    orc.set_threads(8)
+    try:
+        d_ref, _ = orc.lbfgs_direction(g, S, Y, rho)
+    finally:
+        orc.set_threads(1)
+    assert rel(d_gram, d_ref) <= TOL_DIRECTION
+    assert rel(d_chain, d_ref) <= TOL_DIRECTION
+    # linearity in g: scaling by a power of two is exact in every operation
+    opt.set_two_loop_mode(dzo.TWOLOOP_GRAM)
+    opt.current_gradient.upload(4.0 * g)
+    assert np.array_equal(opt.compute_step_direction().to_host(), 4.0 * d_gram)
+    # secant property of the implicit inverse Hessian: H_k y_1 = s_1, so d(g = y_1) = -s_1
+    opt.current_gradient.upload(Y[0])
+    assert rel(opt.compute_step_direction().to_host(), -S[0]) <= 1e-9
