@@ -65,6 +65,23 @@ _lib = None
 _inited = False
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's); if libdzo_hip.so bound to the system copy and torch later loaded
+    its own, the second runtime finds no device.  Bind to torch's copy whenever torch is
+    installed -- without importing torch -- so the load order never matters."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Load the C-ABI library (no device needed for loading)."""
     global _lib
@@ -72,6 +89,7 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise DzoError(2, f"{LIB_PATH} is not built; run __graft_entry__.build() "
                               "(there is no CPU fallback)")
+        _preload_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

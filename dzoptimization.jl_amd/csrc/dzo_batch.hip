@@ -452,6 +452,7 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
     DZO_HIP(hipHostMalloc((void **)&b->count_host, sizeof(unsigned long long), hipHostMallocDefault));
     DZO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     DZO_HIP(hipMemcpy(b->st.x, x0_dev, vb, hipMemcpyDeviceToDevice));        // :769 copy
+    DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     if (b->lds_bytes > 48 * 1024) {
         // gfx950 has 160 KiB of LDS per CU; dynamic requests above the default need the attribute
         const void *fn = nullptr;

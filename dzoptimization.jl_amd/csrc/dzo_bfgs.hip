@@ -158,8 +158,10 @@ __global__ __launch_bounds__(kBlock) void phi_point_kernel(int64_t n, T *__restr
         changed |= (xi != nw);
         nonzero |= (di != (T)0);
     }
-    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
-    if (__any(nonzero) && (threadIdx.x & 63) == 0) atomicOr(flags + 1, 1);
+    __shared__ int lds_flag;
+    block_raise_flag(changed, flags, &lds_flag);
+    __syncthreads();
+    block_raise_flag(nonzero, flags + 1, &lds_flag);
 }
 
 // move (:943-945): dx = x_old, dg = g_old (un-negated backups), x = fma(-t, dir, x)
@@ -501,6 +503,7 @@ static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double init
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 32)));
     DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocDefault));
     DZO_HIP(hipMemcpy(o->x, x0_dev, (size_t)o->n * es, hipMemcpyDeviceToDevice));   // :769 copy
+    DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     if (o->constraint)
         DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT, "@assert constraint_success (legacy/DZOptimization.jl:770-771)");
     DZO_TRY(bfgs_eval(o, o->x, &o->f));                          // :772

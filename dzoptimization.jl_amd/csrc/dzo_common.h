@@ -123,6 +123,20 @@ template <typename T> __device__ __forceinline__ void store16(T *p, const T (&v)
     *reinterpret_cast<V *>(p) = t;
 }
 
+// Non-temporal 16-byte load: streamed-once operands (the (s, y) history) should not displace
+// reusable lines; measured +10 % on a 41-stream fp64 read (tools/streambench.hip).
+template <typename T> __device__ __forceinline__ void load16_nt(const T *p, T (&v)[Vec16<T>::N]) {
+    if constexpr (Vec16<T>::N == 2) {
+        typedef double v2f64 __attribute__((ext_vector_type(2)));
+        const v2f64 t = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(p));
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        typedef float v4f32 __attribute__((ext_vector_type(4)));
+        const v4f32 t = __builtin_nontemporal_load(reinterpret_cast<const v4f32 *>(p));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+}
+
 // wave64 sum, result valid in lane 0 (fixed order -> deterministic)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -166,6 +180,18 @@ __device__ __forceinline__ double reduce_partials_all(const double *__restrict__
     for (int w = 0; w < kWaves; ++w) r += lds[w];
     __syncthreads();
     return r;
+}
+
+// Raise a boolean flag in global memory when any thread of the block has `p` set.  ONE plain
+// store per block: every writer stores the same value, so no atomic is needed -- thousands of
+// atomics on one word serialise at ~12 ns each (MI355X_MICROARCH.md, row "fanin") and were
+// measured to double the time of a 4n streaming kernel.
+__device__ __forceinline__ void block_raise_flag(bool p, int32_t *flag, int *lds_flag) {
+    if (threadIdx.x == 0) *lds_flag = 0;
+    __syncthreads();
+    if (__any(p) && (threadIdx.x & 63) == 0) *lds_flag = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && *lds_flag) *flag = 1;
 }
 
 // Base.isequal for floats: bitwise equal, except that every NaN equals every NaN.

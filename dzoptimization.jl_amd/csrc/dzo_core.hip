@@ -205,7 +205,9 @@ int32_t dzo_free(void *ptr_dev) {
 
 int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes) {
     DZO_TRY(require_init());
+    DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    DZO_HIP(hipDeviceSynchronize());
     return DZO_OK;
 }
 
@@ -221,6 +223,7 @@ int32_t dzo_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes) {
     DZO_TRY(require_init());
     DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice));
+    DZO_HIP(hipDeviceSynchronize());
     return DZO_OK;
 }
 

@@ -20,6 +20,7 @@
 //          2k+1 coefficients per element IN THE REFERENCE'S ELEMENTWISE ORDER (fma chain,
 //          then the rmul! scale, then the second fma chain).  Moves (4k+3)*n elements --
 //          the algorithmic floor of SURVEY.md 8(d) plus one re-read of g.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -57,6 +58,7 @@ struct dzo_lbfgs_s {
     double *gram_partials = nullptr;        // [kGramValues*kMaxHistory][gram_grid]
     double *link_partials = nullptr;        // [4][kMaxPartialBlocks] ping-pong + yy
     int gram_grid = 0;
+    int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
     int spare() const { return (newest + 1) % (m + 1); }
@@ -73,6 +75,9 @@ template <typename T, bool VEC> struct Ld {
     static constexpr int N = VEC ? Vec16<T>::N : 1;
     static __device__ __forceinline__ void load(const T *p, T (&v)[N]) {
         if constexpr (VEC) load16(p, v); else v[0] = p[0];
+    }
+    static __device__ __forceinline__ void load_nt(const T *p, T (&v)[N]) {
+        if constexpr (VEC) load16_nt(p, v); else v[0] = __builtin_nontemporal_load(p);
     }
     static __device__ __forceinline__ void store(T *p, const T (&v)[N]) {
         if constexpr (VEC) store16(p, v); else p[0] = v[0];
@@ -213,23 +218,22 @@ __global__ __launch_bounds__(kBlock) void chain_head_kernel(int64_t n, const T *
 template <typename T> struct GramParams {
     int64_t n;
     const T *g;
-    const T *S;
-    const T *Y;
-    int64_t stride;
+    const T *sp;                // pivot pair (the pair whose Gram row/column is (re)computed)
+    const T *yp;
     int k;
-    int pivot_slot;             // slot of the pair whose Gram row/column is (re)computed
-    SlotMap map;                // logical pair -> slot
+    const T *s[kMaxHistory];    // logical pair -> slot base (wave-uniform index -> scalar loads)
+    const T *y[kMaxHistory];
     double *partials;           // [kGramValues * k][gridDim.x]
 };
 
 // Each block walks tiles of 64 lanes x U 16-B vectors; its 4 waves all read the tile of
 // g, s_p, y_p (L1 hits after the first wave) and split the k pairs between them, so a lane
-// carries 5*PPW fp64 accumulators instead of 5*k.
-template <typename T, int PPW, bool VEC>
+// carries 5*PPW fp64 accumulators instead of 5*k.  History vectors are streamed with
+// non-temporal loads (each element is used exactly once per pass).
+template <typename T, int PPW, bool VEC, int U>
 __global__ __launch_bounds__(kBlock) void gram_pass_kernel(GramParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
-    constexpr int U = 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double acc[PPW][kGramValues];
@@ -238,8 +242,7 @@ __global__ __launch_bounds__(kBlock) void gram_pass_kernel(GramParams<T> p) {
 #pragma unroll
         for (int c = 0; c < kGramValues; ++c) acc[q][c] = 0;
 
-    const T *sp = p.S + (int64_t)p.pivot_slot * p.stride;
-    const T *yp = p.Y + (int64_t)p.pivot_slot * p.stride;
+    const T *sp = p.sp, *yp = p.yp;
     const int64_t nvec = p.n / N;
     const int64_t tile = 64 * U;                       // vectors per block-iteration
     for (int64_t base = (int64_t)blockIdx.x * tile; base < nvec; base += (int64_t)gridDim.x * tile) {
@@ -259,24 +262,28 @@ __global__ __launch_bounds__(kBlock) void gram_pass_kernel(GramParams<T> p) {
         for (int q = 0; q < PPW; ++q) {
             const int i = wave + kWaves * q;
             if (i < p.k) {
-                const int slot = p.map.slot[i];
-                const T *si = p.S + (int64_t)slot * p.stride;
-                const T *yi = p.Y + (int64_t)slot * p.stride;
+                const T *si = p.s[i];
+                const T *yi = p.y[i];
+                T sv[U][N], yv[U][N];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (ok[u]) {
+                        const int64_t vi = base + u * 64 + lane;
+                        L::load_nt(si + vi * N, sv[u]);
+                        L::load_nt(yi + vi * N, yv[u]);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (!ok[u]) continue;
-                    const int64_t vi = base + u * 64 + lane;
-                    T sv[N], yv[N];
-                    L::load(si + vi * N, sv);
-                    L::load(yi + vi * N, yv);
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
-                        const double s = (double)sv[j], y = (double)yv[j];
-                        acc[q][0] = __builtin_fma(s, (double)gv[u][j], acc[q][0]);
-                        acc[q][1] = __builtin_fma(y, (double)gv[u][j], acc[q][1]);
-                        acc[q][2] = __builtin_fma(y, (double)ypv[u][j], acc[q][2]);
-                        acc[q][3] = __builtin_fma(y, (double)spv[u][j], acc[q][3]);
-                        acc[q][4] = __builtin_fma(s, (double)ypv[u][j], acc[q][4]);
+                        const double sx = (double)sv[u][j], yx = (double)yv[u][j];
+                        acc[q][0] = __builtin_fma(sx, (double)gv[u][j], acc[q][0]);
+                        acc[q][1] = __builtin_fma(yx, (double)gv[u][j], acc[q][1]);
+                        acc[q][2] = __builtin_fma(yx, (double)ypv[u][j], acc[q][2]);
+                        acc[q][3] = __builtin_fma(yx, (double)spv[u][j], acc[q][3]);
+                        acc[q][4] = __builtin_fma(sx, (double)ypv[u][j], acc[q][4]);
                     }
                 }
             }
@@ -290,14 +297,13 @@ __global__ __launch_bounds__(kBlock) void gram_pass_kernel(GramParams<T> p) {
             for (int q = 0; q < PPW; ++q) {
                 const int i = wave + kWaves * q;
                 if (i < p.k) {
-                    const int slot = p.map.slot[i];
-                    const double s = (double)p.S[(int64_t)slot * p.stride + e];
-                    const double y = (double)p.Y[(int64_t)slot * p.stride + e];
-                    acc[q][0] = __builtin_fma(s, ge, acc[q][0]);
-                    acc[q][1] = __builtin_fma(y, ge, acc[q][1]);
-                    acc[q][2] = __builtin_fma(y, ype, acc[q][2]);
-                    acc[q][3] = __builtin_fma(y, spe, acc[q][3]);
-                    acc[q][4] = __builtin_fma(s, ype, acc[q][4]);
+                    const double sx = (double)p.s[i][e];
+                    const double yx = (double)p.y[i][e];
+                    acc[q][0] = __builtin_fma(sx, ge, acc[q][0]);
+                    acc[q][1] = __builtin_fma(yx, ge, acc[q][1]);
+                    acc[q][2] = __builtin_fma(yx, ype, acc[q][2]);
+                    acc[q][3] = __builtin_fma(yx, spe, acc[q][3]);
+                    acc[q][4] = __builtin_fma(sx, ype, acc[q][4]);
                 }
             }
         }
@@ -322,16 +328,32 @@ struct GramFinishParams {
     int grid;                   // blocks of the Gram pass
     int do_recurrence;
     SlotMap map;
-    const double *partials;
+    const double *partials;     // reduced values [kGramValues * k]
     const double *rho;          // by slot
     double *Gyy, *Gsy;
     double *sg, *yg;
     double *alpha, *coef, *scale;
 };
 
-// One block.  (1) fixed-order reduction of the per-block partials, (2) refresh of the pivot
-// row/column of the slot-indexed Gram caches, (3) the two-loop recursion on SCALARS by one
-// wave, lane i owning pair i:
+// Second stage of the Gram pass: one block per value sums that value's per-block partials in
+// a fixed order (value-major layout -> contiguous reads).
+__global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
+                                                             double *__restrict__ vals) {
+    __shared__ double lds[kWaves];
+    const double *src = partials + (int64_t)blockIdx.x * grid;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int b = threadIdx.x; b < grid; b += 4 * kBlock) {
+        a0 += src[b];
+        if (b + kBlock < grid) a1 += src[b + kBlock];
+        if (b + 2 * kBlock < grid) a2 += src[b + 2 * kBlock];
+        if (b + 3 * kBlock < grid) a3 += src[b + 3 * kBlock];
+    }
+    const double r = block_sum((a0 + a1) + (a2 + a3), lds);
+    if (threadIdx.x == 0) vals[blockIdx.x] = r;
+}
+
+// One block.  (1) refresh of the pivot row/column of the slot-indexed Gram caches from the
+// reduced values, (2) the two-loop recursion on SCALARS by one wave, lane i owning pair i:
 //     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
 //     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
 __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p) {
@@ -340,13 +362,7 @@ __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p)
     __shared__ double sy[kMaxHistory][kMaxHistory + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = p.k;
-    for (int v = wave; v < kGramValues * k; v += kWaves) {
-        double a = 0;
-        const double *src = p.partials + (int64_t)v * p.grid;
-        for (int b = lane; b < p.grid; b += 64) a += src[b];
-        a = wave_sum_all(a);
-        if (lane == 0) vals[v] = a;
-    }
+    for (int v = threadIdx.x; v < kGramValues * k; v += kBlock) vals[v] = p.partials[v];
     // logical k x k views of the caches (entries of non-pivot pairs were computed by the
     // passes in which THEY were the pivot)
     for (int e = threadIdx.x; e < k * k; e += kBlock) {
@@ -405,68 +421,86 @@ template <typename T> struct CombineParams {
     int64_t n;
     const T *g;
     T *d;
-    const T *S;
-    const T *Y;
-    int64_t stride;
     int k;
-    SlotMap map;
     const double *alpha, *coef, *scale;
+    const T *s[kMaxHistory];    // logical pair -> slot base
+    const T *y[kMaxHistory];
 };
 
 // d[e] = the reference's elementwise recurrence (:438-449) with the scalars already known:
 //   q = g[e]; q = fma(-alpha_i, y_i[e], q) (i = 1..k); q *= scale; q = fma(-c_i, s_i[e], q)
 //   (i = k..1).  Given equal scalars this is bit-identical to the reference's d.
-template <typename T, bool VEC>
+// The 2k coefficients are staged once per block in LDS (wave-uniform broadcast reads), the
+// slot pointers come from the kernel-argument segment (scalar loads), and the history is
+// streamed with non-temporal 16-B loads, UI of them in flight per stream step.
+template <typename T, bool VEC, int U>
 __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
-    constexpr int U = 2;
+    __shared__ T a_s[kMaxHistory], c_s[kMaxHistory];
+    const int k = p.k;
+    if (threadIdx.x < k) {
+        a_s[threadIdx.x] = (T)(-p.alpha[threadIdx.x]);
+        c_s[threadIdx.x] = (T)(-p.coef[threadIdx.x]);
+    }
+    __syncthreads();
+    const T scale = k > 0 ? (T)p.scale[0] : (T)1;
     const int64_t nvec = p.n / N;
     const int64_t nthreads = (int64_t)gridDim.x * kBlock;
-    const int k = p.k;
-    const T scale = (T)p.scale[0];
-    auto run = [&](int64_t e0, int64_t e1, bool two, auto tag) {
-        constexpr int M = decltype(tag)::value;
-        T q0[M], q1[M];
-        if constexpr (M > 1) { load16(p.g + e0, q0); if (two) load16(p.g + e1, q1); }
-        else { q0[0] = p.g[e0]; }
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
+        T q[U][N];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
+            ok[u] = vi < nvec;
+            if (ok[u]) L::load(p.g + vi * N, q[u]);
+        }
 #pragma unroll 4
         for (int i = 0; i < k; ++i) {
-            const T a = (T)(-p.alpha[i]);
-            const T *yi = p.Y + (int64_t)p.map.slot[i] * p.stride;
-            T v0[M], v1[M];
-            if constexpr (M > 1) { load16(yi + e0, v0); if (two) load16(yi + e1, v1); }
-            else { v0[0] = yi[e0]; }
+            const T a = a_s[i];
+            const T *yi = p.y[i];
+            T v[U][N];
 #pragma unroll
-            for (int j = 0; j < M; ++j) { q0[j] = dfma(a, v0[j], q0[j]); if (M > 1 && two) q1[j] = dfma(a, v1[j], q1[j]); }
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) L::load_nt(yi + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[u][j] = dfma(a, v[u][j], q[u][j]);
         }
         if (k > 0) {
 #pragma unroll
-            for (int j = 0; j < M; ++j) { q0[j] = scale * q0[j]; if (M > 1 && two) q1[j] = scale * q1[j]; }
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[u][j] = scale * q[u][j];
         }
 #pragma unroll 4
         for (int i = k - 1; i >= 0; --i) {
-            const T c = (T)(-p.coef[i]);
-            const T *si = p.S + (int64_t)p.map.slot[i] * p.stride;
-            T v0[M], v1[M];
-            if constexpr (M > 1) { load16(si + e0, v0); if (two) load16(si + e1, v1); }
-            else { v0[0] = si[e0]; }
+            const T c = c_s[i];
+            const T *si = p.s[i];
+            T v[U][N];
 #pragma unroll
-            for (int j = 0; j < M; ++j) { q0[j] = dfma(c, v0[j], q0[j]); if (M > 1 && two) q1[j] = dfma(c, v1[j], q1[j]); }
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) L::load_nt(si + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[u][j] = dfma(c, v[u][j], q[u][j]);
         }
-        if constexpr (M > 1) { store16(p.d + e0, q0); if (two) store16(p.d + e1, q1); }
-        else { p.d[e0] = q0[0]; }
-    };
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ok[u]) L::store(p.d + (base + (int64_t)u * kBlock + threadIdx.x) * N, q[u]);
+    }
     if constexpr (VEC) {
-        for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
-            const int64_t v0 = base + threadIdx.x, v1 = base + kBlock + threadIdx.x;
-            if (v0 < nvec) run(v0 * N, v1 * N, v1 < nvec, std::integral_constant<int, N>{});
+        const int64_t e = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (e < p.n) {
+            T q = p.g[e];
+            for (int i = 0; i < k; ++i) q = dfma(a_s[i], p.y[i][e], q);
+            if (k > 0) q = scale * q;
+            for (int i = k - 1; i >= 0; --i) q = dfma(c_s[i], p.s[i][e], q);
+            p.d[e] = q;
         }
-        const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-        if (i < p.n) run(i, i, false, std::integral_constant<int, 1>{});
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += nthreads)
-            run(i, i, false, std::integral_constant<int, 1>{});
     }
 }
 
@@ -591,24 +625,32 @@ template <typename T> static int32_t direction_chain(dzo_lbfgs_s *o) {
 }
 
 // ---------------------------------------------------------------------------- GRAM driver
+static int tune(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool recurrence) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     const int k = o->k;
     GramParams<T> gp;
-    gp.n = c.n; gp.g = (const T *)c.g; gp.S = (const T *)o->S; gp.Y = (const T *)o->Y;
-    gp.stride = o->stride; gp.k = k; gp.pivot_slot = o->slot_of(pivot); gp.map = make_map(o);
+    memset(&gp, 0, sizeof(gp));
+    gp.n = c.n; gp.g = (const T *)c.g; gp.k = k;
+    gp.sp = o->s_slot<T>(o->slot_of(pivot)); gp.yp = o->y_slot<T>(o->slot_of(pivot));
+    for (int i = 0; i < k; ++i) { gp.s[i] = o->s_slot<T>(o->slot_of(i)); gp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     gp.partials = o->gram_partials;
     const bool vec = al16(c.g);
     const int ppw = (k + kWaves - 1) / kWaves;
     const int grid = o->gram_grid;
     {
         DZO_TIMED("lbfgs_gram_pass", s);
-#define GP(P)                                                                                              \
-    do {                                                                                                   \
-        if (vec) hipLaunchKernelGGL((gram_pass_kernel<T, P, true>), dim3(grid), dim3(kBlock), 0, s, gp);   \
-        else hipLaunchKernelGGL((gram_pass_kernel<T, P, false>), dim3(grid), dim3(kBlock), 0, s, gp);      \
+#define GPU_(P, UU)                                                                                           \
+    do {                                                                                                      \
+        if (vec) hipLaunchKernelGGL((gram_pass_kernel<T, P, true, UU>), dim3(grid), dim3(kBlock), 0, s, gp);  \
+        else hipLaunchKernelGGL((gram_pass_kernel<T, P, false, UU>), dim3(grid), dim3(kBlock), 0, s, gp);     \
     } while (0)
+#define GP(P) do { if (o->gram_u == 1) GPU_(P, 1); else if (o->gram_u == 4) GPU_(P, 4); else GPU_(P, 2); } while (0)
         if (ppw <= 1) GP(1);
         else if (ppw <= 2) GP(2);
         else if (ppw <= 3) GP(3);
@@ -619,10 +661,16 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         else if (ppw <= 12) GP(12);
         else GP(16);
 #undef GP
+#undef GPU_
+    }
+    double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid;   // reduced values
+    {
+        DZO_TIMED("lbfgs_gram_reduce", s);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * k), dim3(kBlock), 0, s, o->gram_partials, grid, vals);
     }
     GramFinishParams fp;
     fp.k = k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = grid; fp.do_recurrence = recurrence ? 1 : 0;
-    fp.map = gp.map; fp.partials = o->gram_partials; fp.rho = o->rho;
+    fp.map = make_map(o); fp.partials = vals; fp.rho = o->rho;
     fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     {
@@ -646,15 +694,26 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     o->gram_rebuild = false;
     o->gram_stale = 0;
     CombineParams<T> cp;
-    cp.n = c.n; cp.g = (const T *)c.g; cp.d = (T *)o->d; cp.S = (const T *)o->S; cp.Y = (const T *)o->Y;
-    cp.stride = o->stride; cp.k = k; cp.map = make_map(o);
+    memset(&cp, 0, sizeof(cp));
+    cp.n = c.n; cp.g = (const T *)c.g; cp.d = (T *)o->d; cp.k = k;
+    for (int i = 0; i < k; ++i) { cp.s[i] = o->s_slot<T>(o->slot_of(i)); cp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     cp.alpha = o->alpha; cp.coef = o->coef; cp.scale = o->scale;
     const bool vec = al16(c.g);
-    const int grid = stream_grid(c.n, (vec ? Vec16<T>::N : 1) * 2);
+    const int u = o->combine_u;
+    int64_t per_block = (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u;
+    int64_t blocks = (c.n + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)ctx().cus * o->combine_blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    const int grid = (int)(blocks < 1 ? 1 : blocks);
     {
         DZO_TIMED("lbfgs_combine", s);
-        if (vec) hipLaunchKernelGGL((combine_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, cp);
-        else hipLaunchKernelGGL((combine_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, cp);
+#define CB(UU)                                                                                             \
+    do {                                                                                                   \
+        if (vec) hipLaunchKernelGGL((combine_kernel<T, true, UU>), dim3(grid), dim3(kBlock), 0, s, cp);    \
+        else hipLaunchKernelGGL((combine_kernel<T, false, UU>), dim3(grid), dim3(kBlock), 0, s, cp);       \
+    } while (0)
+        if (u == 1) CB(1); else if (u == 4) CB(4); else CB(2);
+#undef CB
     }
     DZO_HIP(hipGetLastError());
     return DZO_OK;
@@ -750,18 +809,23 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     ALLOC(o->S, slab);
     ALLOC(o->Y, slab);
     ALLOC(o->d, (size_t)o->stride * es);
-    o->gram_grid = ctx().cus * 4;
+    o->gram_u = tune("DZO_TUNE_GRAM_U", 4);
+    o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
+    o->combine_blocks_per_cu = tune("DZO_TUNE_COMBINE_BPC", 8);
+    o->gram_grid = ctx().cus * tune("DZO_TUNE_GRAM_BPC", 8);
     if (o->gram_grid > kMaxPartialBlocks) o->gram_grid = kMaxPartialBlocks;
     {
-        const int64_t tiles = (n / (16 / (int64_t)es) + 127) / 128;
+        const int64_t tile_v = 64 * (int64_t)o->gram_u;
+        const int64_t tiles = (n / (16 / (int64_t)es) + tile_v - 1) / tile_v;
         if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
     }
     const size_t nscal = (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory +
-                         (size_t)kGramValues * kMaxHistory * o->gram_grid + 4 * (size_t)kMaxPartialBlocks;
+                         (size_t)kGramValues * kMaxHistory * (o->gram_grid + 1) + 4 * (size_t)kMaxPartialBlocks;
     double *base = nullptr;
     ALLOC(base, nscal * sizeof(double));
 #undef ALLOC
     (void)hipMemset(base, 0, nscal * sizeof(double));
+    (void)hipDeviceSynchronize();
     o->rho = base; base += m1;
     o->alpha = base; base += kMaxHistory;
     o->coef = base; base += kMaxHistory;
@@ -770,7 +834,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->Gsy = base; base += (size_t)m1 * m1;
     o->sg = base; base += kMaxHistory;
     o->yg = base; base += kMaxHistory;
-    o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * o->gram_grid;
+    o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * (o->gram_grid + 1);
     o->link_partials = base;
     // :366-374 zero-filled deltas: the whole ring starts zeroed
     DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
@@ -1029,6 +1093,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     o->refresh_delta_ptrs();
     DZO_HIP(hipMemset(c.dx, 0, (size_t)o->stride * es));
     DZO_HIP(hipMemset(c.dg, 0, (size_t)o->stride * es));
+    DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     c.iteration_count = iteration_count;
     o->gram_rebuild = true;
     o->gram_stale = 0;

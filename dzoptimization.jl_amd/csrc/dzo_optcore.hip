@@ -9,51 +9,53 @@
 namespace dzo {
 
 template <typename T, bool VEC, bool FIRST>
-__global__ __launch_bounds__(kBlock) void trial_kernel(int64_t n, T *x, T *backup, const T *__restrict__ d, T t,
-                                                       int32_t *__restrict__ changed) {
+__global__ __launch_bounds__(kBlock) void trial_kernel(int64_t n, T *x, T *__restrict__ backup, const T *__restrict__ d,
+                                                       T t, int32_t *__restrict__ changed) {
     constexpr int N = VEC ? Vec16<T>::N : 1;
+    constexpr int U = 4;
     const int64_t nthreads = (int64_t)gridDim.x * kBlock;
     bool diff = false;
     const int64_t nvec = n / N;
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * 2; base < nvec; base += nthreads * 2) {
+    const T *src = FIRST ? x : backup;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
+        T xo[U][N], dv[U][N];
+        // all loads first: x is read and written through the same pointer, so the compiler
+        // cannot hoist the later loads above the earlier stores by itself
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
-            if (v >= nvec) continue;
-            const int64_t i = v * N;
-            T xo[N], dv[N], xn[N];
-            if constexpr (VEC) {
-                load16(FIRST ? x + i : backup + i, xo);
-                load16(d + i, dv);
-            } else {
-                xo[0] = FIRST ? x[i] : backup[i];
-                dv[0] = d[i];
+            if (v < nvec) {
+                if constexpr (VEC) { load16(src + v * N, xo[u]); load16(d + v * N, dv[u]); }
+                else { xo[u][0] = src[v]; dv[u][0] = d[v]; }
             }
+        }
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                xn[j] = dfma(t, dv[j], xo[j]);                      // :124
-                diff |= !is_equal(xn[j], xo[j]);                     // :128
-            }
-            if constexpr (VEC) {
-                store16(x + i, xn);
-                if (FIRST) store16(backup + i, xo);                  // :118
-            } else {
-                x[i] = xn[0];
-                if (FIRST) backup[i] = xo[0];
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
+            if (v < nvec) {
+                T xn[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    xn[j] = dfma(t, dv[u][j], xo[u][j]);             // :124
+                    diff |= !is_equal(xn[j], xo[u][j]);              // :128
+                }
+                if constexpr (VEC) { store16(x + v * N, xn); if (FIRST) store16(backup + v * N, xo[u]); }   // :118
+                else { x[v] = xn[0]; if (FIRST) backup[v] = xo[u][0]; }
             }
         }
     }
     if constexpr (VEC) {
         const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (i < n) {
-            const T xo = FIRST ? x[i] : backup[i];
+            const T xo = src[i];
             const T xn = dfma(t, d[i], xo);
             diff |= !is_equal(xn, xo);
             x[i] = xn;
             if (FIRST) backup[i] = xo;
         }
     }
-    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+    __shared__ int lds_flag;
+    block_raise_flag(diff, changed, &lds_flag);
 }
 
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -62,7 +64,7 @@ template <typename T>
 static void launch_trial(hipStream_t s, int64_t n, T *x, T *backup, const T *d, T t, bool first, int32_t *changed) {
     DZO_TIMED("lbfgs_trial", s);
     const bool vec = al16(x) && al16(backup) && al16(d);
-    const int grid = stream_grid(n, (vec ? Vec16<T>::N : 1) * 2);
+    const int grid = stream_grid(n, (vec ? Vec16<T>::N : 1) * 4);
 #define L(V, F) hipLaunchKernelGGL((trial_kernel<T, V, F>), dim3(grid), dim3(kBlock), 0, s, n, x, backup, d, t, changed)
     if (vec) { if (first) L(true, true); else L(true, false); }
     else { if (first) L(false, true); else L(false, false); }
@@ -73,6 +75,7 @@ int32_t core_alloc(OptCore &c) {
     DZO_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     DZO_HIP(hipMalloc((void **)&c.ws, sizeof(double) * (2 * kMaxPartialBlocks + 16)));
     DZO_HIP(hipMemset(c.ws, 0, sizeof(double) * (2 * kMaxPartialBlocks + 16)));
+    DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     DZO_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * 8, hipHostMallocDefault));
     return DZO_OK;
 }

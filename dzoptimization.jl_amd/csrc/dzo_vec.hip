@@ -160,7 +160,8 @@ __global__ __launch_bounds__(kBlock) void isequal_kernel(int64_t n, const T *__r
             for (int j = 0; j < N; ++j) diff |= !is_equal(av[j], bv[j]);
         },
         [&](int64_t i) { diff |= !is_equal(a[i], b[i]); });
-    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(differs, 1);  // boolean: order-free
+    __shared__ int lds_flag;
+    block_raise_flag(diff, differs, &lds_flag);
 }
 
 // ---------------------------------------------------------------------------- launchers

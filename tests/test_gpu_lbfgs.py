@@ -206,30 +206,67 @@ def test_constructor_state_matches_reference_init():
                            dzo.DeviceArray.from_host(orc.rosenbrock_chain_x0(8)), -1.0, 3)
 
 
+def _sync_from_oracle(opt, ref):
+    """Upload the oracle's complete state into the GPU optimizer ("state
+    uploaded from the CPU restatement each checked step, so trajectories cannot diverge")."""
+    opt.current_point.upload(ref.current_point)
+    opt.current_gradient.upload(ref.current_gradient)
+    opt.set_objective_value(ref.current_objective_value)
+    S, Y = ref.history_arrays()
+    opt.set_history(S, Y, ref.rho_history, iteration_count=ref.iteration_count)
+
+
 @pytest.mark.parametrize("mode", [dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM], ids=["chain", "gram"])
-@pytest.mark.parametrize("n,m,steps", [(2, 3, 40), (1000, 5, 60), (4099, 20, 60)])
-def test_step_trajectory_matches_oracle(n, m, steps, mode):
+@pytest.mark.parametrize("n,m,steps", [(2, 3, 60), (1000, 5, 80), (4099, 20, 80)])
+def test_each_step_matches_oracle_on_identical_state(n, m, steps, mode):
+    """Per-step parity: every step!() starts from the oracle's state and must reproduce the
+    oracle's next state.  L-BFGS on a non-convex objective amplifies last-bit differences
+    of the dot products from step to step, so free-running trajectories of ANY two
+    implementations with different reduction orders drift apart (see the free-running test)."""
     opt, ref, _ = _gpu_and_oracle(n, m, mode=mode)
+    worst = 0.0
     for it in range(steps):
+        _sync_from_oracle(opt, ref)
         opt.step(); ref.step()
         assert opt.is_stuck == ref.is_stuck and opt.iteration_count == ref.iteration_count
         if ref.is_stuck:
             break
-        assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
-        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-11, it
-        assert abs(opt.current_objective_value - ref.current_objective_value) <= 1e-10 * abs(ref.current_objective_value)
-        assert opt.last_trials == ref.last_trials
+        e = rel(opt.step_direction.to_host(), ref.step_direction)
+        worst = max(worst, e)
+        assert e <= TOL_DIRECTION, (it, e)
+        assert opt.last_trials == ref.last_trials, it
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-12, it
+        assert abs(opt.current_objective_value - ref.current_objective_value) <= 1e-12 * abs(ref.current_objective_value)
+        assert rel(opt.delta_point.to_host(), ref.delta_point) <= TOL_DIRECTION
+        assert rel(opt.delta_gradient.to_host(), ref.delta_gradient) <= 1e-9
         assert opt.history_count == ref.history_count
         assert np.allclose(opt.rho_history, ref.rho_history, rtol=1e-9)
+    print(f"worst per-step direction error n={n} m={m}: {worst:.3e}")
+
+
+@pytest.mark.parametrize("mode", [dzo.TWOLOOP_CHAIN, dzo.TWOLOOP_GRAM], ids=["chain", "gram"])
+def test_free_running_trajectory_stays_close_then_converges(mode):
+    n, m = 1000, 5
+    opt, ref, _ = _gpu_and_oracle(n, m, mode=mode)
+    for it in range(10):                                   # early steps: still within 1e-10
+        opt.step(); ref.step()
+        assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-11, it
+        assert opt.last_trials == ref.last_trials and opt.history_count == ref.history_count
+    steps = 10
+    while not opt.is_stuck and steps < 20000:
+        opt.step(); steps += 1
+    assert opt.is_stuck and opt.current_objective_value < 1e-20
+    assert np.allclose(opt.current_point.to_host(), 1.0, atol=1e-9)
 
 
 def test_run_and_test_invariants_on_device():
     """legacy/DZOptimization.jl:998-1049 -- exact equalities hold on the GPU path too."""
-    n, m = 515, 6
+    n, m = 130, 6
     opt, _, prob = _gpu_and_oracle(n, m)
     ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
     prev_x, prev_g = opt.current_point.to_host(), opt.current_gradient.to_host()
-    for it in range(400):
+    for it in range(5000):
         opt.step()
         x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
         if opt.is_stuck:
@@ -272,10 +309,12 @@ def test_callback_path_equals_builtin_path():
     a = dzo.LBFGSOptimizer(constraint, objective, gradient, dzo.DeviceArray.from_host(x0), 1.0, m)
     ref = orc.LBFGS(ref_p, x0.copy(), 1.0, m)
     for it in range(25):
+        _sync_from_oracle(a, ref)
         a.step(); ref.step()
         assert rel(a.current_point.to_host(), ref.current_point) <= 1e-12
         assert a.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-12)
         assert np.array_equal(a.current_gradient.to_host(), ref_p.grad(a.current_point.to_host()))
+        assert a.last_trials == ref.last_trials
     assert calls["f"] >= 26 and calls["g"] == 26 and calls["c"] >= 26
 
 
