@@ -138,6 +138,153 @@ def cpu_baseline(n, m, warm, steps, threads):
     return steps / dt, f
 
 
+# ------------------------------------------------------------------------------ secondary workloads
+def quadratic_matrix(n, r=8):
+    """C2: A = D + U U'/r, D = diag(1 + 99 u) (seed 2), U entries u - 1/2 (seed 3)."""
+    dvec = 1.0 + 99.0 * pcg32_uniform(n, 2)
+    U = (pcg32_uniform(n * r, 3) - 0.5).reshape(n, r, order="F")
+    A = (U @ U.T) / r
+    A[np.diag_indices(n)] += dvec
+    return 0.5 * (A + A.T)
+
+
+def secondary_workload(args):
+    """Configs 2, 4, 5 of BASELINE.json: same JSON shape, their own metric strings."""
+    import importlib
+    import torch
+    world, rank, local = _dist_setup(args.gpus)
+    from dzo_loader import dzo
+    dzo.init(local)
+    sharding = importlib.import_module("dzoptimization_jl_amd.sharding")
+    info = dzo.device_info()
+    out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    if args.workload == "bfgs_dense":
+        n = 4096 if args.n == 10_000_000 else args.n
+        A = quadratic_matrix(n)
+        prob = dzo.Problem(dzo.QUADRATIC, n, A=A)
+        x0 = pcg32_uniform(n, 4) - 0.5
+        opt = dzo.BFGSOptimizer(prob, None, dzo.DeviceArray.from_host(x0), 1.0)
+        for _ in range(args.warmup):
+            opt.step()
+        dzo.profile_reset(); dzo.profile_enable(True)
+        _barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt.step()
+        dzo.synchronize(); _barrier(world)
+        el = sharding.max_over_ranks(time.perf_counter() - t0)
+        dzo.profile_enable(False)
+        tab = dzo.profile_table()
+        # isolated update + next direction (K8 + K9): 3 n^2 T algorithmic bytes
+        rng = np.random.default_rng(0)
+        Hd = dzo.DeviceArray.from_host(np.eye(n))
+        g = dzo.DeviceArray.from_host(rng.standard_normal(n))
+        scratch, dnext = dzo.DeviceArray(n), dzo.DeviceArray(n)
+        times = []
+        for it in range(12):
+            d, y = rng.standard_normal(n), rng.standard_normal(n)
+            lam = 0.1 if d @ y > 0 else -0.1
+            dd, yd = dzo.DeviceArray.from_host(d), dzo.DeviceArray.from_host(y)
+            dzo.synchronize()
+            t1 = time.perf_counter()
+            dzo.update_inverse_hessian_(Hd, lam, dd, yd, scratch, g, dnext)
+            times.append(time.perf_counter() - t1)
+        upd = float(np.median(times[2:]))
+        kern = {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in tab.items()}
+        kbytes = {"bfgs_symv": n * n * 8, "bfgs_update": 2 * n * n * 8}
+        for k, b in kbytes.items():
+            if k in kern:
+                kern[k]["algorithmic_GBps"] = round(b / (kern[k]["avg_us"] * 1e-6) / 1e9, 1)
+        dom = "bfgs_update"
+        out.update({"metric": "step!() calls/sec and achieved HBM GB/s, dense BFGS n=4096 fp64 (config 2)",
+                    "value": round(world * args.steps / el, 3), "unit": "step!() calls/s",
+                    "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
+                    "config": {"workload": f"dense BFGS on convex quadratic 1/2 x'Ax, n={n}, fp64 (BASELINE configs[1])",
+                               "objective_evals_per_step": round(opt.objective_evaluations / max(opt.iteration_count, 1), 2),
+                               "device": info["name"]},
+                    "update_plus_direction": {"host_wall_us": round(upd * 1e6, 1), "algorithmic_bytes": 3 * n * n * 8,
+                                              "algorithmic_GBps": round(3 * n * n * 8 / upd / 1e9, 1)},
+                    "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern.get(dom, {}).get("algorithmic_GBps"),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(kern.get(dom, {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "note": "H = 128 MiB fits the 256 MiB Infinity Cache"},
+                    "kernels": kern})
+    elif args.workload == "bfgs_batched":
+        n = 256 if args.n == 10_000_000 else args.n
+        B = args.batch
+        lo = rank * B                                              # weak scaling: B instances per GPU
+        X0 = np.stack([pcg32_uniform(n, 1000 + lo + b) for b in range(B)])
+        batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
+        flag = sharding.ConvergenceFlag(poll=1)
+        batch.step(args.warmup, poll=False)
+        dzo.synchronize()
+        dzo.profile_reset(); dzo.profile_enable(True)
+        _barrier(world)
+        it0 = int(batch.iteration_count.to_host().sum())
+        t0 = time.perf_counter()
+        chunk = max(1, args.poll)
+        done_steps = 0
+        while done_steps < args.steps:
+            k = min(chunk, args.steps - done_steps)
+            batch.step(k, poll=False)
+            done_steps += k
+            flag.update(batch.count_active() == 0)                 # RCCL all-reduce of the flag when N > 1
+        dzo.synchronize(); _barrier(world)
+        el = sharding.max_over_ranks(time.perf_counter() - t0)
+        dzo.profile_enable(False)
+        it1 = int(batch.iteration_count.to_host().sum())
+        inst_steps = sharding.sum_over_ranks(float(it1 - it0))
+        tab = dzo.profile_table()
+        kern = {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in tab.items()}
+        ach = 3 * n * n * 8 * (it1 - it0) / (1e-3 * tab["bfgs_batch_step"][1]) / 1e9 if "bfgs_batch_step" in tab else None
+        out.update({"metric": "instance-step!() calls/sec, batched dense BFGS n=256 fp64 (config 5)",
+                    "value": round(inst_steps / el, 1), "unit": "instance-step!() calls/s",
+                    "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
+                    "config": {"workload": f"batched BFGS, {B} instances/GPU x n={n}, chained Rosenbrock, fp64 (BASELINE configs[4])",
+                               "instances_per_gpu": B, "active_at_end": batch.count_active(),
+                               "parallelism": "instances sharded by rank, RCCL all-reduce of the convergence flag only",
+                               "device": info["name"]},
+                    "roofline": {"bound": "hbm", "kernel": "bfgs_batch_step", "achieved": None if ach is None else round(ach, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "note": "3 n^2 T per accepted BFGS instance-step; line searches included in the time"},
+                    "kernels": kern})
+    else:  # lbfgs_lse_f32 (config 4)
+        n = 1_000_000 if args.n == 10_000_000 else args.n
+        m = 10 if args.m == 20 else args.m
+        c = (pcg32_uniform(n, 6) - 0.5).astype(np.float32)
+        prob = dzo.Problem(dzo.LSE, n, np.float32, c=c, lam=1e-2)
+        opt = dzo.LBFGSOptimizer(None, prob, None, dzo.DeviceArray.from_host(np.zeros(n, np.float32)), 1.0, m)
+        for _ in range(m + args.warmup):
+            opt.step()
+        dzo.profile_reset(); dzo.profile_enable(True)
+        _barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt.step()
+        dzo.synchronize(); _barrier(world)
+        el = sharding.max_over_ranks(time.perf_counter() - t0)
+        dzo.profile_enable(False)
+        tab = dzo.profile_table()
+        k = opt.history_count
+        kern = {kk: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for kk, v in tab.items()}
+        tl = sum(1e3 * tab[x][1] for x in ("lbfgs_gram_pass", "lbfgs_gram_reduce", "lbfgs_gram_finish", "lbfgs_combine") if x in tab) / max(tab.get("lbfgs_combine", (1, 0))[0], 1)
+        out.update({"metric": "step!() calls/sec, L-BFGS m=10 log-sum-exp n=10^6 fp32 (config 4)",
+                    "value": round(world * args.steps / el, 2), "unit": "step!() calls/s",
+                    "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f32",
+                    "config": {"workload": f"L-BFGS m={m} on log-sum-exp + ridge, n={n}, fp32 (BASELINE configs[3])",
+                               "stuck": opt.is_stuck, "device": info["name"]},
+                    "roofline": {"bound": "hbm", "kernel": "two_loop", "achieved": round((4 * k + 2) * n * 4 / (tl * 1e-6) / 1e9, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((4 * k + 2) * n * 4 / (tl * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "note": "launch-latency-bound at this size (4 launches, 168 MB)"},
+                    "kernels": kern})
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -152,7 +299,13 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=None, help="n of the CPU sample (default: same n)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32"],
+                    help="lbfgs = BASELINE configs[2] (the headline; default). The others are the remaining "
+                         "BASELINE configs, reported as secondary lines.")
+    ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
     args = ap.parse_args()
+    if args.workload != "lbfgs":
+        return secondary_workload(args)
 
     import torch  # first: loads the ROCm runtime that libdzo_hip.so then shares
     world, rank, local = _dist_setup(args.gpus)
@@ -175,9 +328,11 @@ def main():
         opt.step()
     f_start = opt.current_objective_value
 
+    import importlib
+    sharding = importlib.import_module("dzoptimization_jl_amd.sharding")
+    flag = sharding.ConvergenceFlag(poll=args.poll)     # RCCL all-reduce(MIN) of one int32 when N > 1
     if world > 1:
         import torch.distributed as dist
-        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
 
     dzo.profile_reset()
     dzo.profile_enable(not args.no_kernel_events)
@@ -187,23 +342,14 @@ def main():
     for s in range(args.steps):
         opt.step()
         trials += opt.last_trials
-        if world > 1 and (s + 1) % args.poll == 0:
-            flag.fill_(1 if opt.is_stuck else 0)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # RCCL: global "everyone converged" flag
+        flag.update(opt.is_stuck)                       # global "everyone converged" flag
     dzo.synchronize()
     _barrier(world)
     elapsed = time.perf_counter() - t0
     dzo.profile_enable(False)
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        stuck = torch.tensor([1 if opt.is_stuck else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(stuck, op=dist.ReduceOp.MAX)
-        any_stuck = bool(stuck.item())
-    else:
-        any_stuck = opt.is_stuck
+    elapsed = sharding.max_over_ranks(elapsed)
+    any_stuck = sharding.max_over_ranks(1.0 if opt.is_stuck else 0.0) > 0
 
     table = dzo.profile_table()
     if rank != 0:

@@ -1,0 +1,337 @@
+# DZOptimizationAMD.jl -- Julia host module over the C ABI of include/dzo.h (libdzo_hip.so).
+#
+# Drop-in for the in-place BFGS / L-BFGS `step!()` path of dzhang314/DZOptimization.jl on an
+# AMD MI355X: the same constructors, the same public fields, `step!`, and the termination flag
+# under its three historical names (`is_stuck` live src/DZOptimization.jl:327, `has_terminated`
+# legacy/DZOptimization.jl:478,738, `has_converged` README.md:38).  No CUDA.jl, no AMDGPU.jl:
+# device memory and kernels live behind `ccall`.
+#
+# NOT EXERCISED IN THE BUILD CONTAINER (there is no Julia there); the tested twin of this file
+# is the Python module next to it, which binds the very same symbols with ctypes.  Keep this
+# file thin enough to be correct by inspection: every method is one ccall.
+#
+#   using DZOptimizationAMD
+#   x   = HipVector(rand(10_000_000))
+#   opt = LBFGSOptimizer(nothing, RosenbrockChain(length(x)), nothing, x, 1.0, 20)
+#   while !opt.is_stuck[]; step!(opt); end
+module DZOptimizationAMD
+
+using LinearAlgebra
+import LinearAlgebra: axpy!, axpby!, dot, norm, rmul!
+
+export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, step!,
+       RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem
+
+const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
+
+const DZO_F32, DZO_F64 = Cint(0), Cint(1)
+dtype_code(::Type{Float32}) = DZO_F32
+dtype_code(::Type{Float64}) = DZO_F64
+
+struct DzoError <: Exception
+    code::Int
+    msg::String
+end
+
+function check(rc::Integer)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:dzo_last_error, libdzo), Cstring, ()))
+    rc == 3 && throw(AssertionError(msg))          # the reference's @assert
+    throw(DzoError(rc, msg))
+end
+
+const _initialised = Ref(false)
+function init(device::Integer=0)
+    check(ccall((:dzo_init, libdzo), Cint, (Cint,), device))
+    _initialised[] = true
+end
+ensure_init() = _initialised[] || init(parse(Int, get(ENV, "DZO_DEVICE", "0")))
+
+################################################################################ HipVector
+
+"""Dense device vector: the array type `A<:AbstractArray{T}` the reference's optimizers are
+generic over (src/DZOptimization.jl:101,179,321)."""
+mutable struct HipVector{T<:Union{Float32,Float64}} <: AbstractVector{T}
+    ptr::Ptr{Cvoid}
+    len::Int
+    owner::Bool
+    function HipVector{T}(::UndefInitializer, n::Integer) where {T}
+        ensure_init()
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dzo_malloc, libdzo), Cint, (Ref{Ptr{Cvoid}}, Int64), p, max(n * sizeof(T), 16)))
+        v = new{T}(p[], n, true)
+        finalizer(v) do w
+            w.owner && w.ptr != C_NULL && ccall((:dzo_free, libdzo), Cint, (Ptr{Cvoid},), w.ptr)
+            w.ptr = C_NULL
+        end
+        return v
+    end
+    HipVector{T}(p::Ptr{Cvoid}, n::Integer) where {T} = new{T}(p, n, false)   # borrowed view
+end
+
+function HipVector(a::AbstractArray{T}) where {T<:Union{Float32,Float64}}
+    v = HipVector{T}(undef, length(a))
+    h = Array{T}(vec(a))
+    check(ccall((:dzo_memcpy_h2d, libdzo), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), v.ptr, h, sizeof(h)))
+    return v
+end
+
+Base.size(v::HipVector) = (v.len,)
+Base.length(v::HipVector) = v.len
+Base.similar(v::HipVector{T}) where {T} = HipVector{T}(undef, v.len)
+Base.getindex(v::HipVector, i::Int) = Array(v)[i]          # debugging only: one D2H per call
+function Base.Array(v::HipVector{T}) where {T}
+    h = Vector{T}(undef, v.len)
+    check(ccall((:dzo_memcpy_d2h, libdzo), Cint, (Ptr{T}, Ptr{Cvoid}, Int64), h, v.ptr, sizeof(h)))
+    return h
+end
+function Base.copy!(dst::HipVector{T}, src::HipVector{T}) where {T}
+    check(ccall((:dzo_copy, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}), src.len, dtype_code(T), src.ptr, dst.ptr))
+    return dst
+end
+Base.copy(v::HipVector) = copy!(similar(v), v)
+function Base.fill!(v::HipVector{T}, a) where {T}
+    check(ccall((:dzo_fill, libdzo), Cint, (Int64, Cint, Cdouble, Ptr{Cvoid}), v.len, dtype_code(T), Float64(a), v.ptr))
+    return v
+end
+function Base.isequal(a::HipVector{T}, b::HipVector{T}) where {T}
+    r = Ref{Cint}(0)
+    check(ccall((:dzo_isequal, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}), a.len, dtype_code(T), a.ptr, b.ptr, r))
+    return r[] != 0
+end
+
+# the L1 method set the reference calls (src/DZOptimization.jl:4)
+function axpy!(a::Number, x::HipVector{T}, y::HipVector{T}) where {T}
+    check(ccall((:dzo_axpy, libdzo), Cint, (Int64, Cint, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}), x.len, dtype_code(T), Float64(a), x.ptr, y.ptr))
+    return y
+end
+function axpby!(a::Number, x::HipVector{T}, b::Number, y::HipVector{T}) where {T}
+    check(ccall((:dzo_axpby, libdzo), Cint, (Int64, Cint, Cdouble, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), x.len, dtype_code(T), Float64(a), x.ptr, Float64(b), y.ptr))
+    return y
+end
+function rmul!(x::HipVector{T}, a::Number) where {T}
+    check(ccall((:dzo_scal, libdzo), Cint, (Int64, Cint, Cdouble, Ptr{Cvoid}), x.len, dtype_code(T), Float64(a), x.ptr))
+    return x
+end
+function dot(x::HipVector{T}, y::HipVector{T}) where {T}
+    r = Ref{Cdouble}(0)
+    check(ccall((:dzo_dot, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), x.len, dtype_code(T), x.ptr, y.ptr, r))
+    return T(r[])
+end
+function norm(x::HipVector{T}) where {T}
+    r = Ref{Cdouble}(0)
+    check(ccall((:dzo_nrm2, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ref{Cdouble}), x.len, dtype_code(T), x.ptr, r))
+    return T(r[])
+end
+
+################################################################################ built-in objectives
+
+struct BuiltinProblem{T}
+    handle::Ptr{Cvoid}
+    n::Int
+    keep::Any
+end
+function _problem(kind, n, ::Type{T}; A=nothing, c=nothing, lambda=0.0) where {T}
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_problem_create, libdzo), Cint,
+                (Cint, Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                kind, n, dtype_code(T), A === nothing ? C_NULL : A.ptr, c === nothing ? C_NULL : c.ptr, lambda, h))
+    return BuiltinProblem{T}(h[], n, (A, c))
+end
+Rosenbrock2D(::Type{T}=Float64) where {T} = _problem(0, 2, T)
+RosenbrockChain(n::Integer, ::Type{T}=Float64) where {T} = _problem(1, n, T)
+DenseQuadratic(A::HipVector{T}, n::Integer) where {T} = _problem(2, n, T; A=A)      # A column-major n*n
+LogSumExp(c::HipVector{T}, lambda) where {T} = _problem(3, length(c), T; c=c, lambda=lambda)
+function (p::BuiltinProblem{T})(x::HipVector{T}) where {T}                           # objective_function(x)
+    f = Ref{Cdouble}(0)
+    check(ccall((:dzo_problem_eval, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), p.handle, x.ptr, f))
+    return T(f[])
+end
+function gradient!(p::BuiltinProblem{T}, g::HipVector{T}, x::HipVector{T}) where {T}
+    check(ccall((:dzo_problem_grad, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), p.handle, g.ptr, x.ptr))
+    return g
+end
+
+################################################################################ callbacks
+
+# C trampolines: ctx is a pointer to a Julia Ref holding (constraint!, objective, gradient!, T, n)
+struct Callbacks{C,F,G,T}
+    constraint!::C
+    objective::F
+    gradient!::G
+    n::Int
+end
+function _c_constraint(ctx::Ptr{Cvoid}, x::Ptr{Cvoid})::Cint
+    cb = unsafe_pointer_to_objref(ctx)[]
+    return Cint(cb.constraint!(_view(cb, x)) ? 1 : 0)
+end
+function _c_objective(ctx::Ptr{Cvoid}, x::Ptr{Cvoid})::Cdouble
+    cb = unsafe_pointer_to_objref(ctx)[]
+    return Cdouble(cb.objective(_view(cb, x)))
+end
+function _c_gradient(ctx::Ptr{Cvoid}, g::Ptr{Cvoid}, x::Ptr{Cvoid})::Cvoid
+    cb = unsafe_pointer_to_objref(ctx)[]
+    cb.gradient!(_view(cb, g), _view(cb, x))
+    return nothing
+end
+_view(cb::Callbacks{C,F,G,T}, p::Ptr{Cvoid}) where {C,F,G,T} = HipVector{T}(p, cb.n)
+
+################################################################################ L-BFGS
+
+abstract type AbstractOptimizer{T,A} end
+function step! end
+
+"""`LBFGSOptimizer(constraint!, objective, gradient!, x0, step, m)` (src/DZOptimization.jl:400-407)
+or the full form with `f0, g0` (:347-356).  `objective` may be a `BuiltinProblem`, in which case
+the whole step runs on the device.  Aliases `x0` as `current_point` (:393)."""
+struct LBFGSOptimizer{T,A,C,F,G} <: AbstractOptimizer{T,A}
+    handle::Ptr{Cvoid}
+    constraint_function!::C
+    objective_function::F
+    gradient_function!::G
+    current_point::A
+    history_length::Int
+    keep::Any
+end
+
+function LBFGSOptimizer(constraint!::C, objective::F, gradient!::G, x0::HipVector{T},
+                        initial_step_length::Real, history_length::Int) where {T,C,F,G}
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    if objective isa BuiltinProblem && constraint! === nothing
+        check(ccall((:dzo_lbfgs_create_problem, libdzo), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                    objective.handle, history_length, x0.ptr, initial_step_length, h))
+        return LBFGSOptimizer{T,HipVector{T},C,F,G}(h[], constraint!, objective, gradient!, x0, history_length, nothing)
+    end
+    cb = Ref(Callbacks{C,F,G,T}(constraint!, objective, gradient!, length(x0)))
+    cf = constraint! === nothing ? C_NULL : @cfunction(_c_constraint, Cint, (Ptr{Cvoid}, Ptr{Cvoid}))
+    check(ccall((:dzo_lbfgs_create_callbacks, libdzo), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                cf, @cfunction(_c_objective, Cdouble, (Ptr{Cvoid}, Ptr{Cvoid})),
+                @cfunction(_c_gradient, Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})),
+                pointer_from_objref(cb), length(x0), history_length, dtype_code(T), x0.ptr, initial_step_length, h))
+    return LBFGSOptimizer{T,HipVector{T},C,F,G}(h[], constraint!, objective, gradient!, x0, history_length, cb)
+end
+
+function LBFGSOptimizer(constraint!::C, objective::F, gradient!::G, x0::HipVector{T}, f0::Real, g0::HipVector{T},
+                        initial_step_length::Real, history_length::Int) where {T,C,F,G}
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_lbfgs_create, libdzo), Cint, (Int64, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Ptr{Cvoid}}),
+                length(x0), history_length, dtype_code(T), x0.ptr, g0.ptr, f0, initial_step_length, h))
+    cb = Ref(Callbacks{C,F,G,T}(constraint!, objective, gradient!, length(x0)))
+    cf = constraint! === nothing ? C_NULL : @cfunction(_c_constraint, Cint, (Ptr{Cvoid}, Ptr{Cvoid}))
+    check(ccall((:dzo_lbfgs_set_callbacks, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                h[], cf, @cfunction(_c_objective, Cdouble, (Ptr{Cvoid}, Ptr{Cvoid})),
+                @cfunction(_c_gradient, Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), pointer_from_objref(cb)))
+    return LBFGSOptimizer{T,HipVector{T},C,F,G}(h[], constraint!, objective, gradient!, x0, history_length, (cb, g0))
+end
+
+"""`step!(opt)` (src/DZOptimization.jl:454-509)."""
+step!(opt::LBFGSOptimizer) = (check(ccall((:dzo_lbfgs_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
+
+_lb_i(o, w) = (v = Ref{Int64}(0); check(ccall((:dzo_lbfgs_get_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), getfield(o, :handle), w, v)); v[])
+_lb_s(o, w) = (v = Ref{Cdouble}(0); check(ccall((:dzo_lbfgs_get_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), getfield(o, :handle), w, v)); v[])
+function _lb_p(o::LBFGSOptimizer{T}, w, idx=0) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_lbfgs_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}), getfield(o, :handle), w, idx, p))
+    return HipVector{T}(p[], length(getfield(o, :current_point)))
+end
+function _lb_hist(o::LBFGSOptimizer{T}, sym) where {T}
+    buf = Vector{Cdouble}(undef, 64); cnt = Ref{Cint}(0)
+    check(ccall((sym, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), getfield(o, :handle), buf, 64, cnt))
+    return T.(buf[1:cnt[]])
+end
+
+# Public fields of the reference (src/DZOptimization.jl:321-344); scalars come back boxed in
+# 0-dim arrays like the reference's Array{T,0}, so `opt.is_stuck[]` reads the same.
+function Base.getproperty(o::LBFGSOptimizer{T}, s::Symbol) where {T}
+    s in (:is_stuck, :has_terminated, :has_converged) && return fill(_lb_i(o, 0) != 0)
+    s === :iteration_count && return fill(Int(_lb_i(o, 1)))
+    s === :current_objective_value && return fill(T(_lb_s(o, 0)))
+    s === :delta_objective_value && return fill(T(_lb_s(o, 1)))
+    s === :delta_point && return _lb_p(o, 1)
+    s === :current_gradient && return _lb_p(o, 2)
+    s === :delta_gradient && return _lb_p(o, 3)
+    s === :step_direction && return _lb_p(o, 4)
+    s === :delta_point_history && return [_lb_p(o, 5, i - 1) for i in 1:_lb_i(o, 4)]
+    s === :delta_gradient_history && return [_lb_p(o, 6, i - 1) for i in 1:_lb_i(o, 4)]
+    s === :rho_history && return _lb_hist(o, :dzo_lbfgs_get_rho)
+    s === :alpha_history && return _lb_hist(o, :dzo_lbfgs_get_alpha)
+    return getfield(o, s)
+end
+
+################################################################################ dense BFGS
+
+"""`BFGSOptimizer(objective, gradient!, [constraint!,] x0, initial_step_length)` (README.md:33-36,
+legacy/DZOptimization.jl:753-766).  Copies `x0` (:769)."""
+struct BFGSOptimizer{T,F,G,C}
+    handle::Ptr{Cvoid}
+    objective_function::F
+    gradient_function!::G
+    constraint_function!::C
+    n::Int
+    keep::Any
+end
+BFGSOptimizer(objective, gradient!, x0::HipVector, step::Real) = BFGSOptimizer(objective, gradient!, nothing, x0, step)
+function BFGSOptimizer(objective::F, gradient!::G, constraint!::C, x0::HipVector{T}, step::Real) where {T,F,G,C}
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    if objective isa BuiltinProblem && constraint! === nothing
+        check(ccall((:dzo_bfgs_create_problem, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), objective.handle, x0.ptr, step, h))
+        return BFGSOptimizer{T,F,G,C}(h[], objective, gradient!, constraint!, length(x0), nothing)
+    end
+    cb = Ref(Callbacks{C,F,G,T}(constraint!, objective, gradient!, length(x0)))
+    cf = constraint! === nothing ? C_NULL : @cfunction(_c_constraint, Cint, (Ptr{Cvoid}, Ptr{Cvoid}))
+    check(ccall((:dzo_bfgs_create_callbacks, libdzo), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                @cfunction(_c_objective, Cdouble, (Ptr{Cvoid}, Ptr{Cvoid})),
+                @cfunction(_c_gradient, Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), cf,
+                pointer_from_objref(cb), length(x0), dtype_code(T), x0.ptr, step, h))
+    return BFGSOptimizer{T,F,G,C}(h[], objective, gradient!, constraint!, length(x0), cb)
+end
+
+"""`step!(opt)` (legacy/DZOptimization.jl:891-994)."""
+step!(opt::BFGSOptimizer) = (check(ccall((:dzo_bfgs_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
+
+_bf_i(o, w) = (v = Ref{Int64}(0); check(ccall((:dzo_bfgs_get_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), getfield(o, :handle), w, v)); v[])
+_bf_s(o, w) = (v = Ref{Cdouble}(0); check(ccall((:dzo_bfgs_get_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), getfield(o, :handle), w, v)); v[])
+function _bf_p(o::BFGSOptimizer{T}, w, len=getfield(o, :n)) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_bfgs_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), getfield(o, :handle), w, p))
+    return HipVector{T}(p[], len)
+end
+function Base.getproperty(o::BFGSOptimizer{T}, s::Symbol) where {T}
+    s in (:has_converged, :has_terminated, :is_stuck) && return fill(_bf_i(o, 0) != 0)
+    s === :iteration_count && return fill(Int(_bf_i(o, 1)))
+    s === :last_step_type && return fill(Int(_bf_i(o, 3)))       # 0 Null, 1 GradientDescent, 2 BFGS (:727-731)
+    s === :current_objective_value && return fill(T(_bf_s(o, 0)))
+    s === :last_step_length && return fill(T(_bf_s(o, 1)))
+    s === :current_point && return _bf_p(o, 0)
+    s === :delta_point && return _bf_p(o, 1)
+    s === :current_gradient && return _bf_p(o, 2)
+    s === :delta_gradient && return _bf_p(o, 3)
+    s === :next_step_direction && return _bf_p(o, 4)
+    s === :approximate_inverse_hessian && return _bf_p(o, 5, getfield(o, :n)^2)   # column-major n*n
+    return getfield(o, s)
+end
+
+################################################################################ AdGD
+
+"""`AdGDOptimizer(constraint!, objective, gradient!, x0, initial_step_length)`
+(src/DZOptimization.jl:245-251); built-in objectives only in this thin binding."""
+struct AdGDOptimizer{T}
+    handle::Ptr{Cvoid}
+    current_point::HipVector{T}
+    keep::Any
+end
+function AdGDOptimizer(::Nothing, objective::BuiltinProblem{T}, ::Any, x0::HipVector{T}, step::Real) where {T}
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_adgd_create_problem, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), objective.handle, x0.ptr, step, h))
+    return AdGDOptimizer{T}(h[], x0, objective)
+end
+step!(opt::AdGDOptimizer) = (check(ccall((:dzo_adgd_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
+
+end # module
