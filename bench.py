@@ -255,25 +255,35 @@ def secondary_workload(args):
         c = (pcg32_uniform(n, 6) - 0.5).astype(np.float32)
         prob = dzo.Problem(dzo.LSE, n, np.float32, c=c, lam=1e-2)
         opt = dzo.LBFGSOptimizer(None, prob, None, dzo.DeviceArray.from_host(np.zeros(n, np.float32)), 1.0, m)
-        for _ in range(m + args.warmup):
+        # this objective is strongly convex: fp32 L-BFGS is stuck (converged) after ~20-40 steps, so
+        # the timed region is the run itself (history still filling during the first m steps)
+        for _ in range(min(args.warmup, 2)):
             opt.step()
         dzo.profile_reset(); dzo.profile_enable(True)
         _barrier(world)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        done = 0
+        ksum = 0
+        while done < args.steps and not opt.is_stuck:
             opt.step()
+            done += 1
+            ksum += opt.history_count
         dzo.synchronize(); _barrier(world)
         el = sharding.max_over_ranks(time.perf_counter() - t0)
         dzo.profile_enable(False)
         tab = dzo.profile_table()
-        k = opt.history_count
+        args.steps = max(done, 1)
+        k = ksum / max(done, 1)
         kern = {kk: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for kk, v in tab.items()}
         tl = sum(1e3 * tab[x][1] for x in ("lbfgs_gram_pass", "lbfgs_gram_reduce", "lbfgs_gram_finish", "lbfgs_combine") if x in tab) / max(tab.get("lbfgs_combine", (1, 0))[0], 1)
+        tl = max(tl, 1e-9)
+        out["steps"] = done
         out.update({"metric": "step!() calls/sec, L-BFGS m=10 log-sum-exp n=10^6 fp32 (config 4)",
                     "value": round(world * args.steps / el, 2), "unit": "step!() calls/s",
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f32",
                     "config": {"workload": f"L-BFGS m={m} on log-sum-exp + ridge, n={n}, fp32 (BASELINE configs[3])",
-                               "stuck": opt.is_stuck, "device": info["name"]},
+                               "stuck_at_end": opt.is_stuck, "mean_history": round(k, 2),
+                               "f_end": opt.current_objective_value, "device": info["name"]},
                     "roofline": {"bound": "hbm", "kernel": "two_loop", "achieved": round((4 * k + 2) * n * 4 / (tl * 1e-6) / 1e9, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((4 * k + 2) * n * 4 / (tl * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                  "traffic": None, "note": "launch-latency-bound at this size (4 launches, 168 MB)"},

@@ -58,6 +58,8 @@ struct dzo_lbfgs_s {
     double *gram_partials = nullptr;        // [kGramValues*kMaxHistory][gram_grid]
     double *link_partials = nullptr;        // [4][kMaxPartialBlocks] ping-pong + yy
     int gram_grid = 0;
+    bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
+    int gram_variant = 1;           // 1 = lane-distributed accumulators, 0 = pair-per-wave
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
@@ -226,98 +228,138 @@ template <typename T> struct GramParams {
     double *partials;           // [kGramValues * k][gridDim.x]
 };
 
-// Each block walks tiles of 64 lanes x U 16-B vectors; its 4 waves all read the tile of
-// g, s_p, y_p (L1 hits after the first wave) and split the k pairs between them, so a lane
-// carries 5*PPW fp64 accumulators instead of 5*k.  History vectors are streamed with
-// non-temporal loads (each element is used exactly once per pass).
-template <typename T, int PPW, bool VEC, int U>
-__global__ __launch_bounds__(kBlock) void gram_pass_kernel(GramParams<T> p) {
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-wide sums of FIVE values with 9 cross-lane exchanges instead of 5 x 6: a transposed
+// ("reduce-scatter") butterfly -- at the xor-32 / 16 / 8 steps a lane keeps only part of the
+// values and ships the rest to its partner, so after three steps every lane owns ONE value,
+// which the xor-4 / 2 / 1 steps finish.  Totals come back through v_readlane (scalar, no LDS).
+// Fixed association order -> deterministic.
+__device__ __forceinline__ void wave_sum5(const double (&t)[5], int lane, double (&tot)[5]) {
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+    // xor 32: lanes with b5 = 0 keep {t0,t1,t2}, lanes with b5 = 1 keep {t3,t4}
+    const double r0 = __shfl_xor(b5 ? t[0] : t[3], 32, 64);
+    const double r1 = __shfl_xor(b5 ? t[1] : t[4], 32, 64);
+    const double r2 = __shfl_xor(b5 ? t[2] : 0.0, 32, 64);
+    const double a0 = (b5 ? t[3] : t[0]) + r0;      // t0 | t3
+    const double a1 = (b5 ? t[4] : t[1]) + r1;      // t1 | t4
+    const double a2 = t[2] + r2;                    // t2 | (unused)
+    // xor 16: (b5,b4) = 00 keeps {t0,t1}, 01 keeps {t2}, 10 keeps {t3}, 11 keeps {t4}
+    const double u0 = b5 ? (b4 ? a0 : a1) : (b4 ? a0 : a2);
+    const double u1 = (!b5 && b4) ? a1 : 0.0;
+    const double v0 = __shfl_xor(u0, 16, 64);
+    const double v1 = __shfl_xor(u1, 16, 64);
+    const double c0 = (b5 ? (b4 ? a1 : a0) : (b4 ? a2 : a0)) + v0;   // t0 | t2 | t3 | t4
+    const double c1 = a1 + v1;                                         // t1 (group 00 only)
+    // xor 8: group 00 splits {t0,t1} by b3; the other groups hold one value already
+    const bool g00 = !b5 && !b4;
+    const double x = __shfl_xor(g00 ? (b3 ? c0 : c1) : c0, 8, 64);
+    double e = (g00 ? (b3 ? c1 : c0) : c0) + x;
+    e += __shfl_xor(e, 4, 64);
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 1, 64);
+    tot[0] = readlane_f64(e, 0);
+    tot[1] = readlane_f64(e, 8);
+    tot[2] = readlane_f64(e, 16);
+    tot[3] = readlane_f64(e, 32);
+    tot[4] = readlane_f64(e, 48);
+}
+
+// Gram pass, lane-distributed accumulators (the default).  All waves of all blocks walk the
+// pairs in the same order and read 16-B-per-lane contiguous chunks of ONE stream at a time --
+// the access pattern of combine_kernel, which HBM serves ~10 % faster than the pair-per-wave
+// variant's 8 concurrent streams per block (measured: equal queue depth, lower DRAM
+// efficiency).  The 5 dot products of a (tile, pair) are reduced across the wave by a
+// butterfly and added into lane i's accumulators for pair i, so a lane carries 5 fp64
+// accumulators whatever k is (k <= 64 = wave width), occupancy stays high, and no operand is
+// loaded twice.  VALU/LDS cost of the butterflies: ~15 % of the memory time at U = 4.
+template <typename T, bool VEC, int U>
+__global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double acc[PPW][kGramValues];
+    const int wave = threadIdx.x >> 6;
+    double acc[kGramValues];
 #pragma unroll
-    for (int q = 0; q < PPW; ++q)
-#pragma unroll
-        for (int c = 0; c < kGramValues; ++c) acc[q][c] = 0;
-
+    for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
     const T *sp = p.sp, *yp = p.yp;
+    const int k = p.k;
     const int64_t nvec = p.n / N;
-    const int64_t tile = 64 * U;                       // vectors per block-iteration
-    for (int64_t base = (int64_t)blockIdx.x * tile; base < nvec; base += (int64_t)gridDim.x * tile) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
         T gv[U][N], spv[U][N], ypv[U][N];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t vi = base + u * 64 + lane;
+            const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
             ok[u] = vi < nvec;
             if (ok[u]) {
-                L::load(p.g + vi * N, gv[u]);
-                L::load(sp + vi * N, spv[u]);
-                L::load(yp + vi * N, ypv[u]);
+                L::load_nt(p.g + vi * N, gv[u]);
+                L::load_nt(sp + vi * N, spv[u]);
+                L::load_nt(yp + vi * N, ypv[u]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { gv[u][j] = 0; spv[u][j] = 0; ypv[u][j] = 0; }
             }
         }
+        for (int i = 0; i < k; ++i) {
+            const T *si = p.s[i];
+            const T *yi = p.y[i];
+            T sv[U][N], yv[U][N];
 #pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            const int i = wave + kWaves * q;
-            if (i < p.k) {
-                const T *si = p.s[i];
-                const T *yi = p.y[i];
-                T sv[U][N], yv[U][N];
+            for (int u = 0; u < U; ++u) {
+                if (ok[u]) {
+                    const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
+                    L::load_nt(si + vi * N, sv[u]);
+                    L::load_nt(yi + vi * N, yv[u]);
+                } else {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (ok[u]) {
-                        const int64_t vi = base + u * 64 + lane;
-                        L::load_nt(si + vi * N, sv[u]);
-                        L::load_nt(yi + vi * N, yv[u]);
-                    }
+                    for (int j = 0; j < N; ++j) { sv[u][j] = 0; yv[u][j] = 0; }
                 }
+            }
+            double t[kGramValues] = {0, 0, 0, 0, 0};
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!ok[u]) continue;
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        const double sx = (double)sv[u][j], yx = (double)yv[u][j];
-                        acc[q][0] = __builtin_fma(sx, (double)gv[u][j], acc[q][0]);
-                        acc[q][1] = __builtin_fma(yx, (double)gv[u][j], acc[q][1]);
-                        acc[q][2] = __builtin_fma(yx, (double)ypv[u][j], acc[q][2]);
-                        acc[q][3] = __builtin_fma(yx, (double)spv[u][j], acc[q][3]);
-                        acc[q][4] = __builtin_fma(sx, (double)ypv[u][j], acc[q][4]);
-                    }
+                for (int j = 0; j < N; ++j) {
+                    const double sx = (double)sv[u][j], yx = (double)yv[u][j];
+                    t[0] = __builtin_fma(sx, (double)gv[u][j], t[0]);
+                    t[1] = __builtin_fma(yx, (double)gv[u][j], t[1]);
+                    t[2] = __builtin_fma(yx, (double)ypv[u][j], t[2]);
+                    t[3] = __builtin_fma(yx, (double)spv[u][j], t[3]);
+                    t[4] = __builtin_fma(sx, (double)ypv[u][j], t[4]);
                 }
+            }
+            double tot[kGramValues];
+            wave_sum5(t, lane, tot);
+            if (lane == i) {
+#pragma unroll
+                for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
             }
         }
     }
-    // scalar tail (n not a multiple of the vector width): block 0 only, lane 0 of each wave
-    if (VEC && blockIdx.x == 0 && lane == 0) {
+    // scalar tail (n not a multiple of the vector width): lane i of wave 0 in block 0 owns pair i
+    if (VEC && blockIdx.x == 0 && wave == 0 && lane < k) {
         for (int64_t e = nvec * N; e < p.n; ++e) {
             const double ge = (double)p.g[e], spe = (double)sp[e], ype = (double)yp[e];
-#pragma unroll
-            for (int q = 0; q < PPW; ++q) {
-                const int i = wave + kWaves * q;
-                if (i < p.k) {
-                    const double sx = (double)p.s[i][e];
-                    const double yx = (double)p.y[i][e];
-                    acc[q][0] = __builtin_fma(sx, ge, acc[q][0]);
-                    acc[q][1] = __builtin_fma(yx, ge, acc[q][1]);
-                    acc[q][2] = __builtin_fma(yx, ype, acc[q][2]);
-                    acc[q][3] = __builtin_fma(yx, spe, acc[q][3]);
-                    acc[q][4] = __builtin_fma(sx, ype, acc[q][4]);
-                }
-            }
+            const double sx = (double)p.s[lane][e], yx = (double)p.y[lane][e];
+            acc[0] = __builtin_fma(sx, ge, acc[0]);
+            acc[1] = __builtin_fma(yx, ge, acc[1]);
+            acc[2] = __builtin_fma(yx, ype, acc[2]);
+            acc[3] = __builtin_fma(yx, spe, acc[3]);
+            acc[4] = __builtin_fma(sx, ype, acc[4]);
         }
     }
+    if (lane < k) {
+        const int64_t pcount = (int64_t)gridDim.x * kWaves;
+        const int64_t pidx = (int64_t)blockIdx.x * kWaves + wave;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        const int i = wave + kWaves * q;
-        if (i < p.k) {
-#pragma unroll
-            for (int c = 0; c < kGramValues; ++c) {
-                const double r = wave_sum(acc[q][c]);
-                if (lane == 0) p.partials[(int64_t)(i * kGramValues + c) * gridDim.x + blockIdx.x] = r;
-            }
-        }
+        for (int c = 0; c < kGramValues; ++c) p.partials[(int64_t)(lane * kGramValues + c) * pcount + pidx] = acc[c];
     }
 }
 
@@ -546,8 +588,10 @@ __global__ __launch_bounds__(kBlock) void delta_rho_kernel(int64_t n, const T *_
 }
 
 __global__ __launch_bounds__(kBlock) void finish_to_kernel(const double *__restrict__ partials, int count,
-                                                           double *__restrict__ dst, int to_f32) {
+                                                           double *__restrict__ dst, int to_f32,
+                                                           const int32_t *__restrict__ gate) {
     __shared__ double lds[kWaves];
+    if (gate && *gate != 1) return;
     double r = reduce_partials_all(partials, count, lds);
     if (threadIdx.x == 0) dst[0] = to_f32 ? (double)(float)r : r;
 }
@@ -630,6 +674,21 @@ static int tune(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals) {
+    hipStream_t s = o->core.stream;
+    GramFinishParams fp;
+    fp.k = o->k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = 0; fp.do_recurrence = recurrence ? 1 : 0;
+    fp.map = make_map(o); fp.partials = vals; fp.rho = o->rho;
+    fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
+    fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
+    {
+        DZO_TIMED("lbfgs_gram_finish", s);
+        hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(kBlock), 0, s, fp);
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
 template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool recurrence) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
@@ -641,44 +700,34 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     for (int i = 0; i < k; ++i) { gp.s[i] = o->s_slot<T>(o->slot_of(i)); gp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     gp.partials = o->gram_partials;
     const bool vec = al16(c.g);
-    const int ppw = (k + kWaves - 1) / kWaves;
-    const int grid = o->gram_grid;
-    {
-        DZO_TIMED("lbfgs_gram_pass", s);
-#define GPU_(P, UU)                                                                                           \
-    do {                                                                                                      \
-        if (vec) hipLaunchKernelGGL((gram_pass_kernel<T, P, true, UU>), dim3(grid), dim3(kBlock), 0, s, gp);  \
-        else hipLaunchKernelGGL((gram_pass_kernel<T, P, false, UU>), dim3(grid), dim3(kBlock), 0, s, gp);     \
+    if (o->gram_variant == 1) {
+        // lane-distributed accumulators: one launch shape for every k (the pair-per-wave
+        // variant, 5*ceil(k/4) accumulators per lane and 8 concurrent streams per block, measured
+        // 5 % slower at k = 20 and was removed)
+        int64_t per_block = (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * o->gram_u;
+        int64_t blocks = (c.n + per_block - 1) / per_block;
+        if (blocks > o->gram_grid) blocks = o->gram_grid;
+        const int lgrid = (int)(blocks < 1 ? 1 : blocks);
+        {
+            DZO_TIMED("lbfgs_gram_pass", s);
+#define GL(UU)                                                                                                  \
+    do {                                                                                                        \
+        if (vec) hipLaunchKernelGGL((gram_pass_lanes_kernel<T, true, UU>), dim3(lgrid), dim3(kBlock), 0, s, gp); \
+        else hipLaunchKernelGGL((gram_pass_lanes_kernel<T, false, UU>), dim3(lgrid), dim3(kBlock), 0, s, gp);    \
     } while (0)
-#define GP(P) do { if (o->gram_u == 1) GPU_(P, 1); else if (o->gram_u == 4) GPU_(P, 4); else GPU_(P, 2); } while (0)
-        if (ppw <= 1) GP(1);
-        else if (ppw <= 2) GP(2);
-        else if (ppw <= 3) GP(3);
-        else if (ppw <= 4) GP(4);
-        else if (ppw <= 5) GP(5);
-        else if (ppw <= 6) GP(6);
-        else if (ppw <= 8) GP(8);
-        else if (ppw <= 12) GP(12);
-        else GP(16);
-#undef GP
-#undef GPU_
+            if (o->gram_u == 1) GL(1); else if (o->gram_u == 2) GL(2); else if (o->gram_u == 8) GL(8); else GL(4);
+#undef GL
+        }
+        const int pcount = lgrid * kWaves;
+        double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
+        {
+            DZO_TIMED("lbfgs_gram_reduce", s);
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * k), dim3(kBlock), 0, s, o->gram_partials, pcount, vals);
+        }
+        return gram_finish_launch(o, pivot, recurrence, vals);
     }
-    double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid;   // reduced values
-    {
-        DZO_TIMED("lbfgs_gram_reduce", s);
-        hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * k), dim3(kBlock), 0, s, o->gram_partials, grid, vals);
-    }
-    GramFinishParams fp;
-    fp.k = k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = grid; fp.do_recurrence = recurrence ? 1 : 0;
-    fp.map = make_map(o); fp.partials = vals; fp.rho = o->rho;
-    fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
-    fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
-    {
-        DZO_TIMED("lbfgs_gram_finish", s);
-        hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(kBlock), 0, s, fp);
-    }
-    DZO_HIP(hipGetLastError());
-    return DZO_OK;
+    set_error("unknown Gram variant");
+    return DZO_ERR_INVALID;
 }
 
 template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
@@ -730,14 +779,15 @@ static int32_t lbfgs_direction(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
+static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done);
+
 static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
-    const int sp = o->spare();
+    const bool vec = al16(c.g);
+    const int grid = stream_grid(c.n, (vec ? 16 / (int)dtype_size(c.dtype) : 1) * 2);
     {
         DZO_TIMED("lbfgs_delta_rho", s);
-        const bool vec = al16(c.g);
-        const int grid = stream_grid(c.n, (vec ? 16 / (int)dtype_size(c.dtype) : 1) * 2);
         if (c.dtype == DZO_F64) {
             if (vec) hipLaunchKernelGGL((delta_rho_kernel<double, true>), dim3(grid), dim3(kBlock), 0, s, c.n, (const double *)c.g, (double *)c.dg, (const double *)c.dx, c.partials());
             else hipLaunchKernelGGL((delta_rho_kernel<double, false>), dim3(grid), dim3(kBlock), 0, s, c.n, (const double *)c.g, (double *)c.dg, (const double *)c.dx, c.partials());
@@ -745,11 +795,36 @@ static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
             if (vec) hipLaunchKernelGGL((delta_rho_kernel<float, true>), dim3(grid), dim3(kBlock), 0, s, c.n, (const float *)c.g, (float *)c.dg, (const float *)c.dx, c.partials());
             else hipLaunchKernelGGL((delta_rho_kernel<float, false>), dim3(grid), dim3(kBlock), 0, s, c.n, (const float *)c.g, (float *)c.dg, (const float *)c.dx, c.partials());
         }
-        // :505  rho of the pair being pushed, stored by slot (rounded to T like the reference's dot)
-        hipLaunchKernelGGL(finish_to_kernel, dim3(1), dim3(kBlock), 0, s, c.partials(), grid, o->rho + sp,
-                           c.dtype == DZO_F32 ? 1 : 0);
     }
     DZO_HIP(hipGetLastError());
+    return lbfgs_finish_push(o, grid, false);
+}
+
+// :505 rho of the pair being pushed (fixed-order sum of the partials), then the ring rotation
+static int32_t lbfgs_rho_finish(dzo_lbfgs_s *o, int grid, const int32_t *gate) {
+    OptCore &c = o->core;
+    DZO_TIMED("lbfgs_rho_finish", c.stream);
+    // stored by slot, rounded to T like the reference's dot
+    hipLaunchKernelGGL(finish_to_kernel, dim3(1), dim3(kBlock), 0, c.stream, c.partials(), grid, o->rho + o->spare(),
+                       c.dtype == DZO_F32 ? 1 : 0, gate);
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+// Tail of an accepted step, enqueued BEFORE the host knows the trial's outcome (gated on the
+// device-side decision): :145 + :478-480 + :505 for the built-in chained Rosenbrock objective.
+static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
+    dzo_lbfgs_s *o = static_cast<dzo_lbfgs_s *>(self);
+    OptCore &c = o->core;
+    int grid = 0;
+    DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, gate));
+    return lbfgs_rho_finish(o, grid, gate);
+}
+
+static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done) {
+    OptCore &c = o->core;
+    const int sp = o->spare();
+    if (!rho_done) DZO_TRY(lbfgs_rho_finish(o, grid, nullptr));
     // :482-496  pushfirst!: the spare slots (= delta_point, delta_gradient) become pair 0
     o->newest = sp;
     if (o->k < o->m) o->k += 1;
@@ -768,8 +843,24 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
                 "step! needs objective and gradient (callbacks or a built-in problem)");
     if (c.iteration_count > 0) DZO_TRY(lbfgs_direction(o));   // :463-471
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
-    DZO_TRY(core_backtracking_step(c, 1.0, o->d));        // :473
+    const bool fused = !c.objective && !c.gradient && !c.constraint &&
+                       problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
+    c.defer_delta = fused;
+    c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
+    c.speculative_self = o;
+    int32_t rc = core_backtracking_step(c, 1.0, o->d);    // :473
+    const bool speculated = c.speculative_tail != nullptr;
+    c.defer_delta = false;
+    c.speculative_tail = nullptr;
+    DZO_TRY(rc);
     if (c.is_stuck) return DZO_OK;                        // :474-476
+    if (fused && speculated) return lbfgs_finish_push(o, 0, true);   // the gated tail already ran
+    if (fused) {
+        // :145 + :478-480 + partials of :505 in one pass
+        int grid = 0;
+        DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid));
+        return lbfgs_finish_push(o, grid, false);
+    }
     DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
     DZO_TRY(core_gradient(c));                            // :479
     return lbfgs_post_gradient(o);                        // :480-507
@@ -810,6 +901,8 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     ALLOC(o->Y, slab);
     ALLOC(o->d, (size_t)o->stride * es);
     o->gram_u = tune("DZO_TUNE_GRAM_U", 4);
+    o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
+    o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
     o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
     o->combine_blocks_per_cu = tune("DZO_TUNE_COMBINE_BPC", 8);
     o->gram_grid = ctx().cus * tune("DZO_TUNE_GRAM_BPC", 8);
@@ -820,7 +913,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
     }
     const size_t nscal = (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory +
-                         (size_t)kGramValues * kMaxHistory * (o->gram_grid + 1) + 4 * (size_t)kMaxPartialBlocks;
+                         (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1) + 4 * (size_t)kMaxPartialBlocks;
     double *base = nullptr;
     ALLOC(base, nscal * sizeof(double));
 #undef ALLOC
@@ -834,7 +927,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->Gsy = base; base += (size_t)m1 * m1;
     o->sg = base; base += kMaxHistory;
     o->yg = base; base += kMaxHistory;
-    o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * (o->gram_grid + 1);
+    o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1);
     o->link_partials = base;
     // :366-374 zero-filled deltas: the whole ring starts zeroed
     DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));

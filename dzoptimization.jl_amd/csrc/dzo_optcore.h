@@ -33,10 +33,17 @@ struct OptCore {
     int64_t max_halvings = 4096;  // build-added escape from the NaN loop
     int64_t last_trials = 0;
     bool search_open = false;     // begin_search called, first trial not yet taken
+    bool defer_delta = false;     // accept leaves x_old in dx; a fused kernel finishes delta_point
+    // Speculative tail: when set, it is enqueued right after every trial's decision kernel and
+    // BEFORE the host learns the outcome; the kernels it launches must be gated on status().
+    int32_t (*speculative_tail)(void *self, const int32_t *gate) = nullptr;
+    void *speculative_self = nullptr;
+    hipEvent_t decided = nullptr;
 
     double *partials() const { return ws; }
     double *result() const { return ws + 2 * kMaxPartialBlocks; }          // [0]=f_new [1]=misc
     int32_t *flag() const { return reinterpret_cast<int32_t *>(ws + 2 * kMaxPartialBlocks + 4); }
+    int32_t *status() const { return reinterpret_cast<int32_t *>(ws + 2 * kMaxPartialBlocks + 3); }  // 0 reject 1 accept 2 stuck
     bool has_objective() const { return objective != nullptr || problem != nullptr; }
     bool has_gradient() const { return gradient != nullptr || problem != nullptr; }
 };

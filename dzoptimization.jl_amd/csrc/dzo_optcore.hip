@@ -58,6 +58,19 @@ __global__ __launch_bounds__(kBlock) void trial_kernel(int64_t n, T *x, T *__res
     block_raise_flag(diff, changed, &lds_flag);
 }
 
+// Device-side acceptance test of take_backtracking_step! (:128, :139): lets the host enqueue the
+// accepted-step tail speculatively instead of idling the GPU across a host round trip.
+__global__ void decide_kernel(const double *__restrict__ result, const int32_t *__restrict__ changed, double f_cur,
+                              int to_f32, int32_t *__restrict__ status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double f_new = to_f32 ? (double)(float)result[0] : result[0];
+        int32_t st = 0;
+        if (*changed == 0) st = 2;                               // :128 isequal -> stuck
+        else if (f_new < f_cur) st = 1;                          // :139 strict decrease
+        *status = st;
+    }
+}
+
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
@@ -77,6 +90,7 @@ int32_t core_alloc(OptCore &c) {
     DZO_HIP(hipMemset(c.ws, 0, sizeof(double) * (2 * kMaxPartialBlocks + 16)));
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     DZO_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * 8, hipHostMallocDefault));
+    DZO_HIP(hipEventCreateWithFlags(&c.decided, hipEventDisableTiming));
     return DZO_OK;
 }
 
@@ -84,6 +98,7 @@ void core_free(OptCore &c) {
     if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (c.ws) (void)hipFree(c.ws);
     if (c.host) (void)hipHostFree(c.host);
+    if (c.decided) (void)hipEventDestroy(c.decided);
     if (c.owns_g && c.g) (void)hipFree(c.g);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c.ws = nullptr; c.host = nullptr; c.stream = nullptr;
@@ -105,9 +120,21 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     c.search_open = false;
     const bool fused = fuse_objective && c.problem && !c.objective && !c.constraint;
     if (fused) DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
-    // one D->H copy brings back {f_new, misc, flag}
+    const bool speculate = fused && c.speculative_tail != nullptr;
+    if (speculate) {
+        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, s, (const double *)c.result(), (const int32_t *)c.flag(),
+                           c.f, c.dtype == DZO_F32 ? 1 : 0, c.status());
+        DZO_HIP(hipGetLastError());
+    }
+    // one D->H copy brings back {f_new, misc, status, flag}
     DZO_HIP(hipMemcpyAsync(c.host, c.result(), sizeof(double) * 5, hipMemcpyDeviceToHost, s));
-    DZO_HIP(hipStreamSynchronize(s));
+    if (speculate) {
+        DZO_HIP(hipEventRecord(c.decided, s));
+        DZO_TRY(c.speculative_tail(c.speculative_self, c.status()));   // gated kernels, enqueued blind
+        DZO_HIP(hipEventSynchronize(c.decided));
+    } else {
+        DZO_HIP(hipStreamSynchronize(s));
+    }
     *changed = reinterpret_cast<int32_t *>(c.host + 4)[0] != 0;
     if (f_valid) *f_valid = fused;
     if (fused && f_new) *f_new = round_to_dtype(c.dtype, c.host[0]);
@@ -117,6 +144,7 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
 int32_t core_accept(OptCore &c, double f_new) {
     c.df = round_to_dtype(c.dtype, f_new - c.f);          // :142-143
     c.f = f_new;                                          // :144
+    if (c.defer_delta) return DZO_OK;                     // the fused post-step kernel computes :145
     // :145  delta_point = 1*x + (-1)*delta_point  (exactly x_new - x_old)
     DZO_DISPATCH(c.dtype, launch_axpby<T>(c.stream, c.n, (T)1, (const T *)c.x, (T)-1, (T *)c.dx));
     DZO_HIP(hipGetLastError());

@@ -19,4 +19,8 @@ namespace dzo {
 int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev);
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
+// Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).
+bool problem_has_fused_post(const dzo_problem_s *p, const void *x, const void *dx, const void *g, const void *dg);
+int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x, void *dx, void *g, void *dg,
+                                 double *partials, int *grid_out, const int32_t *gate = nullptr);
 }  // namespace dzo

@@ -98,6 +98,82 @@ __global__ __launch_bounds__(kBlock) void rosen_chain_grad_kernel(int64_t n, T *
     if (t < n) g[t] = rosen_grad_elem<T>(t, n, t > 0 ? x[t - 1] : (T)0, x[t], t + 1 < n ? x[t + 1] : (T)0);
 }
 
+// Fused tail of an accepted L-BFGS step for the chained Rosenbrock objective (K3 + K5 + K12):
+//   delta_point    = x - x_old                       (src/DZOptimization.jl:145)
+//   g_new          = grad f(x)                       (:479)
+//   delta_gradient = g_new - g_old                   (:478,:480)
+//   partials of rho = delta_point . delta_gradient   (:505)
+// One pass: reads x, x_old (in dx), g_old; writes dx, g (in place), dg.  6n elements instead of
+// the 11n of the four separate passes (axpby 3n, copy 2n, gradient 2n, delta+rho 4n).  Neighbour
+// values for the gradient stencil come from wave shuffles; only lanes 0 / 63 touch memory again.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rosen_accept_grad_delta_kernel(int64_t n, const T *__restrict__ x,
+                                                                         T *__restrict__ dx, T *__restrict__ g,
+                                                                         T *__restrict__ dg,
+                                                                         double *__restrict__ partials,
+                                                                         const int32_t *__restrict__ gate) {
+    constexpr int N = Vec16<T>::N;
+    constexpr int U = 2;
+    __shared__ double lds[kWaves];
+    // speculative launch: the host enqueues this kernel before it knows whether the trial was
+    // accepted; the device-side decision (decide_kernel) gates it
+    if (gate && *gate != 1) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
+        T xv[U][N], xo[U][N], go[U][N];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
+            ok[u] = v < nvec;
+            if (ok[u]) { load16(x + v * N, xv[u]); load16(dx + v * N, xo[u]); load16(g + v * N, go[u]); }
+            else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { xv[u][j] = 0; xo[u][j] = 0; go[u][j] = 0; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
+            const int64_t i = v * N;
+            // neighbours: previous lane's last element, next lane's first element
+            T xprev = __shfl_up(xv[u][N - 1], 1, 64);
+            T xnext = __shfl_down(xv[u][0], 1, 64);
+            if (ok[u]) {
+                if (lane == 0) xprev = i > 0 ? x[i - 1] : (T)0;
+                if (lane == 63 || v + 1 >= nvec) xnext = (i + N < n) ? x[i + N] : (T)0;
+                T gn[N], dxn[N], dgn[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const T xp = j > 0 ? xv[u][(j + N - 1) % N] : xprev;
+                    const T xn = j + 1 < N ? xv[u][(j + 1) % N] : xnext;
+                    gn[j] = rosen_grad_elem<T>(i + j, n, xp, xv[u][j], xn);
+                    dxn[j] = xv[u][j] - xo[u][j];
+                    dgn[j] = gn[j] - go[u][j];
+                    acc = __builtin_fma((double)dxn[j], (double)dgn[j], acc);
+                }
+                store16(dx + i, dxn);
+                store16(g + i, gn);
+                store16(dg + i, dgn);
+            }
+        }
+    }
+    // scalar tail
+    const int64_t t = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) {
+        const T gn = rosen_grad_elem<T>(t, n, t > 0 ? x[t - 1] : (T)0, x[t], t + 1 < n ? x[t + 1] : (T)0);
+        const T dxn = x[t] - dx[t];
+        const T dgn = gn - g[t];
+        acc = __builtin_fma((double)dxn, (double)dgn, acc);
+        dx[t] = dxn; g[t] = gn; dg[t] = dgn;
+    }
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 // ------------------------------------------------------------------ dense quadratic (config 2)
 // One block per column j of the column-major symmetric A: c_j = A[:,j].x (coalesced along
 // the column), g_j = c_j, and the objective partial is x_j*c_j.  No cross-block reduction.
@@ -301,6 +377,28 @@ template <typename T> static int32_t grad_async_t(dzo_problem_s *p, hipStream_t 
         set_error("unknown problem kind %d", p->kind);
         return DZO_ERR_INVALID;
     }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+bool problem_has_fused_post(const dzo_problem_s *p, const void *x, const void *dx, const void *g, const void *dg) {
+    auto al = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    return p && p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && al(x) && al(dx) && al(g) && al(dg);
+}
+
+int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x, void *dx, void *g, void *dg,
+                                 double *partials, int *grid_out, const int32_t *gate) {
+    DZO_TIMED("lbfgs_fused_accept_grad_delta", s);
+    const int64_t n = p->n;
+    const int vecn = p->dtype == DZO_F64 ? 2 : 4;
+    const int grid = stream_grid(n, vecn * 2);
+    if (p->dtype == DZO_F64)
+        hipLaunchKernelGGL(rosen_accept_grad_delta_kernel<double>, dim3(grid), dim3(kBlock), 0, s, n, (const double *)x,
+                           (double *)dx, (double *)g, (double *)dg, partials, gate);
+    else
+        hipLaunchKernelGGL(rosen_accept_grad_delta_kernel<float>, dim3(grid), dim3(kBlock), 0, s, n, (const float *)x,
+                           (float *)dx, (float *)g, (float *)dg, partials, gate);
+    *grid_out = grid;
     DZO_HIP(hipGetLastError());
     return DZO_OK;
 }
