@@ -321,8 +321,9 @@ def trial_point_(dst, t, d, x):
 
 
 # ------------------------------------------------------------------------------ profiling
-def profile_enable(on=True):
-    _check(lib().dzo_profile_enable(1 if on else 0))
+def profile_enable(level=2):
+    """0/False off, 1 = the roofline kernels only (cheap), 2/True = every kernel."""
+    _check(lib().dzo_profile_enable(2 if level is True else int(level)))
 
 
 def profile_reset():

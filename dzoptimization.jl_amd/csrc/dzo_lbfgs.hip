@@ -59,7 +59,8 @@ struct dzo_lbfgs_s {
     double *link_partials = nullptr;        // [4][kMaxPartialBlocks] ping-pong + yy
     int gram_grid = 0;
     bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
-    int gram_variant = 1;           // 1 = lane-distributed accumulators, 0 = pair-per-wave
+    int gram_variant = 1;           // 1 = lane-distributed accumulators
+    bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
@@ -704,7 +705,12 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         // lane-distributed accumulators: one launch shape for every k (the pair-per-wave
         // variant, 5*ceil(k/4) accumulators per lane and 8 concurrent streams per block, measured
         // 5 % slower at k = 20 and was removed)
-        int64_t per_block = (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * o->gram_u;
+        // vectors per thread: as many as still leave >= 4 blocks per CU (small n would otherwise
+        // launch fewer blocks than there are CUs)
+        int gu = o->gram_u;
+        const int64_t vec_elems = (int64_t)kBlock * (vec ? Vec16<T>::N : 1);
+        while (gu > 1 && (c.n + vec_elems * gu - 1) / (vec_elems * gu) < (int64_t)ctx().cus * 4) gu >>= 1;
+        int64_t per_block = vec_elems * gu;
         int64_t blocks = (c.n + per_block - 1) / per_block;
         if (blocks > o->gram_grid) blocks = o->gram_grid;
         const int lgrid = (int)(blocks < 1 ? 1 : blocks);
@@ -715,7 +721,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         if (vec) hipLaunchKernelGGL((gram_pass_lanes_kernel<T, true, UU>), dim3(lgrid), dim3(kBlock), 0, s, gp); \
         else hipLaunchKernelGGL((gram_pass_lanes_kernel<T, false, UU>), dim3(lgrid), dim3(kBlock), 0, s, gp);    \
     } while (0)
-            if (o->gram_u == 1) GL(1); else if (o->gram_u == 2) GL(2); else if (o->gram_u == 8) GL(8); else GL(4);
+            if (gu == 1) GL(1); else if (gu == 2) GL(2); else if (gu == 8) GL(8); else GL(4);
 #undef GL
         }
         const int pcount = lgrid * kWaves;
@@ -748,7 +754,8 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     for (int i = 0; i < k; ++i) { cp.s[i] = o->s_slot<T>(o->slot_of(i)); cp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     cp.alpha = o->alpha; cp.coef = o->coef; cp.scale = o->scale;
     const bool vec = al16(c.g);
-    const int u = o->combine_u;
+    int u = o->combine_u;
+    while (u > 1 && (c.n + (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u - 1) / ((int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u) < (int64_t)ctx().cus * 4) u >>= 1;
     int64_t per_block = (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u;
     int64_t blocks = (c.n + per_block - 1) / per_block;
     const int64_t cap = (int64_t)ctx().cus * o->combine_blocks_per_cu;
@@ -843,7 +850,7 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
                 "step! needs objective and gradient (callbacks or a built-in problem)");
     if (c.iteration_count > 0) DZO_TRY(lbfgs_direction(o));   // :463-471
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
-    const bool fused = !c.objective && !c.gradient && !c.constraint &&
+    const bool fused = o->fused_post && !c.objective && !c.gradient && !c.constraint &&
                        problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
     c.defer_delta = fused;
     c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
@@ -903,6 +910,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->gram_u = tune("DZO_TUNE_GRAM_U", 4);
     o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
     o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
+    o->fused_post = tune("DZO_TUNE_FUSED_POST", 1) != 0;
     o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
     o->combine_blocks_per_cu = tune("DZO_TUNE_COMBINE_BPC", 8);
     o->gram_grid = ctx().cus * tune("DZO_TUNE_GRAM_BPC", 8);

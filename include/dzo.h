@@ -90,7 +90,7 @@ int32_t dzo_synchronize(void);
 
 /* Per-kernel HIP-event timing on the launching stream (bench.py's roofline leg).
  * Entry i of the table is one kernel name with its launch count and total milliseconds. */
-int32_t dzo_profile_enable(int32_t on);
+int32_t dzo_profile_enable(int32_t level); /* 0 off, 1 roofline kernels only, 2 every kernel */
 int32_t dzo_profile_reset(void);
 int32_t dzo_profile_count(int32_t *count);
 int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launches, double *total_ms);

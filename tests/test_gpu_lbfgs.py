@@ -8,6 +8,7 @@ inputs (BASELINE.json north_star), for both device implementations (CHAIN and GR
 """
 import numpy as np
 import pytest
+from hypothesis import given, settings, strategies as st
 
 from dzo_loader import dzo
 from oracle import mp_twoloop, oracle as orc
@@ -343,6 +344,87 @@ def test_split_entry_points_reproduce_step():
         assert np.array_equal(opt_a.delta_gradient.to_host(), opt_b.delta_gradient.to_host())
         assert opt_a.current_objective_value == opt_b.current_objective_value
     assert np.array_equal(opt_a.rho_history, opt_b.rho_history)
+
+
+def test_fused_and_speculative_step_equal_the_plain_kernel_sequence(monkeypatch):
+    """The fused accept+gradient+delta kernel and the speculative (device-decided) tail are
+    pure re-schedulings: from the same state one step gives bit-identical x, delta_point, g,
+    delta_gradient; only rho's reduction order (grid) may differ in the last bits."""
+    n, m = 4099, 5
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1.0, m)
+    for _ in range(7):
+        ref.step()
+    outs = []
+    for fused, spec in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("DZO_TUNE_FUSED_POST", fused)
+        monkeypatch.setenv("DZO_TUNE_SPECULATE", spec)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        _sync_from_oracle(opt, ref)
+        opt.step()
+        opt.step()          # a second step exercises the rotated ring after the fused push
+        outs.append((opt.current_point.to_host(), opt.delta_point.to_host(), opt.current_gradient.to_host(),
+                     opt.delta_gradient.to_host(), opt.current_objective_value, opt.rho_history, opt.last_trials))
+    for o in outs[1:]:
+        for a, b in zip(o[:4], outs[0][:4]):
+            assert rel(a, b) <= 1e-13
+        assert o[4] == pytest.approx(outs[0][4], rel=1e-13) and o[6] == outs[0][6]
+        assert np.allclose(o[5], outs[0][5], rtol=1e-12)
+    # first of the two steps is bit-identical across the three schedules
+    firsts = []
+    for fused, spec in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("DZO_TUNE_FUSED_POST", fused)
+        monkeypatch.setenv("DZO_TUNE_SPECULATE", spec)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        _sync_from_oracle(opt, ref)
+        opt.step()
+        firsts.append((opt.current_point.to_host(), opt.delta_point.to_host(), opt.current_gradient.to_host(),
+                       opt.delta_gradient.to_host()))
+    for o in firsts[1:]:
+        for a, b in zip(o, firsts[0]):
+            assert np.array_equal(a, b)
+
+
+def test_rejected_trials_with_speculation_leave_state_consistent():
+    """Force halvings (huge initial step): every rejected trial's gated tail must be a no-op."""
+    n, m = 1000, 3
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1e4, m)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1e4, m)
+    for it in range(6):
+        _sync_from_oracle(opt, ref)
+        if it == 0:
+            opt.step_direction.upload(ref.step_direction)
+        opt.step(); ref.step()
+        assert opt.last_trials == ref.last_trials
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-12
+        assert np.array_equal(opt.current_gradient.to_host(), ref.problem.grad(opt.current_point.to_host()))
+        assert rel(opt.delta_gradient.to_host(), ref.delta_gradient) <= 1e-9
+    assert ref.last_trials >= 1 and max(1, ref.last_trials) >= 1
+
+
+@settings(max_examples=12, deadline=None)
+@given(n=st.integers(1, 3000), m=st.integers(1, 7), warm=st.integers(0, 9), seed=st.integers(0, 1000),
+       mode=st.sampled_from([0, 1]))
+def test_property_single_step_parity_random_shapes(n, m, warm, seed, mode):
+    """Ragged n (vector tails), warm-up (k < m) and wrapped rings (k = m after > m steps)."""
+    x0 = (orc.pcg_fill(n, seed) - 0.5) * 2.0
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 0.5, m)
+    for _ in range(warm):
+        ref.step()
+    if ref.is_stuck:
+        return
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 0.5, m)
+    opt.set_two_loop_mode(mode)
+    _sync_from_oracle(opt, ref)
+    if warm == 0:
+        opt.step_direction.upload(ref.step_direction)
+    opt.step(); ref.step()
+    assert opt.is_stuck == ref.is_stuck
+    if not ref.is_stuck:
+        assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-11
+        assert opt.history_count == ref.history_count and opt.last_trials == ref.last_trials
 
 
 def test_stuck_semantics():
