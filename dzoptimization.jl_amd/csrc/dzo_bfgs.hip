@@ -28,9 +28,13 @@ namespace dzo {
 constexpr int kColsPerBlock = 4;
 
 // t_j = H[:,j] . v for a group of columns per block
+// With `dvec` non-null the kernel also emits, per column group, the partial sums of
+// overlap = d.v (:873) and v.t (:876) over its own columns (v = delta_gradient, t = H*v), so the
+// update kernel can form the scalars itself and the single-block scalars launch disappears.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kBlock) void symv_kernel(int64_t n, const T *__restrict__ H, const T *__restrict__ v,
-                                                      T *__restrict__ out) {
+                                                      T *__restrict__ out, const T *__restrict__ dvec,
+                                                      double *__restrict__ part_ov, double *__restrict__ part_vt) {
     constexpr int N = VEC ? Vec16<T>::N : 1;
     __shared__ double lds[kWaves];
     const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
@@ -52,11 +56,20 @@ __global__ __launch_bounds__(kBlock) void symv_kernel(int64_t n, const T *__rest
                 }
             }
         }
+        double pov = 0, pvt = 0;
 #pragma unroll
         for (int c = 0; c < kColsPerBlock; ++c) {
             const double r = block_sum(acc[c], lds);
-            if (threadIdx.x == 0 && j0 + c < n) out[j0 + c] = (T)r;
+            if (threadIdx.x == 0 && j0 + c < n) {
+                const T tj = (T)r;
+                out[j0 + c] = tj;
+                if (dvec) {
+                    pov = __builtin_fma((double)dvec[j0 + c], (double)v[j0 + c], pov);
+                    pvt = __builtin_fma((double)v[j0 + c], (double)tj, pvt);
+                }
+            }
         }
+        if (dvec && threadIdx.x == 0) { part_ov[grp] = pov; part_vt[grp] = pvt; }
     }
 }
 
@@ -87,13 +100,27 @@ __global__ __launch_bounds__(kBlock) void bfgs_scalars_kernel(int64_t n, T *__re
 }
 
 // H[:,j] update (:878-886) fused with d_next_j = H_new[:,j] . g (:958-960)
-template <typename T, bool VEC, bool DIRECTION>
+// FUSED: `dp` is the UNSCALED direction; every block first sums the per-group partials of
+// overlap and dg.t written by symv_kernel (fixed order, identical in every block), forms
+// inv = 1/overlap (:874) and delta (:876) itself, and scales d on the fly -- the same rounded
+// values the reference stores before using them.
+template <typename T, bool VEC, bool DIRECTION, bool FUSED>
 __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__restrict__ H, const T *__restrict__ dp,
                                                              const T *__restrict__ t, const double *__restrict__ scalars,
-                                                             const T *__restrict__ g, T *__restrict__ d_next) {
+                                                             const T *__restrict__ g, T *__restrict__ d_next,
+                                                             const double *__restrict__ part_ov,
+                                                             const double *__restrict__ part_vt, int nparts, T lambda) {
     constexpr int N = VEC ? Vec16<T>::N : 1;
     __shared__ double lds[kWaves];
-    const T delta = (T)scalars[1];
+    T delta, inv = (T)1;
+    if constexpr (FUSED) {
+        const T overlap = (T)reduce_partials_all(part_ov, nparts, lds);
+        const T dgt = (T)reduce_partials_all(part_vt, nparts, lds);
+        inv = (T)1 / overlap;
+        delta = lambda * overlap + dgt;
+    } else {
+        delta = (T)scalars[1];
+    }
     const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
     for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int64_t j0 = grp * kColsPerBlock;
@@ -102,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__res
 #pragma unroll
         for (int c = 0; c < kColsPerBlock; ++c) {
             const int64_t j = j0 + c < n ? j0 + c : n - 1;
-            sj[c] = dp[j];                                   // :879
+            sj[c] = FUSED ? dp[j] * inv : dp[j];             // :879 (:874 applied on the fly when FUSED)
             tj[c] = t[j];                                    // :880
             acc[c] = 0;
         }
@@ -110,6 +137,10 @@ __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__res
             T di[N], ti[N], gi[N];
             if constexpr (VEC) { load16(dp + i, di); load16(t + i, ti); if (DIRECTION) load16(g + i, gi); }
             else { di[0] = dp[i]; ti[0] = t[i]; if (DIRECTION) gi[0] = g[i]; }
+            if constexpr (FUSED) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) di[q] = di[q] * inv;
+            }
 #pragma unroll
             for (int c = 0; c < kColsPerBlock; ++c) {
                 if (j0 + c < n) {
@@ -184,8 +215,30 @@ template <typename T> void launch_symv(hipStream_t s, int64_t n, const T *H, con
     const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(v);
     const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
     const int grid = (int)(groups < 65535 ? groups : 65535);
-    if (vec) hipLaunchKernelGGL((symv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out);
-    else hipLaunchKernelGGL((symv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out);
+    if (vec) hipLaunchKernelGGL((symv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out, (const T *)nullptr, (double *)nullptr, (double *)nullptr);
+    else hipLaunchKernelGGL((symv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out, (const T *)nullptr, (double *)nullptr, (double *)nullptr);
+}
+
+// update_inverse_hessian! + next direction in TWO launches (step! path): the scalars ride on
+// the symv epilogue / update prologue.  `d` is left unscaled (step! overwrites it anyway, :958).
+// part needs 2 * ceil(n / kColsPerBlock) doubles.
+template <typename T>
+void launch_bfgs_update_fused(hipStream_t s, int64_t n, T *H, T lambda, const T *d, const T *dg, T *scratch, const T *g,
+                              T *d_next, double *part) {
+    const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(d) && al16(dg) && al16(scratch) && al16(g);
+    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    const int grid = (int)(groups < 65535 ? groups : 65535);
+    double *part_ov = part, *part_vt = part + groups;
+    {
+        DZO_TIMED("bfgs_symv", s);
+        if (vec) hipLaunchKernelGGL((symv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)H, dg, scratch, d, part_ov, part_vt);
+        else hipLaunchKernelGGL((symv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)H, dg, scratch, d, part_ov, part_vt);
+    }
+    {
+        DZO_TIMED("bfgs_update", s);
+        if (vec) hipLaunchKernelGGL((bfgs_update_kernel<T, true, true, true>), dim3(grid), dim3(kBlock), 0, s, n, H, d, (const T *)scratch, (const double *)nullptr, g, d_next, (const double *)part_ov, (const double *)part_vt, (int)groups, lambda);
+        else hipLaunchKernelGGL((bfgs_update_kernel<T, false, true, true>), dim3(grid), dim3(kBlock), 0, s, n, H, d, (const T *)scratch, (const double *)nullptr, g, d_next, (const double *)part_ov, (const double *)part_vt, (int)groups, lambda);
+    }
 }
 
 // update_inverse_hessian! (:864-889) + optional next direction; all scalars stay on device
@@ -204,7 +257,7 @@ void launch_bfgs_update(hipStream_t s, int64_t n, T *H, T lambda, T *d, const T 
         const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
         const int grid = (int)(groups < 65535 ? groups : 65535);
         const bool dir = g != nullptr && d_next != nullptr;
-#define L(V, D) hipLaunchKernelGGL((bfgs_update_kernel<T, V, D>), dim3(grid), dim3(kBlock), 0, s, n, H, (const T *)d, (const T *)scratch, (const double *)scalars_dev, g, d_next)
+#define L(V, D) hipLaunchKernelGGL((bfgs_update_kernel<T, V, D, false>), dim3(grid), dim3(kBlock), 0, s, n, H, (const T *)d, (const T *)scratch, (const double *)scalars_dev, g, d_next, (const double *)nullptr, (const double *)nullptr, 0, (T)0)
         if (vec) { if (dir) L(true, true); else L(true, false); }
         else { if (dir) L(false, true); else L(false, false); }
 #undef L
@@ -236,6 +289,7 @@ struct dzo_bfgs_s {
     void *ref_point = nullptr;                  // LineSearchEvaluator.reference_point (:17)
     int32_t max_increases = 0;                  // QuadraticLineSearch.max_increases (:181-188)
     int64_t evals = 0;
+    double *upd_part = nullptr;                 // device: 2*ceil(n/4) partials of the fused update scalars
     double *ws = nullptr;                       // device: partials + scalars + flags
     double *host = nullptr;                     // pinned
     double *partials() const { return ws; }
@@ -463,8 +517,13 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
         o->iteration_count += 1;                                 // :940
         DZO_TRY(bfgs_move(o, t_b, o->d));                        // :943-950
         // :953-960 update_inverse_hessian!(H, -t_b, d, dg, scratch) fused with d = H*g
-        DZO_DISPATCH(dt, launch_bfgs_update<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (T *)o->d, (const T *)o->dg,
-                                               (T *)o->scratch, (const T *)o->g, (T *)o->d_alt, o->scalars()));
+        if (o->n >= 65535LL * kColsPerBlock) {
+            DZO_DISPATCH(dt, launch_bfgs_update<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (T *)o->d, (const T *)o->dg,
+                                                   (T *)o->scratch, (const T *)o->g, (T *)o->d_alt, o->scalars()));
+        } else {
+            DZO_DISPATCH(dt, launch_bfgs_update_fused<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (const T *)o->d, (const T *)o->dg,
+                                                         (T *)o->scratch, (const T *)o->g, (T *)o->d_alt, o->upd_part));
+        }
         DZO_HIP(hipGetLastError());
         std::swap(o->d, o->d_alt);
     } else if (f_g < o->f) {                                     // :962
@@ -499,6 +558,7 @@ static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double init
             return DZO_ERR_NOMEM;
         }
     }
+    DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));
     DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 32)));
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 32)));
     DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocDefault));
@@ -526,7 +586,7 @@ extern "C" {
 int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
     if (!o) return DZO_OK;
     if (o->stream) (void)hipStreamSynchronize(o->stream);
-    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->H, o->ws};
+    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->H, o->ws, o->upd_part};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
     if (o->stream) (void)hipStreamDestroy(o->stream);

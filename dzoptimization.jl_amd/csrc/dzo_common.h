@@ -137,6 +137,18 @@ template <typename T> __device__ __forceinline__ void load16_nt(const T *p, T (&
     }
 }
 
+template <typename T> __device__ __forceinline__ void store16_nt(T *p, const T (&v)[Vec16<T>::N]) {
+    if constexpr (Vec16<T>::N == 2) {
+        typedef double v2f64 __attribute__((ext_vector_type(2)));
+        v2f64 t; t.x = v[0]; t.y = v[1];
+        __builtin_nontemporal_store(t, reinterpret_cast<v2f64 *>(p));
+    } else {
+        typedef float v4f32 __attribute__((ext_vector_type(4)));
+        v4f32 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f32 *>(p));
+    }
+}
+
 // wave64 sum, result valid in lane 0 (fixed order -> deterministic)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

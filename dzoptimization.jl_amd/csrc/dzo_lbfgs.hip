@@ -61,6 +61,7 @@ struct dzo_lbfgs_s {
     bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
     int gram_variant = 1;           // 1 = lane-distributed accumulators
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
+    bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
@@ -81,6 +82,9 @@ template <typename T, bool VEC> struct Ld {
     }
     static __device__ __forceinline__ void load_nt(const T *p, T (&v)[N]) {
         if constexpr (VEC) load16_nt(p, v); else v[0] = __builtin_nontemporal_load(p);
+    }
+    static __device__ __forceinline__ void store_nt(T *p, const T (&v)[N]) {
+        if constexpr (VEC) store16_nt(p, v); else __builtin_nontemporal_store(v[0], p);
     }
     static __device__ __forceinline__ void store(T *p, const T (&v)[N]) {
         if constexpr (VEC) store16(p, v); else p[0] = v[0];
@@ -308,10 +312,13 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
                 for (int j = 0; j < N; ++j) { gv[u][j] = 0; spv[u][j] = 0; ypv[u][j] = 0; }
             }
         }
-        for (int i = 0; i < k; ++i) {
+        // two register sets: the loads of pair i+1 are in flight while pair i is multiplied and
+        // reduced (the butterfly is a ~0.3 us dependent chain that would otherwise sit between
+        // consecutive memory round trips of the wave)
+        T sA[U][N], yA[U][N], sB[U][N], yB[U][N];
+        auto fetch = [&](int i, T (&sv)[U][N], T (&yv)[U][N]) {
             const T *si = p.s[i];
             const T *yi = p.y[i];
-            T sv[U][N], yv[U][N];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (ok[u]) {
@@ -323,6 +330,8 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
                     for (int j = 0; j < N; ++j) { sv[u][j] = 0; yv[u][j] = 0; }
                 }
             }
+        };
+        auto consume = [&](int i, const T (&sv)[U][N], const T (&yv)[U][N]) {
             double t[kGramValues] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -342,6 +351,13 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
 #pragma unroll
                 for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
             }
+        };
+        if (k > 0) fetch(0, sA, yA);
+        for (int i = 0; i < k; i += 2) {
+            if (i + 1 < k) fetch(i + 1, sB, yB);
+            consume(i, sA, yA);
+            if (i + 2 < k) fetch(i + 2, sA, yA);
+            if (i + 1 < k) consume(i + 1, sB, yB);
         }
     }
     // scalar tail (n not a multiple of the vector width): lane i of wave 0 in block 0 owns pair i
@@ -476,7 +492,7 @@ template <typename T> struct CombineParams {
 // The 2k coefficients are staged once per block in LDS (wave-uniform broadcast reads), the
 // slot pointers come from the kernel-argument segment (scalar loads), and the history is
 // streamed with non-temporal 16-B loads, UI of them in flight per stream step.
-template <typename T, bool VEC, int U>
+template <typename T, bool VEC, int U, bool NTS>
 __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
@@ -533,7 +549,10 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (ok[u]) L::store(p.d + (base + (int64_t)u * kBlock + threadIdx.x) * N, q[u]);
+            if (ok[u]) {
+                T *dst = p.d + (base + (int64_t)u * kBlock + threadIdx.x) * N;
+                if constexpr (NTS) L::store_nt(dst, q[u]); else L::store(dst, q[u]);
+            }
     }
     if constexpr (VEC) {
         const int64_t e = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -763,10 +782,11 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     const int grid = (int)(blocks < 1 ? 1 : blocks);
     {
         DZO_TIMED("lbfgs_combine", s);
-#define CB(UU)                                                                                             \
-    do {                                                                                                   \
-        if (vec) hipLaunchKernelGGL((combine_kernel<T, true, UU>), dim3(grid), dim3(kBlock), 0, s, cp);    \
-        else hipLaunchKernelGGL((combine_kernel<T, false, UU>), dim3(grid), dim3(kBlock), 0, s, cp);       \
+#define CB(UU)                                                                                                   \
+    do {                                                                                                         \
+        if (vec && o->combine_nts) hipLaunchKernelGGL((combine_kernel<T, true, UU, true>), dim3(grid), dim3(kBlock), 0, s, cp);  \
+        else if (vec) hipLaunchKernelGGL((combine_kernel<T, true, UU, false>), dim3(grid), dim3(kBlock), 0, s, cp);  \
+        else hipLaunchKernelGGL((combine_kernel<T, false, UU, false>), dim3(grid), dim3(kBlock), 0, s, cp);      \
     } while (0)
         if (u == 1) CB(1); else if (u == 4) CB(4); else CB(2);
 #undef CB
@@ -911,6 +931,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
     o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
     o->fused_post = tune("DZO_TUNE_FUSED_POST", 1) != 0;
+    o->combine_nts = tune("DZO_TUNE_COMBINE_NTS", 1) != 0;
     o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
     o->combine_blocks_per_cu = tune("DZO_TUNE_COMBINE_BPC", 8);
     o->gram_grid = ctx().cus * tune("DZO_TUNE_GRAM_BPC", 8);

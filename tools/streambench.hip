@@ -45,6 +45,38 @@ __global__ __launch_bounds__(256) void multi_read_k(const double2 *__restrict__ 
     }
     if (acc == 1.2345e300) out[0] = acc;
 }
+// K nt-read streams + one written stream (the combine kernel's traffic shape)
+template <int U, bool NTSTORE>
+__global__ __launch_bounds__(256) void multi_read_write_k(const double2 *__restrict__ base, long stride_v, int K, long nv, double2 *__restrict__ out) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    for (long i = (long)blockIdx.x * 256 * U + threadIdx.x; i < nv; i += (long)gridDim.x * 256 * U) {
+        double2 acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = make_double2(0, 0);
+#pragma unroll 4
+        for (int s = 0; s < K; ++s) {
+            const double2 *p = base + (long)s * stride_v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                long j = i + u * 256;
+                if (j < nv) {
+                    v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(&p[j]));
+                    acc[u].x = __builtin_fma(1.0001, v.x, acc[u].x);
+                    acc[u].y = __builtin_fma(1.0001, v.y, acc[u].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long j = i + u * 256;
+            if (j < nv) {
+                if (NTSTORE) { v2 w; w.x = acc[u].x; w.y = acc[u].y; __builtin_nontemporal_store(w, reinterpret_cast<v2 *>(&out[j])); }
+                else out[j] = acc[u];
+            }
+        }
+    }
+}
+
 // blocked layout: [chunk][slot][CHV vectors]; block-iteration handles one chunk of CHV vectors
 template <int CHV>
 __global__ __launch_bounds__(256) void blocked_read_k(const double2 *__restrict__ base, int K, int slots, long nchunks, double *out) {
@@ -86,7 +118,7 @@ int main(int argc, char **argv) {
         ms = time_ms([&] { hipLaunchKernelGGL(triad_k, dim3(grid), dim3(256), 0, 0, buf, buf + stride_v, out2, 1.5, nv); });
         printf("triad  grid=%5d  %.1f us  %.0f GB/s (2r+w)\n", grid, ms * 1e3, 3.0 * n * 8 / ms / 1e6);
     }
-    for (int K : {1, 2, 4, 8, 16, 41}) {
+    for (int K : {41}) {
         for (int g : {4, 8, 16}) {
             int grid = cus * g;
             double ms = time_ms([&] { hipLaunchKernelGGL((multi_read_k<2, false>), dim3(grid), dim3(256), 0, 0, buf, stride_v, K, nv, out); }, 10);
@@ -94,6 +126,14 @@ int main(int argc, char **argv) {
             double msn = time_ms([&] { hipLaunchKernelGGL((multi_read_k<2, true>), dim3(grid), dim3(256), 0, 0, buf, stride_v, K, nv, out); }, 10);
             printf("read K=%2d grid=%5d  U2 %.0f GB/s  U4 %.0f GB/s  U2-nt %.0f GB/s\n", K, grid, (double)K * n * 8 / ms / 1e6, (double)K * n * 8 / ms4 / 1e6, (double)K * n * 8 / msn / 1e6);
         }
+    }
+    for (int g : {4, 8, 16}) {
+        int grid = cus * g;
+        double m2 = time_ms([&] { hipLaunchKernelGGL((multi_read_write_k<2, false>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, nv, out2); }, 10);
+        double m4 = time_ms([&] { hipLaunchKernelGGL((multi_read_write_k<4, false>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, nv, out2); }, 10);
+        double m4n = time_ms([&] { hipLaunchKernelGGL((multi_read_write_k<4, true>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, nv, out2); }, 10);
+        printf("read41+write1 grid=%5d  U2 %.1f us (%.0f GB/s)  U4 %.1f us (%.0f GB/s)  U4-ntstore %.1f us (%.0f GB/s)\n", grid,
+               m2 * 1e3, 42.0 * n * 8 / m2 / 1e6, m4 * 1e3, 42.0 * n * 8 / m4 / 1e6, m4n * 1e3, 42.0 * n * 8 / m4n / 1e6);
     }
     {   // blocked layout with 41 of 42 slots
         const int slots = 42;
