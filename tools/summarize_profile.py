@@ -27,7 +27,7 @@ def find(d, pat):
     return hits[0] if hits else None
 
 
-def kernel_stats(trace_dir, skip_first_per_kernel=0):
+def kernel_stats(trace_dir, steady=50):
     f = find(trace_dir, "*kernel_trace.csv")
     rows = list(csv.DictReader(open(f)))
     agg = defaultdict(list)
@@ -36,8 +36,12 @@ def kernel_stats(trace_dir, skip_first_per_kernel=0):
     out = []
     total = sum(sum(v) for v in agg.values())
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        # the bench's timed region is its LAST `steps` iterations (history full, k = m); the
+        # earlier launches belong to the untimed ring fill / warm-up and stream fewer vectors
+        tail = v[-steady:] if len(v) >= steady else v
         out.append({"kernel": k, "calls": len(v), "total_us": round(sum(v) / 1e3, 1), "avg_us": round(sum(v) / len(v) / 1e3, 2),
-                    "min_us": round(min(v) / 1e3, 2), "max_us": round(max(v) / 1e3, 2), "pct": round(100 * sum(v) / total, 2)})
+                    "min_us": round(min(v) / 1e3, 2), "max_us": round(max(v) / 1e3, 2), "pct": round(100 * sum(v) / total, 2),
+                    f"timed_region_avg_us_last{steady}": round(sum(tail) / len(tail) / 1e3, 2)})
     return out
 
 
@@ -76,10 +80,11 @@ def main():
                       "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr),
                       "hbm_bytes_per_launch": int(rd + wr),
                       "note": "read = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024; mean over the larger half of launches"}
-        names = {"gram_pass_kernel<double, 5, true, 4>": "lbfgs_gram_pass", "combine_kernel<double, true, 4>": "lbfgs_combine"}
-        for long_name, alias in names.items():
-            if long_name in out:
-                out[alias] = out[long_name]
+        for long_name in list(out):
+            if long_name.startswith("gram_pass_lanes_kernel<double"):
+                out["lbfgs_gram_pass"] = out[long_name]
+            if long_name.startswith("combine_kernel<double"):
+                out["lbfgs_combine"] = out[long_name]
         json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_pmc.json")
