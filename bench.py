@@ -78,10 +78,18 @@ def _dist_setup(gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks on the same device):
+    #   BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0  -> both ranks on cuda:0, flag all-reduced over gloo
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         if gpus != 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
@@ -315,12 +323,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10_000_000)
-    ap.add_argument("--m", type=int, default=20)
+    ap.add_argument("--dim", dest="n", type=int, default=10_000_000, help="problem dimension n")
+    ap.add_argument("--history", dest="m", type=int, default=20, help="L-BFGS history length m")
     ap.add_argument("--mode", choices=["gram", "chain"], default="gram")
     ap.add_argument("--poll", type=int, default=10, help="all-reduce the convergence flag every POLL steps (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=None, help="n of the CPU sample (default: same n)")
+    ap.add_argument("--cpu-dim", dest="cpu_n", type=int, default=None, help="n of the CPU sample (default: same n)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--kernel-events", type=int, default=1, choices=[1, 2],
@@ -397,7 +405,7 @@ def main():
             ach = kernels[dom]["algorithmic_GBps"]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and n == 10_000_000 and k == 20:   # the PMC passes were taken at the headline size
                 try:
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
