@@ -148,6 +148,8 @@ ABI = {
     "dzo_trial_point": [_i64, _i32, _vp, _dbl, _vp, _vp],
     "dzo_problem_create": [_i32, _i64, _i32, _vp, _vp, _dbl, _P(_vp)], "dzo_problem_destroy": [_vp],
     "dzo_problem_eval": [_vp, _vp, _P(_dbl)], "dzo_problem_grad": [_vp, _vp, _vp],
+    "dzo_problem_set_l2": [_vp, _dbl], "dzo_problem_set_box_gradient": [_vp, _i32, _dbl, _dbl],
+    "dzo_problem_set_box_constraint": [_vp, _i32, _dbl, _dbl], "dzo_box_clamp": [_i64, _i32, _vp, _dbl, _dbl],
     "dzo_lbfgs_create": [_i64, _i32, _i32, _vp, _vp, _dbl, _dbl, _P(_vp)],
     "dzo_lbfgs_create_callbacks": [CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp, _i64, _i32, _i32, _vp,
                                    _dbl, _P(_vp)],
@@ -316,6 +318,11 @@ def isequal(a, b):
     _check(lib().dzo_isequal(a.size, _dt(a.dtype), a.ptr, b.ptr, C.byref(r))); return bool(r.value)
 
 
+def box_clamp_(x, lower_bound, upper_bound):
+    """``UniformBoxConstraint(lo, hi)(x)`` (legacy/DZOptimization.jl:264-272); returns True."""
+    _check(lib().dzo_box_clamp(x.size, _dt(x.dtype), x.ptr, lower_bound, upper_bound)); return True
+
+
 def trial_point_(dst, t, d, x):
     _check(lib().dzo_trial_point(x.size, _dt(x.dtype), dst.ptr, t, d.ptr, x.ptr)); return dst
 
@@ -349,7 +356,11 @@ class Problem:
     """Built-in device objective; callable like the reference's callbacks:
     ``p(x)`` = objective_function(x), ``p.gradient_(g, x)`` = gradient_function!(g, x)."""
 
-    def __init__(self, kind, n, dtype=np.float64, A=None, c=None, lam=0.0):
+    def __init__(self, kind, n, dtype=np.float64, A=None, c=None, lam=0.0, l2=0.0, box_gradient=None,
+                 box_constraint=None):
+        """``l2``: L2RegularizationWrapper + L2GradientWrapper lambda; ``box_gradient=(lo, hi)``:
+        UniformBoxGradientWrapper; ``box_constraint=(lo, hi)``: UniformBoxConstraint as the
+        constraint_function! of optimizers built from this problem (legacy/DZOptimization.jl:219-296)."""
         _need_init()
         self.kind, self.n, self.dtype = kind, int(n), np.dtype(dtype)
         # device layout is column-major (legacy/DZOptimization.jl:746): C-order of A' == F-order of A
@@ -359,6 +370,12 @@ class Problem:
         _check(lib().dzo_problem_create(kind, self.n, _dt(dtype), self.A.ptr if self.A else None,
                                         self.c.ptr if self.c else None, lam, C.byref(h)))
         self.h = h
+        if l2:
+            _check(lib().dzo_problem_set_l2(h, l2))
+        if box_gradient is not None:
+            _check(lib().dzo_problem_set_box_gradient(h, 1, box_gradient[0], box_gradient[1]))
+        if box_constraint is not None:
+            _check(lib().dzo_problem_set_box_constraint(h, 1, box_constraint[0], box_constraint[1]))
 
     def __call__(self, x):
         f = C.c_double()
@@ -719,7 +736,7 @@ def step_(opt):
 
 __all__ = [
     "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "BatchedBFGS", "Problem", "DeviceArray", "step_",
-    "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_",
+    "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
     "update_inverse_hessian_", "symv_", "init", "build", "lib", "device_info", "synchronize",
     "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",
 ]

@@ -97,6 +97,8 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
 int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initial_step_length, dzo_adgd_t *out) {
     DZO_TRY(require_init());
     DZO_REQUIRE(problem && x_dev && out, DZO_ERR_INVALID, "null argument");
+    if (problem->cons_on)                                          // :256-258
+        DZO_TRY(dzo_box_clamp(problem->n, problem->dtype, x_dev, problem->cons_lo, problem->cons_hi));
     double f0 = 0;
     DZO_TRY(dzo_problem_eval(problem, x_dev, &f0));                // :260
     void *g = nullptr;
@@ -106,6 +108,7 @@ int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initi
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
     (*out)->core.problem = problem;
+    (*out)->core.box_on = problem->cons_on; (*out)->core.box_lo = problem->cons_lo; (*out)->core.box_hi = problem->cons_hi;
     return DZO_OK;
 }
 

@@ -353,6 +353,8 @@ static int32_t bfgs_point(dzo_bfgs_s *o, const void *dir, double t, bool *change
 // f(P(scratch)) for the point already in scratch (legacy :35-44)
 static int32_t bfgs_phi_at_scratch(dzo_bfgs_s *o, double *f, bool *feasible) {
     *feasible = true;
+    if (!o->constraint && o->problem && o->problem->cons_on)     // built-in UniformBoxConstraint (:36)
+        DZO_TRY(box_clamp_async(o->stream, o->n, o->dtype, o->scratch, o->problem->cons_lo, o->problem->cons_hi));
     if (o->constraint) {
         DZO_HIP(hipStreamSynchronize(o->stream));
         if (!o->constraint(o->cb_ctx, o->scratch)) {           // :36-42
@@ -486,6 +488,8 @@ static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir) {
                                                   (const T *)dir, (const T *)o->g, (T)t, (T *)o->dx, (T *)o->dg));
     }
     DZO_HIP(hipGetLastError());
+    if (!o->constraint && o->problem && o->problem->cons_on)     // :946 built-in box
+        DZO_TRY(box_clamp_async(s, o->n, o->dtype, o->x, o->problem->cons_lo, o->problem->cons_hi));
     if (o->constraint) {                                         // :946-947
         DZO_HIP(hipStreamSynchronize(s));
         DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT,
@@ -566,6 +570,8 @@ static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double init
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     if (o->constraint)
         DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT, "@assert constraint_success (legacy/DZOptimization.jl:770-771)");
+    else if (o->problem && o->problem->cons_on)
+        DZO_TRY(box_clamp_async(o->stream, o->n, o->dtype, o->x, o->problem->cons_lo, o->problem->cons_hi));
     DZO_TRY(bfgs_eval(o, o->x, &o->f));                          // :772
     DZO_REQUIRE(!(o->f != o->f), DZO_ERR_ASSERT, "@assert !isnan(initial_objective_value) (legacy/DZOptimization.jl:773)");
     DZO_TRY(bfgs_grad(o));                                       // :775-776

@@ -1014,6 +1014,8 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
                                  double initial_step_length, dzo_lbfgs_t *out) {
     DZO_TRY(require_init());
     DZO_REQUIRE(problem && x_dev && out, DZO_ERR_INVALID, "null argument");
+    if (problem->cons_on)                                 // :412-414 @assert constraint_function!(initial_point)
+        DZO_TRY(dzo_box_clamp(problem->n, problem->dtype, x_dev, problem->cons_lo, problem->cons_hi));
     double f0 = 0;
     DZO_TRY(dzo_problem_eval(problem, x_dev, &f0));       // :416
     void *g = nullptr;
@@ -1023,6 +1025,7 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
     (*out)->core.problem = problem;
+    (*out)->core.box_on = problem->cons_on; (*out)->core.box_lo = problem->cons_lo; (*out)->core.box_hi = problem->cons_hi;
     return DZO_OK;
 }
 
@@ -1039,6 +1042,8 @@ int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t o, dzo_problem_t problem) {
     DZO_REQUIRE(!problem || (problem->n == o->core.n && problem->dtype == o->core.dtype), DZO_ERR_INVALID,
                 "problem size/dtype does not match the optimizer");
     o->core.problem = problem;
+    o->core.box_on = problem && problem->cons_on;
+    if (problem) { o->core.box_lo = problem->cons_lo; o->core.box_hi = problem->cons_hi; }
     return DZO_OK;
 }
 

@@ -17,6 +17,7 @@ struct OptCore {
     dzo_gradient_fn gradient = nullptr;       // :325
     void *cb_ctx = nullptr;
     dzo_problem_s *problem = nullptr;         // built-in objective; used when callbacks are NULL
+    bool box_on = false; double box_lo = 0, box_hi = 0;   // built-in UniformBoxConstraint (legacy :258-272)
 
     bool is_stuck = false;                    // :327
     int64_t iteration_count = 0;              // :328

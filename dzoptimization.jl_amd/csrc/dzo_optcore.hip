@@ -119,6 +119,8 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     DZO_HIP(hipGetLastError());
     c.search_open = false;
     const bool fused = fuse_objective && c.problem && !c.objective && !c.constraint;
+    // built-in box constraint: projection is always feasible, so it can ride in the stream (:134-135)
+    if (fused && c.box_on) DZO_TRY(box_clamp_async(s, c.n, c.dtype, c.x, c.box_lo, c.box_hi));
     if (fused) DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
     const bool speculate = fused && c.speculative_tail != nullptr;
     if (speculate) {
@@ -157,7 +159,8 @@ int32_t core_reject(OptCore &c) {
 }
 
 int32_t core_constraint(OptCore &c, bool *feasible) {
-    if (!c.constraint) { *feasible = true; return DZO_OK; }      // isnothing(...) :134
+    if (!c.constraint) { *feasible = true; return DZO_OK; }      // isnothing(...) :134 (a built-in box was
+                                                                 // already applied inside core_trial)
     DZO_HIP(hipStreamSynchronize(c.stream));
     *feasible = c.constraint(c.cb_ctx, c.x) != 0;                // :135
     return DZO_OK;

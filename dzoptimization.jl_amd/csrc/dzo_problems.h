@@ -9,6 +9,10 @@ struct dzo_problem_s {
     const void *A = nullptr;   // QUADRATIC: n x n column-major symmetric, device
     const void *c = nullptr;   // LSE: centre, device
     double lambda = 0;
+    // decorators (legacy/DZOptimization.jl:219-296)
+    double l2 = 0;                         // L2 wrappers' lambda; 0 = off
+    bool bg_on = false; double bg_lo = 0, bg_hi = 0;       // UniformBoxGradientWrapper
+    bool cons_on = false; double cons_lo = 0, cons_hi = 0; // UniformBoxConstraint as constraint_function!
     double *scratch = nullptr; // device partials
     double *result = nullptr;  // device: [f, ...] inside scratch
     double *host = nullptr;    // pinned host scalars
@@ -23,4 +27,6 @@ int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void 
 bool problem_has_fused_post(const dzo_problem_s *p, const void *x, const void *dx, const void *g, const void *dg);
 int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x, void *dx, void *g, void *dg,
                                  double *partials, int *grid_out, const int32_t *gate = nullptr);
+// x[i] = clamp(x[i], lo, hi) on stream s (UniformBoxConstraint, legacy :264-272)
+int32_t box_clamp_async(hipStream_t s, int64_t n, int32_t dtype, void *x, double lo, double hi);
 }  // namespace dzo

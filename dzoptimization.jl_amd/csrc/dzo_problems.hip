@@ -294,6 +294,56 @@ __global__ __launch_bounds__(kBlock) void lse_grad_kernel(int64_t n, T *__restri
     }
 }
 
+// ------------------------------------------------------------------ decorators (legacy :219-296)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void box_clamp_kernel(int64_t n, T *__restrict__ x, T lo, T hi) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        const T v = x[i];
+        x[i] = v < lo ? lo : (v > hi ? hi : v);              // clamp(x[i], lo, hi) :269
+    }
+}
+// L2GradientWrapper (:247) then UniformBoxGradientWrapper (:289-294), one pass over g
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grad_decorate_kernel(int64_t n, T *__restrict__ g, const T *__restrict__ x,
+                                                               T two_lambda, int box, T lo, T hi) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        T gi = g[i];
+        const T xi = x[i];
+        if (two_lambda != (T)0) gi = dfma(two_lambda, xi, gi);
+        if (box && ((xi <= lo && gi >= (T)0) || (xi >= hi && gi <= (T)0))) gi = (T)0;
+        g[i] = gi;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sumsq_kernel(int64_t n, const T *__restrict__ x, double *__restrict__ partials) {
+    __shared__ double lds[kWaves];
+    double acc = 0;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) acc = __builtin_fma((double)x[i], (double)x[i], acc);
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+// result[0] = f + lambda * norm2(x)  (:232), in T arithmetic
+__global__ __launch_bounds__(kBlock) void l2_finish_kernel(const double *__restrict__ partials, int count, double lambda,
+                                                           int to_f32, double *__restrict__ result) {
+    __shared__ double lds[kWaves];
+    const double ss = reduce_partials_all(partials, count, lds);
+    if (threadIdx.x == 0) {
+        if (to_f32) result[0] = (double)((float)result[0] + (float)lambda * (float)ss);
+        else result[0] = result[0] + lambda * ss;
+    }
+}
+
+int32_t box_clamp_async(hipStream_t s, int64_t n, int32_t dtype, void *x, double lo, double hi) {
+    DZO_TIMED("box_clamp", s);
+    const int grid = stream_grid(n, 4);
+    DZO_DISPATCH(dtype, hipLaunchKernelGGL(box_clamp_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (T *)x, (T)lo, (T)hi));
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
 // ------------------------------------------------------------------ host side
 template <typename T> static int32_t eval_async_t(dzo_problem_s *p, hipStream_t s, const T *x, double *result_dev) {
     const int64_t n = p->n;
@@ -383,7 +433,7 @@ template <typename T> static int32_t grad_async_t(dzo_problem_s *p, hipStream_t 
 
 bool problem_has_fused_post(const dzo_problem_s *p, const void *x, const void *dx, const void *g, const void *dg) {
     auto al = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    return p && p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && al(x) && al(dx) && al(g) && al(dg);
+    return p && p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && p->l2 == 0.0 && !p->bg_on && al(x) && al(dx) && al(g) && al(dg);
 }
 
 int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x, void *dx, void *g, void *dg,
@@ -404,11 +454,28 @@ int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x,
 }
 
 int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev) {
-    DZO_DISPATCH(p->dtype, return eval_async_t<T>(p, s, (const T *)x, result_dev));
+    DZO_DISPATCH(p->dtype, DZO_TRY(eval_async_t<T>(p, s, (const T *)x, result_dev)));
+    if (p->l2 != 0.0) {                                      // L2RegularizationWrapper (:231-232)
+        DZO_TIMED("objective_l2_term", s);
+        const int grid = stream_grid(p->n, 4);
+        double *part = p->scratch;                           // the base evaluation's partials are consumed
+        DZO_DISPATCH(p->dtype, hipLaunchKernelGGL(sumsq_kernel<T>, dim3(grid), dim3(kBlock), 0, s, p->n, (const T *)x, part));
+        hipLaunchKernelGGL(l2_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)part, grid, p->l2,
+                           p->dtype == DZO_F32 ? 1 : 0, result_dev);
+        DZO_HIP(hipGetLastError());
+    }
     return DZO_OK;
 }
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x) {
-    DZO_DISPATCH(p->dtype, return grad_async_t<T>(p, s, (T *)g, (const T *)x));
+    DZO_DISPATCH(p->dtype, DZO_TRY(grad_async_t<T>(p, s, (T *)g, (const T *)x)));
+    if (p->l2 != 0.0 || p->bg_on) {                          // L2GradientWrapper, UniformBoxGradientWrapper
+        DZO_TIMED("gradient_decorators", s);
+        const int grid = stream_grid(p->n, 4);
+        const double l2 = p->dtype == DZO_F32 ? (double)((float)p->l2 + (float)p->l2) : p->l2 + p->l2;   // :247 lambda + lambda
+        DZO_DISPATCH(p->dtype, hipLaunchKernelGGL(grad_decorate_kernel<T>, dim3(grid), dim3(kBlock), 0, s, p->n, (T *)g,
+                                                  (const T *)x, (T)l2, p->bg_on ? 1 : 0, (T)p->bg_lo, (T)p->bg_hi));
+        DZO_HIP(hipGetLastError());
+    }
     return DZO_OK;
 }
 
@@ -438,6 +505,35 @@ int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A
     if (e != hipSuccess) { (void)hipFree(p->scratch); delete p; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
     p->result = p->scratch + scratch - 8;
     *out = p;
+    return DZO_OK;
+}
+
+int32_t dzo_problem_set_l2(dzo_problem_t p, double lambda) {
+    DZO_REQUIRE(p, DZO_ERR_INVALID, "null problem");
+    p->l2 = lambda;
+    return DZO_OK;
+}
+
+int32_t dzo_problem_set_box_gradient(dzo_problem_t p, int32_t enable, double lower_bound, double upper_bound) {
+    DZO_REQUIRE(p, DZO_ERR_INVALID, "null problem");
+    DZO_REQUIRE(!enable || lower_bound <= upper_bound, DZO_ERR_INVALID, "lower_bound > upper_bound");
+    p->bg_on = enable != 0; p->bg_lo = lower_bound; p->bg_hi = upper_bound;
+    return DZO_OK;
+}
+
+int32_t dzo_problem_set_box_constraint(dzo_problem_t p, int32_t enable, double lower_bound, double upper_bound) {
+    DZO_REQUIRE(p, DZO_ERR_INVALID, "null problem");
+    DZO_REQUIRE(!enable || lower_bound <= upper_bound, DZO_ERR_INVALID, "lower_bound > upper_bound");
+    p->cons_on = enable != 0; p->cons_lo = lower_bound; p->cons_hi = upper_bound;
+    return DZO_OK;
+}
+
+int32_t dzo_box_clamp(int64_t n, int32_t dtype, void *x_dev, double lower_bound, double upper_bound) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(n >= 0 && (x_dev || n == 0), DZO_ERR_INVALID, "bad argument");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    if (n > 0) DZO_TRY(box_clamp_async(ctx().stream, n, dtype, x_dev, lower_bound, upper_bound));
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
     return DZO_OK;
 }
 

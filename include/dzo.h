@@ -135,6 +135,18 @@ int32_t dzo_trial_point(int64_t n, int32_t dtype, void *dst_dev, double t, const
 int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A_dev,
                            const void *c_dev, double lambda, dzo_problem_t *out);
 int32_t dzo_problem_destroy(dzo_problem_t p);
+/* Decorators of legacy/DZOptimization.jl:219-296, applied on the device:
+ *   set_l2            L2RegularizationWrapper (f + lambda*norm2(x), :231-232) and L2GradientWrapper
+ *                     (g += 2*lambda*x, :241-249); lambda = 0 switches it off
+ *   set_box_gradient  UniformBoxGradientWrapper (:282-296): g[i] = 0 where x[i] sits on a bound
+ *                     and the gradient pushes outward
+ *   set_box_constraint UniformBoxConstraint (:264-272) used as the optimizers' constraint_function!
+ *                     (clamp, always feasible) when the optimizer is created from this problem */
+int32_t dzo_problem_set_l2(dzo_problem_t p, double lambda);
+int32_t dzo_problem_set_box_gradient(dzo_problem_t p, int32_t enable, double lower_bound, double upper_bound);
+int32_t dzo_problem_set_box_constraint(dzo_problem_t p, int32_t enable, double lower_bound, double upper_bound);
+/* x[i] = clamp(x[i], lo, hi)   UniformBoxConstraint call, legacy/DZOptimization.jl:264-272 */
+int32_t dzo_box_clamp(int64_t n, int32_t dtype, void *x_dev, double lower_bound, double upper_bound);
 int32_t dzo_problem_eval(dzo_problem_t p, const void *x_dev, double *f);
 int32_t dzo_problem_grad(dzo_problem_t p, void *g_dev, const void *x_dev);
 

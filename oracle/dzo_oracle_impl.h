@@ -136,6 +136,12 @@ typedef struct {
     const T *A;      /* QUADRATIC: dense n x n, column-major */
     const T *c;      /* LSE: centre of the quadratic term */
     T lambda;        /* LSE: weight of the quadratic term */
+    /* decorators of legacy/DZOptimization.jl:219-296 ("next" row 8(f).3) */
+    T l2;            /* L2RegularizationWrapper / L2GradientWrapper lambda (:225-249); 0 = off */
+    int32_t bg_on;   /* UniformBoxGradientWrapper (:275-296) */
+    T bg_lo, bg_hi;
+    int32_t cons_on; /* UniformBoxConstraint (:258-272) used as constraint_function! */
+    T cons_lo, cons_hi;
 } FN(orc_problem);
 
 /* Elementwise term formulas are written once, with explicit fma, and the HIP kernels in
@@ -146,7 +152,7 @@ static inline ACC FN(rosen_term)(T xi, T xn) {
     return (ACC)T_FMA((T)100 * t2, t2, t1 * t1);
 }
 
-T FN(orc_problem_eval)(const FN(orc_problem) *p, const T *x) {
+static T FN(problem_eval_base)(const FN(orc_problem) *p, const T *x) {
     const int64_t n = p->n;
     switch (p->kind) {
     case ORC_PROBLEM_ROSENBROCK2D: {
@@ -189,7 +195,7 @@ T FN(orc_problem_eval)(const FN(orc_problem) *p, const T *x) {
     return (T)NAN;
 }
 
-void FN(orc_problem_grad)(const FN(orc_problem) *p, T *g, const T *x) {
+static void FN(problem_grad_base)(const FN(orc_problem) *p, T *g, const T *x) {
     const int64_t n = p->n;
     switch (p->kind) {
     case ORC_PROBLEM_ROSENBROCK2D: {
@@ -242,6 +248,30 @@ void FN(orc_problem_grad)(const FN(orc_problem) *p, T *g, const T *x) {
     }
 }
 
+/* L2RegularizationWrapper call: objective(x) + lambda * norm2(x)  (legacy/DZOptimization.jl:231-232) */
+T FN(orc_problem_eval)(const FN(orc_problem) *p, const T *x) {
+    T f = FN(problem_eval_base)(p, x);
+    if (p->l2 != (T)0) f = f + p->l2 * FN(orc_norm2)(x, p->n);
+    return f;
+}
+
+/* L2GradientWrapper (:241-249): g += (lambda + lambda) * x, then UniformBoxGradientWrapper
+ * (:282-296): zero the components that push against an active bound. */
+void FN(orc_problem_grad)(const FN(orc_problem) *p, T *g, const T *x) {
+    FN(problem_grad_base)(p, g, x);
+    if (p->l2 != (T)0) FN(orc_axpy)(p->l2 + p->l2, x, g, p->n);          /* :247 */
+    if (p->bg_on) {
+        for (int64_t i = 0; i < p->n; ++i) {                               /* :289-294 */
+            if ((x[i] <= p->bg_lo && g[i] >= (T)0) || (x[i] >= p->bg_hi && g[i] <= (T)0)) g[i] = (T)0;
+        }
+    }
+}
+
+/* UniformBoxConstraint call (:264-272): clamp in place, always feasible. */
+void FN(orc_box_clamp)(T *x, T lo, T hi, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) x[i] = x[i] < lo ? lo : (x[i] > hi ? hi : x[i]);
+}
+
 /* Callback triple in the reference's order (src/DZOptimization.jl:323-325). A NULL
  * constraint is the reference's `nothing` (:71,134,412). */
 typedef T (*FN(orc_objective_fn))(void *ctx, const T *x, int64_t n);
@@ -255,6 +285,11 @@ static T FN(problem_obj_cb)(void *ctx, const T *x, int64_t n) {
 static void FN(problem_grad_cb)(void *ctx, T *g, const T *x, int64_t n) {
     (void)n;
     FN(orc_problem_grad)((const FN(orc_problem) *)ctx, g, x);
+}
+static int FN(problem_constraint_cb)(void *ctx, T *x, int64_t n) {
+    const FN(orc_problem) *p = (const FN(orc_problem) *)ctx;
+    FN(orc_box_clamp)(x, p->cons_lo, p->cons_hi, n);
+    return 1;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -346,8 +381,8 @@ FN(orc_lbfgs) *FN(orc_lbfgs_create)(FN(orc_constraint_fn) cf, FN(orc_objective_f
 
 FN(orc_lbfgs) *FN(orc_lbfgs_create_problem)(const FN(orc_problem) *p, T *x0, T *g0_storage,
                                             T initial_step_length, int32_t m) {
-    return FN(orc_lbfgs_create)(NULL, FN(problem_obj_cb), FN(problem_grad_cb), (void *)p, x0,
-                                g0_storage, initial_step_length, m, p->n);
+    return FN(orc_lbfgs_create)(p->cons_on ? FN(problem_constraint_cb) : NULL, FN(problem_obj_cb),
+                                FN(problem_grad_cb), (void *)p, x0, g0_storage, initial_step_length, m, p->n);
 }
 
 void FN(orc_lbfgs_destroy)(FN(orc_lbfgs) *o) {
@@ -479,9 +514,10 @@ FN(orc_adgd) *FN(orc_adgd_create_full)(FN(orc_constraint_fn) cf, FN(orc_objectiv
 
 FN(orc_adgd) *FN(orc_adgd_create_problem)(const FN(orc_problem) *p, T *x0, T *g0_storage,
                                           T initial_step_length) {
+    if (p->cons_on) FN(orc_box_clamp)(x0, p->cons_lo, p->cons_hi, p->n);   /* :256-258 */
     T f0 = FN(orc_problem_eval)(p, x0);                      /* :260 */
     FN(orc_problem_grad)(p, g0_storage, x0);                 /* :262-265 */
-    return FN(orc_adgd_create_full)(NULL, FN(problem_obj_cb), FN(problem_grad_cb), (void *)p, x0,
+    return FN(orc_adgd_create_full)(p->cons_on ? FN(problem_constraint_cb) : NULL, FN(problem_obj_cb), FN(problem_grad_cb), (void *)p, x0,
                                     f0, g0_storage, initial_step_length, p->n);
 }
 
@@ -720,7 +756,8 @@ FN(orc_bfgs) *FN(orc_bfgs_create)(FN(orc_objective_fn) of, FN(orc_gradient_fn) g
 
 FN(orc_bfgs) *FN(orc_bfgs_create_problem)(const FN(orc_problem) *p, const T *x0,
                                           T initial_step_length) {
-    return FN(orc_bfgs_create)(FN(problem_obj_cb), FN(problem_grad_cb), NULL, (void *)p, x0,
+    return FN(orc_bfgs_create)(FN(problem_obj_cb), FN(problem_grad_cb),
+                               p->cons_on ? FN(problem_constraint_cb) : NULL, (void *)p, x0,
                                initial_step_length, p->n);
 }
 

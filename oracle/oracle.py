@@ -56,14 +56,18 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _problem_fields(ct):
+    return [("kind", C.c_int32), ("n", C.c_int64), ("A", C.c_void_p), ("c", C.c_void_p), ("lam", ct),
+            ("l2", ct), ("bg_on", C.c_int32), ("bg_lo", ct), ("bg_hi", ct),
+            ("cons_on", C.c_int32), ("cons_lo", ct), ("cons_hi", ct)]
+
+
 class _ProblemF64(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("n", C.c_int64), ("A", C.c_void_p), ("c", C.c_void_p),
-                ("lam", C.c_double)]
+    _fields_ = _problem_fields(C.c_double)
 
 
 class _ProblemF32(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("n", C.c_int64), ("A", C.c_void_p), ("c", C.c_void_p),
-                ("lam", C.c_float)]
+    _fields_ = _problem_fields(C.c_float)
 
 
 def _declare(L):
@@ -90,6 +94,7 @@ def _declare(L):
         f("orc_isequal", C.c_int, [vp, vp, i64])
         f("orc_problem_eval", ct, [vp, vp])
         f("orc_problem_grad", None, [vp, vp, vp])
+        f("orc_box_clamp", None, [vp, ct, ct, i64])
         f("orc_lbfgs_direction", None, [vp, vp, vp, vp, vp, vp, i32, i64])
         f("orc_lbfgs_create_problem", vp, [vp, vp, vp, ct, i32])
         f("orc_lbfgs_create_full", vp, [vp, vp, vp, vp, vp, ct, vp, ct, i32, i64])
@@ -161,6 +166,12 @@ def scal(x, alpha):
     getattr(lib(), "orc_scal" + _suf(x.dtype))(_ptr(x), alpha, x.size)
 
 
+def box_clamp(x, lo, hi):
+    """UniformBoxConstraint call (legacy/DZOptimization.jl:264-272), in place."""
+    getattr(lib(), "orc_box_clamp" + _suf(x.dtype))(_ptr(x), lo, hi, x.size)
+    return x
+
+
 def isequal(a, b) -> bool:
     return bool(getattr(lib(), "orc_isequal" + _suf(a.dtype))(_ptr(a), _ptr(b), a.size))
 
@@ -168,14 +179,22 @@ def isequal(a, b) -> bool:
 class Problem:
     """Synthetic objective; the reference's user callbacks."""
 
-    def __init__(self, kind, n, dtype=np.float64, A=None, c=None, lam=0.0):
+    def __init__(self, kind, n, dtype=np.float64, A=None, c=None, lam=0.0, l2=0.0, box_gradient=None,
+                 box_constraint=None):
+        """l2: L2RegularizationWrapper/L2GradientWrapper lambda; box_gradient=(lo, hi):
+        UniformBoxGradientWrapper; box_constraint=(lo, hi): UniformBoxConstraint as the
+        optimizer's constraint_function! (legacy/DZOptimization.jl:219-296)."""
         self.kind, self.n, self.dtype = kind, int(n), np.dtype(dtype)
         self.A = None if A is None else np.asfortranarray(A, dtype=dtype)
         self.c = None if c is None else np.ascontiguousarray(c, dtype=dtype)
         cls = _ProblemF64 if self.dtype == np.float64 else _ProblemF32
+        bg = box_gradient or (0.0, 0.0)
+        bc = box_constraint or (0.0, 0.0)
         self.struct = cls(kind, self.n,
                           None if self.A is None else self.A.ctypes.data,
-                          None if self.c is None else self.c.ctypes.data, lam)
+                          None if self.c is None else self.c.ctypes.data, lam,
+                          l2, int(box_gradient is not None), bg[0], bg[1],
+                          int(box_constraint is not None), bc[0], bc[1])
         self.lam = lam
 
     @property
