@@ -175,6 +175,8 @@ ABI = {
     "dzo_bfgs_create_callbacks": [OBJECTIVE_FN, GRADIENT_FN, CONSTRAINT_FN, _vp, _i64, _i32, _vp, _dbl,
                                   _P(_vp)],
     "dzo_bfgs_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_bfgs_destroy": [_vp], "dzo_bfgs_step": [_vp],
+    "dzo_bfgs_convert_problem": [_vp, _vp, _P(_vp)],
+    "dzo_bfgs_convert_callbacks": [_vp, _i32, OBJECTIVE_FN, GRADIENT_FN, CONSTRAINT_FN, _vp, _P(_vp)],
     "dzo_bfgs_update": [_i64, _i32, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "dzo_symv": [_i64, _i32, _vp, _vp, _vp],
     "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32],
@@ -408,6 +410,45 @@ def _wrap_callbacks(constraint, objective, gradient, n, dtype):
     return cf, of, gf
 
 
+class LineSearchEvaluator:
+    """``LineSearchEvaluator(constraint_function!, objective_function, gradient_function!,
+    initial_point, initial_objective_value, initial_gradient, step_direction, overlap)``
+    (src/DZOptimization.jl:29-62); calling it with ``(step_size, compute_gradient)`` evaluates the
+    trial point ``x + t*d``, its objective, the Armijo quotient ``improvement_ratio`` (:84) and,
+    optionally, the trial gradient and the curvature quotient ``slope_ratio`` (:85-90)."""
+
+    def __init__(self, constraint_function_, objective_function, gradient_function_, initial_point,
+                 initial_objective_value, initial_gradient, step_direction, overlap):
+        _need_init()
+        if isinstance(objective_function, Problem):
+            p = objective_function
+            objective_function, gradient_function_ = p, p.gradient_
+        self.current_point, self.current_gradient, self.step_direction = initial_point, initial_gradient, step_direction
+        self.n, self.dtype = initial_point.size, initial_point.dtype
+        assert initial_gradient.size == self.n and step_direction.size == self.n        # :40-42
+        self.current_objective_value, self.overlap = float(initial_objective_value), float(overlap)
+        self.trial_point = DeviceArray(self.n, self.dtype)                              # :48
+        self.trial_gradient = DeviceArray(self.n, self.dtype)                           # :52
+        self.trial_objective_value = self.improvement_ratio = self.slope_ratio = float("nan")
+        self._cbs = _wrap_callbacks(constraint_function_, objective_function,
+                                    gradient_function_ if gradient_function_ is not None else (lambda g, x: None),
+                                    self.n, self.dtype)
+        self._has_gradient = gradient_function_ is not None
+
+    def __call__(self, step_size, compute_gradient):
+        f, ir, sr = C.c_double(), C.c_double(), C.c_double(self.slope_ratio)
+        if compute_gradient and not self._has_gradient:
+            raise AssertionFailed(3, "@assert !isnothing(lse.gradient_function!) (src/DZOptimization.jl:86)")
+        _check(lib().dzo_line_search_eval(self._cbs[0], self._cbs[1], self._cbs[2], None, self.n, _dt(self.dtype),
+                                          self.current_point.ptr, self.current_objective_value, self.step_direction.ptr,
+                                          self.overlap, step_size, int(bool(compute_gradient)), self.trial_point.ptr,
+                                          self.trial_gradient.ptr, C.byref(f), C.byref(ir), C.byref(sr)))
+        self.trial_objective_value, self.improvement_ratio = f.value, ir.value
+        if compute_gradient or f.value >= 1e38:
+            self.slope_ratio = sr.value
+        return f.value
+
+
 class _OptBase:
     _prefix = ""
     _ptr_idx = True
@@ -635,6 +676,26 @@ class BFGSOptimizer(_OptBase):
                                                    initial_step_length, C.byref(h)))
         self.h = h
 
+    @classmethod
+    def convert(cls, dtype, opt, objective_function=None, gradient_function_=None, constraint_function_=None):
+        """``BFGSOptimizer(::Type{T}, opt)`` / ``BFGSOptimizer(T, f, g!, c!, opt)``
+        (legacy/DZOptimization.jl:812-862): continue ``opt`` in element type ``dtype``.
+        ``objective_function`` must be given as a :class:`Problem` of that dtype or as callables."""
+        _need_init()
+        new = cls.__new__(cls)
+        new.n, new.dtype = opt.n, np.dtype(dtype)
+        new._keep = [objective_function, gradient_function_, constraint_function_]
+        h = C.c_void_p()
+        if isinstance(objective_function, Problem):
+            assert objective_function.dtype == new.dtype
+            _check(lib().dzo_bfgs_convert_problem(opt.h, objective_function.h, C.byref(h)))
+        else:
+            cbs = _wrap_callbacks(constraint_function_, objective_function, gradient_function_, new.n, new.dtype)
+            new._keep.append(cbs)
+            _check(lib().dzo_bfgs_convert_callbacks(opt.h, _dt(new.dtype), cbs[1], cbs[2], cbs[0], None, C.byref(h)))
+        new.h = h
+        return new
+
     def step(self):
         """``step!(opt)`` (legacy/DZOptimization.jl:891-994)."""
         _check(lib().dzo_bfgs_step(self.h))
@@ -735,7 +796,7 @@ def step_(opt):
 
 
 __all__ = [
-    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "BatchedBFGS", "Problem", "DeviceArray", "step_",
+    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "BatchedBFGS", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
     "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
     "update_inverse_hessian_", "symv_", "init", "build", "lib", "device_info", "synchronize",
     "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",

@@ -545,7 +545,7 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
     return DZO_OK;
 }
 
-static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double initial_step_length) {
+static int32_t bfgs_alloc(dzo_bfgs_s *o) {
     const size_t es = dtype_size(o->dtype);
     const size_t vbytes = (size_t)((o->n + 63) / 64 * 64) * es;
     DZO_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
@@ -566,6 +566,63 @@ static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double init
     DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 32)));
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 32)));
     DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocDefault));
+    DZO_HIP(hipDeviceSynchronize());
+    return DZO_OK;
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(kBlock) void cast_kernel(int64_t n, const S *__restrict__ src, D *__restrict__ dst) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) dst[i] = (D)src[i];   // T.(v)
+}
+
+static int32_t cast_async(hipStream_t s, int64_t n, int32_t src_dtype, const void *src, int32_t dst_dtype, void *dst) {
+    const int grid = stream_grid(n, 4);
+    if (src_dtype == dst_dtype) {
+        DZO_HIP(hipMemcpyAsync(dst, src, (size_t)n * dtype_size(src_dtype), hipMemcpyDeviceToDevice, s));
+    } else if (src_dtype == DZO_F64) {
+        hipLaunchKernelGGL((cast_kernel<double, float>), dim3(grid), dim3(kBlock), 0, s, n, (const double *)src, (float *)dst);
+    } else {
+        hipLaunchKernelGGL((cast_kernel<float, double>), dim3(grid), dim3(kBlock), 0, s, n, (const float *)src, (double *)dst);
+    }
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+// BFGSOptimizer(::Type{T}, objective, gradient!, constraint!, opt)  legacy/DZOptimization.jl:819-862:
+// re-types a running optimizer; `o` already carries the new dtype and the new callbacks/problem.
+static int32_t bfgs_convert(dzo_bfgs_s *src, dzo_bfgs_s *o) {
+    DZO_HIP(hipStreamSynchronize(src->stream));
+    DZO_TRY(bfgs_alloc(o));
+    hipStream_t s = o->stream;
+    const int64_t n = o->n;
+    DZO_TRY(cast_async(s, n, src->dtype, src->x, o->dtype, o->x));                  // :825 T.(current_point)
+    if (o->constraint) {
+        DZO_HIP(hipStreamSynchronize(s));
+        DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT, "@assert constraint_success (legacy/DZOptimization.jl:826-827)");
+    } else if (o->problem && o->problem->cons_on) {
+        DZO_TRY(box_clamp_async(s, n, o->dtype, o->x, o->problem->cons_lo, o->problem->cons_hi));
+    }
+    DZO_TRY(bfgs_eval(o, o->x, &o->f));                                              // :828
+    DZO_REQUIRE(!(o->f != o->f), DZO_ERR_ASSERT, "@assert !isnan(initial_objective_value) (legacy/DZOptimization.jl:829)");
+    DZO_TRY(bfgs_grad(o));                                                           // :830-831
+    DZO_TRY(cast_async(s, n * n, src->dtype, src->H, o->dtype, o->H));              // :832
+    DZO_DISPATCH(o->dtype, launch_symv<T>(s, n, (const T *)o->H, (const T *)o->g, (T *)o->d));   // :833-836 mul!
+    DZO_HIP(hipGetLastError());
+    DZO_TRY(cast_async(s, n, src->dtype, src->dx, o->dtype, o->dx));                // :853
+    DZO_TRY(cast_async(s, n, src->dtype, src->dg, o->dtype, o->dg));                // :854
+    o->iteration_count = src->iteration_count;                                       // :848
+    o->has_terminated = false;                                                       // :849
+    o->last_step_length = round_to_dtype(o->dtype, src->last_step_length);           // :855
+    o->last_step_type = src->last_step_type;                                         // :856
+    o->max_increases = src->max_increases;
+    DZO_HIP(hipStreamSynchronize(s));
+    return DZO_OK;
+}
+
+static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double initial_step_length) {
+    const size_t es = dtype_size(o->dtype);
+    DZO_TRY(bfgs_alloc(o));
     DZO_HIP(hipMemcpy(o->x, x0_dev, (size_t)o->n * es, hipMemcpyDeviceToDevice));   // :769 copy
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     if (o->constraint)
@@ -621,6 +678,32 @@ int32_t dzo_bfgs_create_problem(dzo_problem_t problem, const void *x0_dev, doubl
     dzo_bfgs_s *o = new dzo_bfgs_s();
     o->n = problem->n; o->dtype = problem->dtype; o->problem = problem;
     int32_t rc = bfgs_create_common(o, x0_dev, initial_step_length);
+    if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_convert_problem(dzo_bfgs_t src, dzo_problem_t problem, dzo_bfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(src && problem && out, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(problem->n == src->n, DZO_ERR_INVALID, "problem size does not match the optimizer");
+    dzo_bfgs_s *o = new dzo_bfgs_s();
+    o->n = src->n; o->dtype = problem->dtype; o->problem = problem;
+    int32_t rc = bfgs_convert(src, o);
+    if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_convert_callbacks(dzo_bfgs_t src, int32_t dtype, dzo_objective_fn objective, dzo_gradient_fn gradient,
+                                   dzo_constraint_fn constraint, void *cb_ctx, dzo_bfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(src && objective && gradient && out, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    dzo_bfgs_s *o = new dzo_bfgs_s();
+    o->n = src->n; o->dtype = dtype; o->objective = objective; o->gradient = gradient; o->constraint = constraint;
+    o->cb_ctx = cb_ctx;
+    int32_t rc = bfgs_convert(src, o);
     if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
     *out = o;
     return DZO_OK;

@@ -259,6 +259,16 @@ int32_t dzo_bfgs_create_callbacks(dzo_objective_fn objective, dzo_gradient_fn gr
                                   dzo_bfgs_t *out);
 int32_t dzo_bfgs_create_problem(dzo_problem_t problem, const void *x0_dev,
                                 double initial_step_length, dzo_bfgs_t *out);
+/* Re-precision constructors BFGSOptimizer(::Type{T}, opt) / (::Type{T}, f, g!, c!, opt)
+ * (legacy/DZOptimization.jl:812-862): a NEW optimizer of the target element type that continues
+ * from `src`: x, H, delta_point, delta_gradient are converted elementwise (T.(..)), f and g are
+ * re-evaluated in the new precision, d = H*g is recomputed (:833-836), iteration_count /
+ * last_step_length / last_step_type carry over, has_terminated restarts as false (:849).
+ * The target type is the new problem's dtype, or `dtype` for the callback form. */
+int32_t dzo_bfgs_convert_problem(dzo_bfgs_t src, dzo_problem_t problem_of_target_dtype, dzo_bfgs_t *out);
+int32_t dzo_bfgs_convert_callbacks(dzo_bfgs_t src, int32_t dtype, dzo_objective_fn objective,
+                                   dzo_gradient_fn gradient, dzo_constraint_fn constraint, void *ctx,
+                                   dzo_bfgs_t *out);
 int32_t dzo_bfgs_destroy(dzo_bfgs_t opt);
 /* step!(opt) (:891-994): competitive quadratic line searches, accept / reset / terminate. */
 int32_t dzo_bfgs_step(dzo_bfgs_t opt);

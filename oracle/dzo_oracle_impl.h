@@ -580,6 +580,14 @@ T FN(orc_line_search_eval)(FN(orc_constraint_fn) cf, FN(orc_objective_fn) of,
     return f_new;
 }
 
+T FN(orc_line_search_eval_problem)(const FN(orc_problem) *p, const T *x, T f_old, const T *dir, T overlap,
+                                   T step_size, int compute_gradient, T *trial_point, T *trial_gradient,
+                                   T *improvement_ratio, T *slope_ratio) {
+    return FN(orc_line_search_eval)(p->cons_on ? FN(problem_constraint_cb) : NULL, FN(problem_obj_cb),
+                                    FN(problem_grad_cb), (void *)p, p->n, x, f_old, dir, overlap, step_size,
+                                    compute_gradient, trial_point, trial_gradient, improvement_ratio, slope_ratio);
+}
+
 /* ------------------------------------------------------------------------------------------
  * Dense BFGS -- legacy/DZOptimization.jl:733-994 (specification by reading; the legacy code
  * cannot run even under Julia because LineSearchFunctor / quadratic_line_search / add! /

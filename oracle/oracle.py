@@ -123,6 +123,7 @@ def _declare(L):
         f("orc_bfgs_line_search", None, [vp, C.c_int, ct, vp, vp])
         f("orc_line_search_eval", ct,
           [vp, vp, vp, vp, i64, vp, ct, vp, ct, ct, C.c_int, vp, vp, vp, vp])
+        f("orc_line_search_eval_problem", ct, [vp, vp, ct, vp, ct, ct, C.c_int, vp, vp, vp, vp])
 
 
 def set_dot_mode(mode: int) -> None:
@@ -432,6 +433,18 @@ class BFGS:
         getattr(lib(), "orc_bfgs_line_search" + self.suf)(
             self.h, int(use_gradient_dir), t0, C.byref(t), C.byref(f))
         return t.value, f.value
+
+
+def line_search_eval(problem, x, f_old, direction, overlap, step_size, compute_gradient):
+    """LineSearchEvaluator call (src/DZOptimization.jl:65-92).
+    Returns (f_new, improvement_ratio, slope_ratio, trial_point, trial_gradient)."""
+    ct = _ct(problem.dtype)
+    tp, tg = np.empty_like(x), np.empty_like(x)
+    ir, sr = ct(), ct()
+    f = getattr(lib(), "orc_line_search_eval_problem" + _suf(problem.dtype))(
+        problem.ref, _ptr(x), f_old, _ptr(direction), overlap, step_size, int(compute_gradient), _ptr(tp), _ptr(tg),
+        C.byref(ir), C.byref(sr))
+    return f, ir.value, sr.value, tp, tg
 
 
 def bfgs_update(H, step_length, d, dg):

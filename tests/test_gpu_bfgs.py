@@ -242,3 +242,34 @@ def test_full_size_config5_shard_properties():
     for _ in range(5):
         ref.step()
     assert rel(batch.current_point.to_host()[3], ref.current_point) <= 1e-7
+
+
+# ------------------------------------------------------------------------------ re-precision (a10)
+def test_reprecision_constructor_continues_the_run():
+    """BFGSOptimizer(::Type{T}, opt) (legacy/DZOptimization.jl:812-862): fp32 warm start, fp64 finish."""
+    n = 32
+    x0 = orc.pcg_fill(n, 7)
+    p32 = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, np.float32)
+    p64 = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, np.float64)
+    lo = dzo.BFGSOptimizer(p32, None, dzo.DeviceArray.from_host(x0.astype(np.float32)), 1.0)
+    for _ in range(15):
+        lo.step()
+    H32, x32 = lo.approximate_inverse_hessian.to_host(), lo.current_point.to_host()
+    hi = dzo.BFGSOptimizer.convert(np.float64, lo, p64)
+    assert hi.dtype == np.float64 and hi.iteration_count == lo.iteration_count            # :848
+    assert not hi.has_terminated and hi.last_step_type == lo.last_step_type               # :849,:856
+    assert np.array_equal(hi.current_point.to_host(), x32.astype(np.float64))              # :825 T.(x)
+    H64 = hi.approximate_inverse_hessian.to_host()
+    assert np.array_equal(H64, H32.astype(np.float64))                                     # :832
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    x = hi.current_point.to_host()
+    assert hi.current_objective_value == pytest.approx(ref_p.eval(x), rel=1e-13)           # :828 in fp64
+    assert np.array_equal(hi.current_gradient.to_host(), ref_p.grad(x))                    # :830-831
+    assert rel(hi.next_step_direction.to_host(), H64 @ ref_p.grad(x)) <= 1e-13            # :833-836
+    assert np.array_equal(hi.delta_point.to_host(), lo.delta_point.to_host().astype(np.float64))
+    f_before = hi.current_objective_value
+    steps = 0
+    while not hi.has_converged and steps < 400:
+        hi.step(); steps += 1
+    assert hi.has_converged and hi.current_objective_value < 1e-18 < f_before
+    assert np.allclose(hi.current_point.to_host(), 1.0, atol=1e-8)

@@ -487,3 +487,36 @@ def test_full_size_two_loop_n1e7_m20():
     # secant property of the implicit inverse Hessian: H_k y_1 = s_1, so d(g = y_1) = -s_1
     opt.current_gradient.upload(Y[0])
     assert rel(opt.compute_step_direction().to_host(), -S[0]) <= 1e-9
+
+
+# ------------------------------------------------------------------------------ LineSearchEvaluator (a6)
+def test_line_search_evaluator_call_matches_oracle():
+    """src/DZOptimization.jl:65-92: trial point, objective, Armijo and curvature quotients."""
+    n = 2049
+    x = orc.rosenbrock_chain_x0(n)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    g = ref_p.grad(x)
+    d = -g / np.linalg.norm(g)
+    overlap = float(g @ d)
+    f0 = ref_p.eval(x)
+    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+    lse = dzo.LineSearchEvaluator(None, prob, None, dzo.DeviceArray.from_host(x), f0, dzo.DeviceArray.from_host(g),
+                                  dzo.DeviceArray.from_host(d), overlap)
+    for t, with_grad in ((1e-3, True), (0.05, False), (0.5, True)):
+        f_new = lse(t, with_grad)
+        f_ref, ir, sr, tp, tg = orc.line_search_eval(ref_p, x, f0, d, overlap, t, with_grad)
+        assert np.array_equal(lse.trial_point.to_host(), tp)                       # fma(t, d, x): bit-exact
+        assert f_new == pytest.approx(f_ref, rel=1e-13)
+        assert lse.improvement_ratio == pytest.approx(ir, rel=1e-9)
+        if with_grad:
+            assert np.array_equal(lse.trial_gradient.to_host(), tg)
+            assert lse.slope_ratio == pytest.approx(sr, rel=1e-10)
+    # infeasible trial point (:71-79): typemax / typemin sentinels, objective not evaluated
+    calls = []
+    lse2 = dzo.LineSearchEvaluator(lambda x_: False, lambda x_: calls.append(1) or 0.0, None,
+                                   dzo.DeviceArray.from_host(x), f0, dzo.DeviceArray.from_host(g),
+                                   dzo.DeviceArray.from_host(d), overlap)
+    assert lse2(0.1, False) == np.finfo(np.float64).max and not calls
+    assert lse2.improvement_ratio == -np.finfo(np.float64).max
+    with pytest.raises(AssertionError):                                             # :86 @assert
+        lse2(0.1, True)
