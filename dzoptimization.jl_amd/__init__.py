@@ -182,6 +182,8 @@ ABI = {
     "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32],
     "dzo_bfgs_get_i": [_vp, _i32, _P(_i64)], "dzo_bfgs_get_s": [_vp, _i32, _P(_dbl)],
     "dzo_bfgs_get_ptr": [_vp, _i32, _P(_vp)],
+    "dzo_gd_create_callbacks": [CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp, _i64, _i32, _vp, _dbl, _P(_vp)],
+    "dzo_gd_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_gd_step": [_vp],
     "dzo_bfgs_batch_create": [_i32, _i64, _i64, _i32, _vp, _dbl, _P(_vp)], "dzo_bfgs_batch_destroy": [_vp],
     "dzo_bfgs_batch_step": [_vp, _i32, _P(_i32)], "dzo_bfgs_batch_get_ptr": [_vp, _i32, _P(_vp)],
     "dzo_bfgs_batch_count_active": [_vp, _P(_i64)],
@@ -723,6 +725,45 @@ class BFGSOptimizer(_OptBase):
         _check(lib().dzo_bfgs_set_max_increases(self.h, v))
 
 
+class GradientDescentOptimizer(BFGSOptimizer):
+    """``GradientDescentOptimizer([constraint_function!,] objective_function, gradient_function!,
+    line_search_function!, initial_point, initial_step_length)`` (legacy/DZOptimization.jl:330-390).
+    ``line_search_function!`` must be ``QuadraticLineSearch()`` -- pass ``None`` or the string;
+    it is the only search the reference defines (:181-216)."""
+
+    def __init__(self, *args):
+        _need_init()
+        if len(args) == 5:
+            constraint_function_, (objective_function, gradient_function_, _ls, initial_point, initial_step_length) = None, args
+        elif len(args) == 6:
+            constraint_function_, objective_function, gradient_function_, _ls, initial_point, initial_step_length = args
+        else:
+            raise TypeError("GradientDescentOptimizer([c!,] f, g!, line_search!, x0, step)")
+        x0 = _as_dev(initial_point)
+        self.n, self.dtype = x0.size, x0.dtype
+        self._keep = [objective_function, gradient_function_, constraint_function_, x0]
+        h = C.c_void_p()
+        if isinstance(objective_function, Problem) and constraint_function_ is None:
+            _check(lib().dzo_gd_create_problem(objective_function.h, x0.ptr, initial_step_length, C.byref(h)))
+        else:
+            if isinstance(objective_function, Problem):
+                p = objective_function
+                objective_function, gradient_function_ = p, p.gradient_
+            cbs = _wrap_callbacks(constraint_function_, objective_function, gradient_function_, self.n, self.dtype)
+            self._keep.append(cbs)
+            _check(lib().dzo_gd_create_callbacks(cbs[0], cbs[1], cbs[2], None, self.n, _dt(self.dtype), x0.ptr,
+                                                 initial_step_length, C.byref(h)))
+        self.h = h
+
+    def step(self):
+        """``step!(opt)`` (legacy/DZOptimization.jl:393-449)."""
+        _check(lib().dzo_gd_step(self.h))
+        return self
+
+    delta_objective_value = property(lambda s: s._s(2))
+    approximate_inverse_hessian = property(lambda s: None)
+
+
 def update_inverse_hessian_(H, step_length, d, dg, scratch, g=None, d_next=None):
     """``update_inverse_hessian!`` (legacy/DZOptimization.jl:864-889) on device arrays, with
     the optional fused next direction ``d_next = H_new * g`` (:958-960)."""
@@ -796,7 +837,7 @@ def step_(opt):
 
 
 __all__ = [
-    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "BatchedBFGS", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
+    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
     "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
     "update_inverse_hessian_", "symv_", "init", "build", "lib", "device_info", "synchronize",
     "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void identity_kernel(int64_t n, T *__restri
         H[e] = (e / n == e % n) ? (T)1 : (T)0;              // :712-720
 }
 
-// scratch = fma(-t, dir, x) with the two bracket flags (:71-80):
+// scratch = fma(t_signed, dir, x) with the two bracket flags (:71-80):
 //   flags[0] |= any(x != new)   ("point_changed"),  flags[1] |= any(dir != 0)  ("!step_is_zero")
 template <typename T>
 __global__ __launch_bounds__(kBlock) void phi_point_kernel(int64_t n, T *__restrict__ dst, T t, const T *__restrict__ dir,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void phi_point_kernel(int64_t n, T *__restr
     bool changed = false, nonzero = false;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
         const T xi = x[i], di = dir[i];
-        const T nw = dfma(-t, di, xi);
+        const T nw = dfma(t, di, xi);                            // t carries the sign: -t for BFGS (:945), +t legacy (:33)
         dst[i] = nw;
         changed |= (xi != nw);
         nonzero |= (di != (T)0);
@@ -288,6 +288,9 @@ struct dzo_bfgs_s {
     void *scratch = nullptr;                    // :748
     void *ref_point = nullptr;                  // LineSearchEvaluator.reference_point (:17)
     int32_t max_increases = 0;                  // QuadraticLineSearch.max_increases (:181-188)
+    double sign = -1.0;                         // trial point x + sign*t*dir: -1 BFGS (:945), +1 legacy evaluator (:33)
+    bool no_hessian = false;                    // legacy GradientDescentOptimizer shares this state without H
+    double df = 0;                              // GradientDescentOptimizer.delta_objective_value (:313)
     int64_t evals = 0;
     double *upd_part = nullptr;                 // device: 2*ceil(n/4) partials of the fused update scalars
     double *ws = nullptr;                       // device: partials + scalars + flags
@@ -337,7 +340,7 @@ static int32_t bfgs_point(dzo_bfgs_s *o, const void *dir, double t, bool *change
         DZO_TIMED("bfgs_trial_point", s);
         const int grid = stream_grid(o->n, 1);
         DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(phi_point_kernel<T>, dim3(grid), dim3(kBlock), 0, s, o->n, (T *)o->scratch,
-                                                  (T)t, (const T *)dir, (const T *)o->x, o->flags()));
+                                                  (T)(o->sign * t), (const T *)dir, (const T *)o->x, o->flags()));
     }
     DZO_HIP(hipGetLastError());
     if (changed || nonzero) {
@@ -555,7 +558,7 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
         if (e != hipSuccess) { set_error("out of device memory allocating BFGS vectors"); return DZO_ERR_NOMEM; }
         DZO_HIP(hipMemset(*v, 0, vbytes));                      // :777-778 zero deltas
     }
-    {
+    if (!o->no_hessian) {
         hipError_t e = hipMalloc(&o->H, (size_t)o->n * (size_t)o->n * es);
         if (e != hipSuccess) {
             set_error("out of device memory allocating the %lld x %lld inverse Hessian", (long long)o->n, (long long)o->n);
@@ -640,11 +643,116 @@ static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double init
     return DZO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Legacy GradientDescentOptimizer (legacy/DZOptimization.jl:305-449) with QuadraticLineSearch
+// (:181-216) as line_search_function!: same search code, sign = +1, d = next_step_direction.
+// ---------------------------------------------------------------------------------------------
+static int32_t gd_inv_norm(dzo_bfgs_s *o, const void *v, double *out) {     // Kernels.jl:141 rsqrt(norm2(x))
+    double ss = 0;
+    DZO_TRY(dot_blocking(o->stream, o->n, o->dtype, v, v, o->partials(), o->host, &ss));
+    *out = o->dtype == DZO_F32 ? (double)(1.0f / sqrtf((float)ss)) : 1.0 / sqrt(ss);
+    return DZO_OK;
+}
+
+static int32_t gd_create_common(dzo_bfgs_s *o, const void *x0_dev, double initial_step_length) {
+    const size_t es = dtype_size(o->dtype);
+    o->no_hessian = true;
+    o->sign = 1.0;
+    DZO_TRY(bfgs_alloc(o));
+    DZO_HIP(hipMemcpy(o->x, x0_dev, (size_t)o->n * es, hipMemcpyDeviceToDevice));   // :339 collect
+    DZO_HIP(hipDeviceSynchronize());
+    if (o->constraint)
+        DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT, "@assert constraint_function!(current_point) (legacy/DZOptimization.jl:340)");
+    else if (o->problem && o->problem->cons_on)
+        DZO_TRY(box_clamp_async(o->stream, o->n, o->dtype, o->x, o->problem->cons_lo, o->problem->cons_hi));
+    DZO_TRY(bfgs_eval(o, o->x, &o->f));                          // :343
+    DZO_TRY(bfgs_grad(o));                                       // :347-348
+    o->last_step_length = 0;                                     // :351
+    double ign = 0;
+    DZO_TRY(gd_inv_norm(o, o->g, &ign));                         // :352
+    if (std::isfinite(ign)) {                                    // :354-357  d = g * (-step * inv_norm)
+        const double sc = round_to_dtype(o->dtype, -initial_step_length * ign);
+        DZO_DISPATCH(o->dtype, launch_scal_oop<T>(o->stream, o->n, (T *)o->d, (T)sc, (const T *)o->g));
+        DZO_HIP(hipGetLastError());
+    }
+    o->has_terminated = !std::isfinite(o->f) || !std::isfinite(ign);   // :364-366
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    return DZO_OK;
+}
+
+static int32_t gd_step(dzo_bfgs_s *o) {
+    if (o->has_terminated) return DZO_OK;                        // :402
+    const int32_t dt = o->dtype;
+    const size_t bytes = (size_t)o->n * dtype_size(dt);
+    hipStream_t s = o->stream;
+    double t, fv;
+    DZO_TRY(bfgs_quadratic_search(o, o->d, o->f, 1.0, &t, &fv)); // :405-407 (bracket starts at step size 1, :89)
+    if (t == 0.0 || !(fv < o->f)) { o->has_terminated = true; return DZO_OK; }   // :410-414
+    o->iteration_count += 1;                                     // :415
+    DZO_HIP(hipMemcpyAsync(o->dx, o->x, bytes, hipMemcpyDeviceToDevice, s));      // :418
+    DZO_DISPATCH(dt, launch_axpy<T>(s, o->n, (T)t, (const T *)o->d, (T *)o->x));  // :419
+    if (o->constraint) {                                         // :420
+        DZO_HIP(hipStreamSynchronize(s));
+        DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT, "@assert constraint_function!(current_point) (legacy/DZOptimization.jl:420)");
+    } else if (o->problem && o->problem->cons_on) {
+        DZO_TRY(box_clamp_async(s, o->n, dt, o->x, o->problem->cons_lo, o->problem->cons_hi));
+    }
+    DZO_DISPATCH(dt, launch_axpby<T>(s, o->n, (T)1, (const T *)o->x, (T)-1, (T *)o->dx));   // :423 delta!(dx, x): dx = x - dx
+    double ss = 0;
+    DZO_TRY(dot_blocking(s, o->n, dt, o->dx, o->dx, o->partials(), o->host, &ss));
+    const double step_length = dt == DZO_F32 ? (double)sqrtf((float)ss) : sqrt(ss);        // :424
+    o->last_step_length = step_length;                           // :425
+    o->df = round_to_dtype(dt, fv - o->f);                       // :428-429
+    o->f = fv;                                                   // :430
+    DZO_HIP(hipMemcpyAsync(o->dg, o->g, bytes, hipMemcpyDeviceToDevice, s));      // :433
+    DZO_TRY(bfgs_grad(o));                                       // :434
+    DZO_DISPATCH(dt, launch_axpby<T>(s, o->n, (T)1, (const T *)o->g, (T)-1, (T *)o->dg));   // :435
+    double ign = 0;
+    DZO_TRY(gd_inv_norm(o, o->g, &ign));                         // :438
+    if (!std::isfinite(ign)) { o->has_terminated = true; return DZO_OK; }          // :439-442
+    const double sc = round_to_dtype(dt, -step_length * ign);
+    DZO_DISPATCH(dt, launch_scal_oop<T>(s, o->n, (T *)o->d, (T)sc, (const T *)o->g));       // :445-446
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(s));
+    return DZO_OK;
+}
+
 }  // namespace dzo
 
 using namespace dzo;
 
 extern "C" {
+
+int32_t dzo_gd_create_problem(dzo_problem_t problem, const void *x0_dev, double initial_step_length, dzo_bfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(problem && x0_dev && out, DZO_ERR_INVALID, "null argument");
+    dzo_bfgs_s *o = new dzo_bfgs_s();
+    o->n = problem->n; o->dtype = problem->dtype; o->problem = problem;
+    int32_t rc = gd_create_common(o, x0_dev, initial_step_length);
+    if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_gd_create_callbacks(dzo_constraint_fn constraint, dzo_objective_fn objective, dzo_gradient_fn gradient,
+                                void *cb_ctx, int64_t n, int32_t dtype, const void *x0_dev, double initial_step_length,
+                                dzo_bfgs_t *out) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(objective && gradient && x0_dev && out && n >= 1, DZO_ERR_INVALID, "bad argument");
+    DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    dzo_bfgs_s *o = new dzo_bfgs_s();
+    o->n = n; o->dtype = dtype; o->objective = objective; o->gradient = gradient; o->constraint = constraint;
+    o->cb_ctx = cb_ctx;
+    int32_t rc = gd_create_common(o, x0_dev, initial_step_length);
+    if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
+    *out = o;
+    return DZO_OK;
+}
+
+int32_t dzo_gd_step(dzo_bfgs_t o) {
+    DZO_REQUIRE(o && o->no_hessian, DZO_ERR_INVALID, "not a GradientDescentOptimizer handle");
+    return gd_step(o);
+}
 
 int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
     if (!o) return DZO_OK;
@@ -711,6 +819,7 @@ int32_t dzo_bfgs_convert_callbacks(dzo_bfgs_t src, int32_t dtype, dzo_objective_
 
 int32_t dzo_bfgs_step(dzo_bfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(!o->no_hessian, DZO_ERR_INVALID, "GradientDescentOptimizer handle: use dzo_gd_step");
     return bfgs_step(o);
 }
 
@@ -763,8 +872,8 @@ int32_t dzo_bfgs_get_i(dzo_bfgs_t o, int32_t what, int64_t *value) {
 
 int32_t dzo_bfgs_get_s(dzo_bfgs_t o, int32_t what, double *value) {
     DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
-    DZO_REQUIRE(what == 0 || what == 1, DZO_ERR_INVALID, "unknown field %d", what);
-    *value = what == 0 ? o->f : o->last_step_length;
+    DZO_REQUIRE(what >= 0 && what <= 2, DZO_ERR_INVALID, "unknown field %d", what);
+    *value = what == 0 ? o->f : (what == 1 ? o->last_step_length : o->df);
     return DZO_OK;
 }
 

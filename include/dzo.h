@@ -295,6 +295,21 @@ int32_t dzo_bfgs_get_s(dzo_bfgs_t opt, int32_t what, double *value);
 int32_t dzo_bfgs_get_ptr(dzo_bfgs_t opt, int32_t what, void **ptr_dev);
 
 /* ---------------------------------------------------------------------------------------
+ * Legacy GradientDescentOptimizer (legacy/DZOptimization.jl:305-449) with
+ * QuadraticLineSearch() (:181-216) as its line_search_function!.  Argument order constraint,
+ * objective, gradient follows :330-337.  The handle type and the getters are the BFGS ones
+ * (dzo_bfgs_get_i / get_s / get_ptr / destroy; get_s field 2 = delta_objective_value, get_ptr
+ * field 4 = next_step_direction = -last_step_length * g/|g|, field 5 is NULL: no Hessian).
+ * ------------------------------------------------------------------------------------- */
+int32_t dzo_gd_create_callbacks(dzo_constraint_fn constraint, dzo_objective_fn objective,
+                                dzo_gradient_fn gradient, void *ctx, int64_t n, int32_t dtype,
+                                const void *x0_dev, double initial_step_length, dzo_bfgs_t *out);
+int32_t dzo_gd_create_problem(dzo_problem_t problem, const void *x0_dev, double initial_step_length,
+                              dzo_bfgs_t *out);
+/* step!(opt) (:393-449) */
+int32_t dzo_gd_step(dzo_bfgs_t opt);
+
+/* ---------------------------------------------------------------------------------------
  * Batched dense BFGS: B independent BFGSOptimizer instances on one device, one workgroup per
  * instance, the whole step (both line searches included) on the device.  "run multiple
  * optimizers in parallel" (README.md:12); sharding across GPUs is one process per GPU with

@@ -618,12 +618,14 @@ typedef struct {
     T *ref_point;                       /* LineSearchEvaluator.reference_point (:17) */
     int32_t max_increases;              /* QuadraticLineSearch.max_increases (:181-188), 0 = off */
     int64_t evals;                      /* objective evaluations so far */
+    T sign;                             /* trial point x + sign*t*dir: -1 for BFGS (:945), +1 for the
+                                           legacy evaluator (:33) used by GradientDescentOptimizer */
 } FN(orc_bfgs);
 
 /* phi(t) = f(P(x - t*dir)), evaluated out of place into `scratch`
  * (legacy/DZOptimization.jl:25-46 with legacy/Kernels.jl:127-135; sign from :945). */
 static T FN(bfgs_phi)(FN(orc_bfgs) *o, const T *dir, T t) {
-    FN(orc_axpy_oop)(o->scratch, -t, dir, o->x, o->n);
+    FN(orc_axpy_oop)(o->scratch, o->sign * t, dir, o->x, o->n);
     if (o->constraint && !o->constraint(o->ctx, o->scratch, o->n)) return T_MAXVAL; /* :40-42 */
     o->evals += 1;
     return o->objective(o->ctx, o->scratch, o->n);
@@ -639,7 +641,7 @@ static void FN(bfgs_bracket)(FN(orc_bfgs) *o, const T *dir, T f0, T t0, T *x1, T
     int step_is_zero = 1, point_changed = 0;                 /* :71-80 */
     for (int64_t i = 0; i < n; ++i) {
         step_is_zero &= (dir[i] == (T)0);
-        T nw = T_FMA(-t0, dir[i], o->x[i]);
+        T nw = T_FMA(o->sign * t0, dir[i], o->x[i]);
         point_changed |= (o->x[i] != nw);
     }
     if (step_is_zero) return;                                /* :83-85 */
@@ -650,7 +652,7 @@ static void FN(bfgs_bracket)(FN(orc_bfgs) *o, const T *dir, T f0, T t0, T *x1, T
         step_is_small = 1;
         if (!T_ISFINITE(step)) return;
         for (int64_t i = 0; i < n; ++i) {
-            T nw = T_FMA(-step, dir[i], o->x[i]);
+            T nw = T_FMA(o->sign * step, dir[i], o->x[i]);
             point_changed |= (o->x[i] != nw);
         }
     }
@@ -759,6 +761,7 @@ FN(orc_bfgs) *FN(orc_bfgs_create)(FN(orc_objective_fn) of, FN(orc_gradient_fn) g
     o->scratch = (T *)malloc((size_t)n * sizeof(T));         /* :785 */
     o->ref_point = (T *)malloc((size_t)n * sizeof(T));
     o->has_terminated = isnan(o->f) ? 1 : 0;                 /* :773 @assert -> terminated */
+    o->sign = (T)-1;
     return o;
 }
 
@@ -818,6 +821,84 @@ void FN(orc_bfgs_step)(FN(orc_bfgs) *o) {
         o->has_terminated = 1;                               /* :989 */
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Legacy GradientDescentOptimizer -- legacy/DZOptimization.jl:305-449,
+ * with line_search_function! = QuadraticLineSearch() (:181-216).  It reuses the search state
+ * of the BFGS restatement with sign = +1 (trial point x + t*d, :33) and d = next_step_direction.
+ * Fields: f / last_step_length / iteration_count / has_terminated / x / g / dx / dg / d as above;
+ * `df` is delta_objective_value (:313).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    FN(orc_bfgs) b;     /* H stays NULL */
+    T df;
+} FN(orc_gd);
+
+static T FN(inv_norm)(const T *x, int64_t n) { return (T)1 / T_SQRT(FN(orc_norm2)(x, n)); }   /* Kernels.jl:141 rsqrt(norm2) */
+
+/* constructor :330-374 */
+FN(orc_gd) *FN(orc_gd_create_problem)(const FN(orc_problem) *p, const T *x0, T initial_step_length) {
+    FN(orc_gd) *o = (FN(orc_gd) *)calloc(1, sizeof(*o));
+    FN(orc_bfgs) *b = &o->b;
+    const int64_t n = p->n;
+    b->objective = FN(problem_obj_cb); b->gradient = FN(problem_grad_cb);
+    b->constraint = p->cons_on ? FN(problem_constraint_cb) : NULL;
+    b->ctx = (void *)p; b->n = n; b->sign = (T)1;
+    b->x = (T *)malloc((size_t)n * sizeof(T));
+    FN(orc_copy)(b->x, x0, n);                                    /* :339 collect */
+    if (b->constraint) b->constraint(b->ctx, b->x, n);            /* :340 @assert */
+    b->dx = (T *)calloc((size_t)n, sizeof(T));                    /* :341 */
+    b->f = b->objective(b->ctx, b->x, n);                         /* :343 */
+    b->g = (T *)malloc((size_t)n * sizeof(T));
+    b->gradient(b->ctx, b->g, b->x, n);                           /* :347-348 */
+    b->dg = (T *)calloc((size_t)n, sizeof(T));                    /* :349 */
+    b->last_step_length = 0;                                      /* :351 */
+    T ign = FN(inv_norm)(b->g, n);                                /* :352 */
+    b->d = (T *)calloc((size_t)n, sizeof(T));                     /* :353 */
+    if (T_ISFINITE(ign)) {                                        /* :354-357 */
+        FN(orc_copy)(b->d, b->g, n);
+        FN(orc_scal)(b->d, -initial_step_length * ign, n);
+    }
+    b->scratch = (T *)malloc((size_t)n * sizeof(T));
+    b->ref_point = (T *)malloc((size_t)n * sizeof(T));
+    b->has_terminated = (!T_ISFINITE(b->f)) || (!T_ISFINITE(ign));   /* :364-366 */
+    return o;
+}
+
+void FN(orc_gd_destroy)(FN(orc_gd) *o) {
+    if (!o) return;
+    free(o->b.x); free(o->b.g); free(o->b.dx); free(o->b.dg); free(o->b.d); free(o->b.scratch); free(o->b.ref_point);
+    free(o);
+}
+
+/* step! :393-449 */
+void FN(orc_gd_step)(FN(orc_gd) *o) {
+    FN(orc_bfgs) *b = &o->b;
+    const int64_t n = b->n;
+    if (b->has_terminated) return;                                /* :402 */
+    T t, fv;
+    FN(bfgs_quadratic_search)(b, b->d, b->f, (T)1, &t, &fv);      /* :405-407 bracket starts at step size 1 (:89) */
+    if (t == (T)0 || !(fv < b->f)) { b->has_terminated = 1; return; }   /* :410-414 */
+    b->iteration_count += 1;                                      /* :415 */
+    FN(orc_copy)(b->dx, b->x, n);                                 /* :418 */
+    FN(orc_axpy)(t, b->d, b->x, n);                               /* :419 */
+    if (b->constraint) b->constraint(b->ctx, b->x, n);            /* :420 */
+    for (int64_t i = 0; i < n; ++i) b->dx[i] = b->x[i] - b->dx[i];   /* :423 delta! */
+    T step_length = T_SQRT(FN(orc_norm2)(b->dx, n));              /* :424 */
+    b->last_step_length = step_length;                            /* :425 */
+    o->df = fv - b->f;                                            /* :428-429 */
+    b->f = fv;                                                    /* :430 */
+    FN(orc_copy)(b->dg, b->g, n);                                 /* :433 */
+    b->gradient(b->ctx, b->g, b->x, n);                           /* :434 */
+    for (int64_t i = 0; i < n; ++i) b->dg[i] = b->g[i] - b->dg[i];   /* :435 */
+    T ign = FN(inv_norm)(b->g, n);                                /* :438 */
+    if (!T_ISFINITE(ign)) { b->has_terminated = 1; return; }      /* :439-442 */
+    const T sc = -step_length * ign;
+    for (int64_t i = 0; i < n; ++i) b->d[i] = sc * b->g[i];       /* :445-446 scale!(dst, alpha, x) */
+}
+
+FN(orc_bfgs) *FN(orc_gd_base)(FN(orc_gd) *o) { return &o->b; }
+T FN(orc_gd_delta_f)(const FN(orc_gd) *o) { return o->df; }
 
 /* ------------------------------------------------------------------------------------------
  * Field accessors for the ctypes loader (oracle/oracle.py); no reference counterpart -- in

@@ -124,6 +124,11 @@ def _declare(L):
         f("orc_line_search_eval", ct,
           [vp, vp, vp, vp, i64, vp, ct, vp, ct, ct, C.c_int, vp, vp, vp, vp])
         f("orc_line_search_eval_problem", ct, [vp, vp, ct, vp, ct, ct, C.c_int, vp, vp, vp, vp])
+        f("orc_gd_create_problem", vp, [vp, vp, ct])
+        f("orc_gd_destroy", None, [vp])
+        f("orc_gd_step", None, [vp])
+        f("orc_gd_base", vp, [vp])
+        f("orc_gd_delta_f", ct, [vp])
 
 
 def set_dot_mode(mode: int) -> None:
@@ -445,6 +450,29 @@ def line_search_eval(problem, x, f_old, direction, overlap, step_size, compute_g
         problem.ref, _ptr(x), f_old, _ptr(direction), overlap, step_size, int(compute_gradient), _ptr(tp), _ptr(tg),
         C.byref(ir), C.byref(sr))
     return f, ir.value, sr.value, tp, tg
+
+
+class GradientDescent(BFGS):
+    """Legacy GradientDescentOptimizer with QuadraticLineSearch (legacy/DZOptimization.jl:305-449)."""
+
+    def __init__(self, problem: Problem, x0, initial_step_length):
+        self.problem, self.dtype = problem, problem.dtype
+        self.suf = _suf(self.dtype)
+        x0 = np.ascontiguousarray(x0, dtype=self.dtype)
+        self.n = x0.size
+        self.gd = getattr(lib(), "orc_gd_create_problem" + self.suf)(problem.ref, _ptr(x0), initial_step_length)
+        self.h = getattr(lib(), "orc_gd_base" + self.suf)(self.gd)     # BFGS accessors read the shared fields
+
+    def close(self):
+        if getattr(self, "gd", None):
+            getattr(lib(), "orc_gd_destroy" + self.suf)(self.gd)
+            self.gd = self.h = None
+
+    def step(self):
+        getattr(lib(), "orc_gd_step" + self.suf)(self.gd)
+        return self
+
+    delta_objective_value = property(lambda s: getattr(lib(), "orc_gd_delta_f" + s.suf)(s.gd))
 
 
 def bfgs_update(H, step_length, d, dg):

@@ -273,3 +273,27 @@ def test_reprecision_constructor_continues_the_run():
         hi.step(); steps += 1
     assert hi.has_converged and hi.current_objective_value < 1e-18 < f_before
     assert np.allclose(hi.current_point.to_host(), 1.0, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------ legacy GD (8f.4)
+def test_legacy_gradient_descent_matches_oracle():
+    n = 300
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    ref = orc.GradientDescent(ref_p, x0, 0.1)
+    opt = dzo.GradientDescentOptimizer(dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, "QuadraticLineSearch",
+                                       dzo.DeviceArray.from_host(x0), 0.1)
+    assert rel(opt.next_step_direction.to_host(), ref.next_step_direction) <= 1e-14
+    scale = np.linalg.norm(x0)
+    for it in range(25):
+        opt.step(); ref.step()
+        assert opt.has_terminated == ref.has_terminated and opt.iteration_count == ref.iteration_count
+        x = opt.current_point.to_host()
+        assert np.linalg.norm(x - ref.current_point) <= 1e-10 * scale, it
+        assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-10)
+        assert opt.last_step_length == pytest.approx(ref.last_step_length, rel=1e-9)
+        assert opt.delta_objective_value == pytest.approx(ref.delta_objective_value, rel=1e-6)
+        assert np.array_equal(opt.current_gradient.to_host(), ref_p.grad(x))
+        assert rel(opt.next_step_direction.to_host(), ref.next_step_direction) <= 1e-9
+    with pytest.raises(dzo.DzoError):
+        dzo._check(dzo.lib().dzo_bfgs_step(opt.h))          # a GD handle is not a BFGS handle

@@ -335,3 +335,30 @@ def test_bfgs_quadratic_invariants_and_direction_identity():
     assert np.allclose(opt.next_step_direction, H @ opt.current_gradient, rtol=1e-12, atol=1e-14)
     hist = _run_and_test(opt, p.eval, p.grad, flag="has_terminated")
     assert hist[-1]["f"] < 1e-20 * max(hist[0]["f"], 1e-300) or hist[-1]["f"] < 1e-25
+
+
+# ------------------------------------------------------- legacy GradientDescentOptimizer (8f.4)
+def test_legacy_gradient_descent_invariants():
+    """legacy/DZOptimization.jl:305-449 with QuadraticLineSearch; run_and_test! equalities."""
+    n = 12
+    p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    x0 = orc.rosenbrock_chain_x0(n)
+    opt = orc.GradientDescent(p, x0, 0.1)
+    g0 = p.grad(x0)
+    assert np.allclose(opt.next_step_direction, -0.1 * g0 / np.linalg.norm(g0), rtol=1e-14)   # :354-357
+    assert opt.last_step_length == 0.0 and not opt.has_terminated                              # :351,:364
+    prev_x, prev_g, prev_f = opt.current_point.copy(), opt.current_gradient.copy(), opt.current_objective_value
+    for i in range(60):
+        opt.step()
+        if opt.has_terminated:
+            break
+        x, g = opt.current_point.copy(), opt.current_gradient.copy()
+        assert opt.iteration_count == i + 1
+        assert np.array_equal(x - prev_x, opt.delta_point) and np.array_equal(g - prev_g, opt.delta_gradient)
+        assert p.eval(x) == opt.current_objective_value < prev_f
+        assert opt.delta_objective_value == opt.current_objective_value - prev_f               # :428-429
+        assert opt.last_step_length == pytest.approx(np.linalg.norm(x - prev_x), rel=1e-14)    # :424
+        want_d = -opt.last_step_length * g / np.linalg.norm(g)                                 # :445-446
+        assert np.allclose(opt.next_step_direction, want_d, rtol=1e-13)
+        prev_x, prev_g, prev_f = x, g, opt.current_objective_value
+    assert opt.iteration_count > 20
