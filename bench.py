@@ -440,7 +440,7 @@ def main():
         "step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 1),
         "roofline": roofline, "kernels": kernels,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N = 1 only
         threads = min(os.cpu_count() or 1, 16)
         cn = args.cpu_n or n
         cwarm = m if cn == n else m
