@@ -43,6 +43,7 @@ struct dzo_lbfgs_s {
     int32_t newest = 0;             // slot of pair 0
     int64_t stride = 0;             // elements between slots
     void *S = nullptr, *Y = nullptr;
+    bool interleaved = true;
     void *d = nullptr;              // :337 step_direction
     int32_t mode = DZO_TWOLOOP_GRAM;
     int32_t n_alpha = 0;            // length(alpha_history) (:498-500)
@@ -60,16 +61,20 @@ struct dzo_lbfgs_s {
     int gram_grid = 0;
     bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
     int gram_variant = 1;           // 1 = lane-distributed accumulators
+    int gram_peel = 1;              // predicate-free path for full tiles
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
     int spare() const { return (newest + 1) % (m + 1); }
-    template <typename T> T *s_slot(int slot) const { return (T *)S + (int64_t)slot * stride; }
-    template <typename T> T *y_slot(int slot) const { return (T *)Y + (int64_t)slot * stride; }
-    void *s_slot_v(int slot) const { return (char *)S + (size_t)slot * stride * dzo::dtype_size(core.dtype); }
-    void *y_slot_v(int slot) const { return (char *)Y + (size_t)slot * stride * dzo::dtype_size(core.dtype); }
+    // layout 1 (default): ONE slab, slots interleaved s_0 y_0 s_1 y_1 ... (Y = S + stride, pair
+    // stride 2*stride): consecutive streams sit an odd number of KiB apart.  layout 0: two slabs.
+    int64_t pair_stride = 0;        // elements between consecutive slots of the same history
+    template <typename T> T *s_slot(int slot) const { return (T *)S + (int64_t)slot * pair_stride; }
+    template <typename T> T *y_slot(int slot) const { return (T *)Y + (int64_t)slot * pair_stride; }
+    void *s_slot_v(int slot) const { return (char *)S + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype); }
+    void *y_slot_v(int slot) const { return (char *)Y + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype); }
     void refresh_delta_ptrs() { core.dx = s_slot_v(spare()); core.dg = y_slot_v(spare()); }
 };
 
@@ -228,6 +233,7 @@ template <typename T> struct GramParams {
     const T *sp;                // pivot pair (the pair whose Gram row/column is (re)computed)
     const T *yp;
     int k;
+    int peel;                   // 1: full tiles run the predicate-free path
     const T *s[kMaxHistory];    // logical pair -> slot base (wave-uniform index -> scalar loads)
     const T *y[kMaxHistory];
     double *partials;           // [kGramValues * k][gridDim.x]
@@ -296,13 +302,18 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
     const int k = p.k;
     const int64_t nvec = p.n / N;
     const int64_t nthreads = (int64_t)gridDim.x * kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
+    // One tile = kBlock*U vectors of every stream.  FULL tiles run without any bounds predicate:
+    // with predicates every load sits behind an exec branch, the compiler can no longer count
+    // outstanding loads and waits vmcnt(0) before each fma block, which serialises the
+    // two-register-set prefetch below.
+    auto do_tile = [&](int64_t base, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         T gv[U][N], spv[U][N], ypv[U][N];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
-            ok[u] = vi < nvec;
+            ok[u] = FULL || vi < nvec;
             if (ok[u]) {
                 L::load_nt(p.g + vi * N, gv[u]);
                 L::load_nt(sp + vi * N, spv[u]);
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             const T *yi = p.y[i];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (ok[u]) {
+                if (FULL || ok[u]) {
                     const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
                     L::load_nt(si + vi * N, sv[u]);
                     L::load_nt(yi + vi * N, yv[u]);
@@ -359,7 +370,14 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             if (i + 2 < k) fetch(i + 2, sA, yA);
             if (i + 1 < k) consume(i + 1, sB, yB);
         }
-    }
+    };
+    const int64_t tile_v = (int64_t)kBlock * U;
+    const int64_t full_tiles = nvec / tile_v;
+    if (p.peel) { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::true_type{}); }
+    else { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::false_type{}); }
+    // ragged last tile: the block that would have taken tile index `full_tiles`
+    if (full_tiles * tile_v < nvec && (int64_t)blockIdx.x == full_tiles % gridDim.x) do_tile(full_tiles * tile_v, std::false_type{});
+    (void)nthreads;
     // scalar tail (n not a multiple of the vector width): lane i of wave 0 in block 0 owns pair i
     if (VEC && blockIdx.x == 0 && wave == 0 && lane < k) {
         for (int64_t e = nvec * N; e < p.n; ++e) {
@@ -719,6 +737,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     gp.sp = o->s_slot<T>(o->slot_of(pivot)); gp.yp = o->y_slot<T>(o->slot_of(pivot));
     for (int i = 0; i < k; ++i) { gp.s[i] = o->s_slot<T>(o->slot_of(i)); gp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     gp.partials = o->gram_partials;
+    gp.peel = o->gram_peel;
     const bool vec = al16(c.g);
     if (o->gram_variant == 1) {
         // lane-distributed accumulators: one launch shape for every k (the pair-per-wave
@@ -915,7 +934,13 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     c.f = round_to_dtype(dtype, initial_objective_value);
     o->m = history_length;
     const size_t es = dtype_size(dtype);
-    o->stride = (n + 63) / 64 * 64;
+    {
+        // slot stride: n rounded up to 1 KiB, and an ODD number of KiB, so that the 2(m+1) streams
+        // never sit a power-of-two distance apart (same HBM channel / bank for equal offsets)
+        size_t sb = ((size_t)n * es + 1023) / 1024 * 1024;
+        if ((sb / 1024) % 2 == 0 && tune("DZO_TUNE_STRIDE_SKEW", 1)) sb += 1024;
+        o->stride = (int64_t)(sb / es);
+    }
     int32_t rc = core_alloc(c);
     if (rc != DZO_OK) { delete o; return rc; }
     const int m1 = o->m + 1;
@@ -924,12 +949,21 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
 #define ALLOC(ptr, bytes)                                                                          \
     e = hipMalloc((void **)&(ptr), (bytes));                                                       \
     if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
-    ALLOC(o->S, slab);
-    ALLOC(o->Y, slab);
+    o->interleaved = tune("DZO_TUNE_INTERLEAVE", 1) != 0;
+    if (o->interleaved) {
+        ALLOC(o->S, 2 * slab);
+        o->Y = (char *)o->S + (size_t)o->stride * es;
+        o->pair_stride = 2 * o->stride;
+    } else {
+        ALLOC(o->S, slab);
+        ALLOC(o->Y, slab);
+        o->pair_stride = o->stride;
+    }
     ALLOC(o->d, (size_t)o->stride * es);
     o->gram_u = tune("DZO_TUNE_GRAM_U", 4);
     o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
     o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
+    o->gram_peel = tune("DZO_TUNE_GRAM_PEEL", 1);
     o->fused_post = tune("DZO_TUNE_FUSED_POST", 1) != 0;
     o->combine_nts = tune("DZO_TUNE_COMBINE_NTS", 1) != 0;
     o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
@@ -959,8 +993,12 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1);
     o->link_partials = base;
     // :366-374 zero-filled deltas: the whole ring starts zeroed
-    DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
-    DZO_HIP(hipMemsetAsync(o->Y, 0, slab, c.stream));
+    if (o->interleaved) {
+        DZO_HIP(hipMemsetAsync(o->S, 0, 2 * slab, c.stream));
+    } else {
+        DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
+        DZO_HIP(hipMemsetAsync(o->Y, 0, slab, c.stream));
+    }
     o->k = 0; o->newest = o->m;   // spare() == 0
     o->refresh_delta_ptrs();
     // :381-388
@@ -984,7 +1022,7 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (!o) return DZO_OK;
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->S) (void)hipFree(o->S);
-    if (o->Y) (void)hipFree(o->Y);
+    if (o->Y && !o->interleaved) (void)hipFree(o->Y);
     if (o->d) (void)hipFree(o->d);
     if (o->rho) (void)hipFree(o->rho);
     core_free(o->core);
