@@ -19,7 +19,8 @@ module DZOptimizationAMD
 using LinearAlgebra
 import LinearAlgebra: axpy!, axpby!, dot, norm, rmul!
 
-export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, step!,
+export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentOptimizer, QuadraticLineSearch,
+       UniformBoxConstraint, with_l2!, with_box_gradient!, with_box_constraint!, step!,
        RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem
 
 const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
@@ -151,6 +152,22 @@ end
 function gradient!(p::BuiltinProblem{T}, g::HipVector{T}, x::HipVector{T}) where {T}
     check(ccall((:dzo_problem_grad, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), p.handle, g.ptr, x.ptr))
     return g
+end
+
+# decorators of legacy/DZOptimization.jl:219-296, applied on the device
+"""`with_l2!(p, lambda)`: L2RegularizationWrapper + L2GradientWrapper (legacy :225-249)."""
+with_l2!(p::BuiltinProblem, lambda::Real) = (check(ccall((:dzo_problem_set_l2, libdzo), Cint, (Ptr{Cvoid}, Cdouble), p.handle, lambda)); p)
+"""`with_box_gradient!(p, lo, hi)`: UniformBoxGradientWrapper (legacy :275-296)."""
+with_box_gradient!(p::BuiltinProblem, lo::Real, hi::Real) =
+    (check(ccall((:dzo_problem_set_box_gradient, libdzo), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble), p.handle, 1, lo, hi)); p)
+"""`with_box_constraint!(p, lo, hi)`: UniformBoxConstraint (legacy :258-272) as constraint_function!."""
+with_box_constraint!(p::BuiltinProblem, lo::Real, hi::Real) =
+    (check(ccall((:dzo_problem_set_box_constraint, libdzo), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble), p.handle, 1, lo, hi)); p)
+"""`UniformBoxConstraint(lo, hi)(x)` on a device vector (legacy :264-272)."""
+struct UniformBoxConstraint{T}; lower_bound::T; upper_bound::T; end
+function (c::UniformBoxConstraint)(x::HipVector{T}) where {T}
+    check(ccall((:dzo_box_clamp, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Cdouble, Cdouble), x.len, dtype_code(T), x.ptr, c.lower_bound, c.upper_bound))
+    return true
 end
 
 ################################################################################ callbacks
@@ -316,6 +333,23 @@ function Base.getproperty(o::BFGSOptimizer{T}, s::Symbol) where {T}
     s === :approximate_inverse_hessian && return _bf_p(o, 5, getfield(o, :n)^2)   # column-major n*n
     return getfield(o, s)
 end
+
+################################################################################ legacy gradient descent
+
+"""`GradientDescentOptimizer(objective, gradient!, QuadraticLineSearch(), x0, step)`
+(legacy/DZOptimization.jl:377-390); built-in objectives only in this thin binding.  The handle is a
+BFGS-family handle, so the `BFGSOptimizer` getters apply (no `approximate_inverse_hessian`)."""
+struct QuadraticLineSearch; max_increases::Int; end
+QuadraticLineSearch() = QuadraticLineSearch(0)
+function GradientDescentOptimizer(objective::BuiltinProblem{T}, ::Any, ls::QuadraticLineSearch, x0::HipVector{T}, step::Real) where {T}
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_gd_create_problem, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), objective.handle, x0.ptr, step, h))
+    check(ccall((:dzo_bfgs_set_max_increases, libdzo), Cint, (Ptr{Cvoid}, Cint), h[], ls.max_increases))
+    return GDHandle{T}(h[], length(x0), objective)
+end
+struct GDHandle{T}; handle::Ptr{Cvoid}; n::Int; keep::Any; end
+step!(opt::GDHandle) = (check(ccall((:dzo_gd_step, libdzo), Cint, (Ptr{Cvoid},), opt.handle)); opt)
 
 ################################################################################ AdGD
 

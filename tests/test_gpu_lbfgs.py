@@ -403,7 +403,7 @@ def test_rejected_trials_with_speculation_leave_state_consistent():
     assert ref.last_trials >= 1 and max(1, ref.last_trials) >= 1
 
 
-@settings(max_examples=12, deadline=None)
+@settings(max_examples=int(__import__('os').environ.get('DZO_FUZZ_EXAMPLES', '12')), deadline=None, derandomize=True)
 @given(n=st.integers(1, 3000), m=st.integers(1, 7), warm=st.integers(0, 9), seed=st.integers(0, 1000),
        mode=st.sampled_from([0, 1]))
 def test_property_single_step_parity_random_shapes(n, m, warm, seed, mode):

@@ -136,7 +136,7 @@ def test_two_loop_equals_dense_inverse_recursion():
     assert np.linalg.norm(d - d_dense) <= 1e-11 * np.linalg.norm(d_dense)
 
 
-@settings(max_examples=25, deadline=None)
+@settings(max_examples=25, deadline=None, derandomize=True)
 @given(n=st.integers(1, 64), k=st.integers(0, 6), seed=st.integers(0, 2**31))
 def test_two_loop_dot_mode_invariance(n, k, seed):
     g, S, Y, rho = _pairs(n, k, seed)
