@@ -520,3 +520,39 @@ def test_line_search_evaluator_call_matches_oracle():
     assert lse2.improvement_ratio == -np.finfo(np.float64).max
     with pytest.raises(AssertionError):                                             # :86 @assert
         lse2(0.1, True)
+
+
+def test_full_size_step_run_config3_invariants():
+    """BASELINE config 3 at full size (n = 10^7, m = 20, fp64): 120 step!() calls on the device;
+    strict decrease every step, and the exact run_and_test! equalities at sampled steps."""
+    n, m = 10_000_000, 20
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    f_prev = opt.current_objective_value
+    assert f_prev == pytest.approx(ref_p.eval(x0), rel=1e-12)
+    trials = 0
+    for it in range(120):
+        sample = it in (0, 19, 20, 21, 63, 119)                  # warm-up, ring wrap, steady state
+        if sample:
+            x_old, g_old = opt.current_point.to_host(), opt.current_gradient.to_host()
+        opt.step()
+        assert not opt.is_stuck
+        f = opt.current_objective_value
+        assert f < f_prev                                        # :139 strict decrease
+        assert opt.delta_objective_value == pytest.approx(f - f_prev, rel=1e-9)
+        f_prev = f
+        trials += opt.last_trials
+        if sample:
+            x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
+            assert np.array_equal(x - x_old, opt.delta_point.to_host())          # :1035-1039 exact
+            assert np.array_equal(g - g_old, opt.delta_gradient.to_host())       # :1042-1046 exact
+            orc.set_threads(8)
+            try:
+                assert np.array_equal(ref_p.grad(x), g)                          # :1025-1032 exact
+                assert abs(ref_p.eval(x) - f) <= 1e-12 * f                       # :1019-1022 (reduction order)
+            finally:
+                orc.set_threads(1)
+            assert np.array_equal(opt.delta_point_history[0].to_host(), x - x_old)
+    assert opt.iteration_count == 120 and opt.history_count == m
+    assert trials <= 2 * 120
