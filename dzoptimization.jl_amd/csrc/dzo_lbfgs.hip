@@ -62,6 +62,9 @@ struct dzo_lbfgs_s {
     bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
     int gram_variant = 1;           // 1 = lane-distributed accumulators
     int gram_peel = 1;              // predicate-free path for full tiles
+    bool rho_pending = false;       // rho partials of the newest pair await their final sum
+    int tail_grid = 0;              // grid of the last speculative tail (its partial count)
+    int rho_pending_count = 0, rho_pending_slot = 0;
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
@@ -390,11 +393,19 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             acc[4] = __builtin_fma(sx, ype, acc[4]);
         }
     }
+    // combine the four waves of the block in a fixed order, then one partial per (value, block)
+    __shared__ double wacc[kWaves][kMaxHistory][kGramValues];
     if (lane < k) {
-        const int64_t pcount = (int64_t)gridDim.x * kWaves;
-        const int64_t pidx = (int64_t)blockIdx.x * kWaves + wave;
 #pragma unroll
-        for (int c = 0; c < kGramValues; ++c) p.partials[(int64_t)(lane * kGramValues + c) * pcount + pidx] = acc[c];
+        for (int c = 0; c < kGramValues; ++c) wacc[wave][lane][c] = acc[c];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < k) {
+#pragma unroll
+        for (int c = 0; c < kGramValues; ++c) {
+            const double r = (wacc[0][lane][c] + wacc[1][lane][c]) + (wacc[2][lane][c] + wacc[3][lane][c]);
+            p.partials[(int64_t)(lane * kGramValues + c) * gridDim.x + blockIdx.x] = r;
+        }
     }
 }
 
@@ -414,9 +425,18 @@ struct GramFinishParams {
 
 // Second stage of the Gram pass: one block per value sums that value's per-block partials in
 // a fixed order (value-major layout -> contiguous reads).
+// The last block (index nvals) optionally finishes the pending rho = delta_point.delta_gradient
+// of the pair pushed by the previous step (:505), saving that step a launch of its own.
 __global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
-                                                             double *__restrict__ vals) {
+                                                             double *__restrict__ vals, int nvals,
+                                                             const double *__restrict__ rho_partials, int rho_count,
+                                                             double *__restrict__ rho_dst, int rho_to_f32) {
     __shared__ double lds[kWaves];
+    if ((int)blockIdx.x == nvals) {
+        const double r = reduce_partials_all(rho_partials, rho_count, lds);
+        if (threadIdx.x == 0) rho_dst[0] = rho_to_f32 ? (double)(float)r : r;
+        return;
+    }
     const double *src = partials + (int64_t)blockIdx.x * grid;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int b = threadIdx.x; b < grid; b += 4 * kBlock) {
@@ -762,11 +782,16 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
             if (gu == 1) GL(1); else if (gu == 2) GL(2); else if (gu == 8) GL(8); else GL(4);
 #undef GL
         }
-        const int pcount = lgrid * kWaves;
+        const int pcount = lgrid;
         double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
         {
             DZO_TIMED("lbfgs_gram_reduce", s);
-            hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * k), dim3(kBlock), 0, s, o->gram_partials, pcount, vals);
+            const int nvals = kGramValues * k;
+            const bool rho = o->rho_pending;
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(nvals + (rho ? 1 : 0)), dim3(kBlock), 0, s, o->gram_partials, pcount,
+                               vals, nvals, (const double *)c.partials(), o->rho_pending_count, o->rho + o->rho_pending_slot,
+                               c.dtype == DZO_F32 ? 1 : 0);
+            o->rho_pending = false;
         }
         return gram_finish_launch(o, pivot, recurrence, vals);
     }
@@ -814,13 +839,18 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
+static int32_t lbfgs_flush_rho(dzo_lbfgs_s *o);
+
 static int32_t lbfgs_direction(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (o->k == 0) {                                      // :438 then the :443 guard
         DZO_HIP(hipMemcpyAsync(o->d, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
         return DZO_OK;
     }
-    if (o->mode == DZO_TWOLOOP_CHAIN) DZO_DISPATCH(c.dtype, return direction_chain<T>(o));
+    if (o->mode == DZO_TWOLOOP_CHAIN) {
+        DZO_TRY(lbfgs_flush_rho(o));
+        DZO_DISPATCH(c.dtype, return direction_chain<T>(o));
+    }
     DZO_DISPATCH(c.dtype, return direction_gram<T>(o));
     return DZO_OK;
 }
@@ -847,6 +877,19 @@ static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
 }
 
 // :505 rho of the pair being pushed (fixed-order sum of the partials), then the ring rotation
+// rho of the newest pair is summed lazily: in GRAM mode the next direction's gram_reduce launch
+// carries it; anything else that needs rho on the device or host flushes it first.
+static int32_t lbfgs_flush_rho(dzo_lbfgs_s *o) {
+    if (!o->rho_pending) return DZO_OK;
+    OptCore &c = o->core;
+    DZO_TIMED("lbfgs_rho_finish", c.stream);
+    hipLaunchKernelGGL(finish_to_kernel, dim3(1), dim3(kBlock), 0, c.stream, c.partials(), o->rho_pending_count,
+                       o->rho + o->rho_pending_slot, c.dtype == DZO_F32 ? 1 : 0, (const int32_t *)nullptr);
+    DZO_HIP(hipGetLastError());
+    o->rho_pending = false;
+    return DZO_OK;
+}
+
 static int32_t lbfgs_rho_finish(dzo_lbfgs_s *o, int grid, const int32_t *gate) {
     OptCore &c = o->core;
     DZO_TIMED("lbfgs_rho_finish", c.stream);
@@ -864,13 +907,22 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
     OptCore &c = o->core;
     int grid = 0;
     DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, gate));
+    o->tail_grid = grid;
+    if (o->mode == DZO_TWOLOOP_GRAM) return DZO_OK;      // rho rides on the next gram_reduce launch
     return lbfgs_rho_finish(o, grid, gate);
 }
 
 static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done) {
     OptCore &c = o->core;
     const int sp = o->spare();
-    if (!rho_done) DZO_TRY(lbfgs_rho_finish(o, grid, nullptr));
+    if (o->mode == DZO_TWOLOOP_GRAM) {
+        // defer the final sum of rho to the next direction's gram_reduce launch
+        o->rho_pending = true;
+        o->rho_pending_count = rho_done ? o->tail_grid : grid;
+        o->rho_pending_slot = sp;
+    } else if (!rho_done) {
+        DZO_TRY(lbfgs_rho_finish(o, grid, nullptr));
+    }
     // :482-496  pushfirst!: the spare slots (= delta_point, delta_gradient) become pair 0
     o->newest = sp;
     if (o->k < o->m) o->k += 1;
@@ -1088,6 +1140,7 @@ int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t o, dzo_problem_t problem) {
 int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t o, int32_t mode) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(mode == DZO_TWOLOOP_CHAIN || mode == DZO_TWOLOOP_GRAM, DZO_ERR_INVALID, "bad two-loop mode %d", mode);
+    DZO_TRY(lbfgs_flush_rho(o));
     if (mode == DZO_TWOLOOP_GRAM && o->mode != DZO_TWOLOOP_GRAM) o->gram_rebuild = true;
     o->mode = mode;
     return DZO_OK;
@@ -1210,6 +1263,7 @@ int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t 
     DZO_REQUIRE(o && count, DZO_ERR_INVALID, "null argument");
     *count = o->k;
     if (!out) return DZO_OK;
+    DZO_TRY(lbfgs_flush_rho(o));
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     double tmp[kMaxHistory + 1];
     DZO_HIP(hipMemcpy(tmp, o->rho, sizeof(double) * (o->m + 1), hipMemcpyDeviceToHost));
@@ -1233,6 +1287,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
+    o->rho_pending = false;                              // the whole history (and its rho) is replaced
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     const size_t es = dtype_size(c.dtype);

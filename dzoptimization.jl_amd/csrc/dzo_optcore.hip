@@ -59,11 +59,25 @@ __global__ __launch_bounds__(kBlock) void trial_kernel(int64_t n, T *x, T *__res
 }
 
 // Device-side acceptance test of take_backtracking_step! (:128, :139): lets the host enqueue the
-// accepted-step tail speculatively instead of idling the GPU across a host round trip.
-__global__ void decide_kernel(const double *__restrict__ result, const int32_t *__restrict__ changed, double f_cur,
-                              int to_f32, int32_t *__restrict__ status) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double f_new = to_f32 ? (double)(float)result[0] : result[0];
+// accepted-step tail speculatively instead of idling the GPU across a host round trip.  When
+// `partials` is given the kernel also performs the objective's final fixed-order sum (one launch
+// fewer per trial) and publishes f_new in result[0].
+__global__ __launch_bounds__(kBlock) void decide_kernel(double *__restrict__ result, const double *__restrict__ partials,
+                                                        int64_t count, double scale,
+                                                        const int32_t *__restrict__ changed, double f_cur, int to_f32,
+                                                        int32_t *__restrict__ status) {
+    __shared__ double lds[kWaves];
+    double f_new;
+    if (partials) {
+        double v = 0;
+        for (int64_t i = threadIdx.x; i < count; i += kBlock) v += partials[i];
+        f_new = scale * block_sum(v, lds);
+        if (threadIdx.x == 0) result[0] = f_new;
+    } else {
+        f_new = result[0];
+    }
+    if (threadIdx.x == 0) {
+        if (to_f32) f_new = (double)(float)f_new;
         int32_t st = 0;
         if (*changed == 0) st = 2;                               // :128 isequal -> stuck
         else if (f_new < f_cur) st = 1;                          // :139 strict decrease
@@ -121,12 +135,20 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     const bool fused = fuse_objective && c.problem && !c.objective && !c.constraint;
     // built-in box constraint: projection is always feasible, so it can ride in the stream (:134-135)
     if (fused && c.box_on) DZO_TRY(box_clamp_async(s, c.n, c.dtype, c.x, c.box_lo, c.box_hi));
-    if (fused) DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
     const bool speculate = fused && c.speculative_tail != nullptr;
     if (speculate) {
-        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, s, (const double *)c.result(), (const int32_t *)c.flag(),
-                           c.f, c.dtype == DZO_F32 ? 1 : 0, c.status());
+        const double *partials = nullptr;
+        int64_t count = 0;
+        double scale = 1.0;
+        if (!problem_eval_partials_async(c.problem, s, c.x, &partials, &count, &scale)) {
+            partials = nullptr;
+            DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
+        }
+        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kBlock), 0, s, c.result(), partials, count, scale,
+                           (const int32_t *)c.flag(), c.f, c.dtype == DZO_F32 ? 1 : 0, c.status());
         DZO_HIP(hipGetLastError());
+    } else if (fused) {
+        DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
     }
     // one D->H copy brings back {f_new, misc, status, flag}
     DZO_HIP(hipMemcpyAsync(c.host, c.result(), sizeof(double) * 5, hipMemcpyDeviceToHost, s));

@@ -21,6 +21,9 @@ struct dzo_problem_s {
 namespace dzo {
 // Enqueue f(x) on `s`; result_dev[0] receives the value (fp64, rounded to T by the caller).
 int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev);
+// Objective partials only (no final sum); false if this objective needs its own finish kernel.
+bool problem_eval_partials_async(dzo_problem_s *p, hipStream_t s, const void *x, const double **partials,
+                                 int64_t *count, double *scale);
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).

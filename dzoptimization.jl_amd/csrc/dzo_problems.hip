@@ -453,6 +453,33 @@ int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x,
     return DZO_OK;
 }
 
+// Objective WITHOUT its final one-block sum: leaves per-block partials so that the caller's
+// decision kernel can do the sum itself (one launch fewer per trial).  Returns false for the
+// objectives whose finish is not a plain scaled sum.
+bool problem_eval_partials_async(dzo_problem_s *p, hipStream_t s, const void *x, const double **partials,
+                                 int64_t *count, double *scale) {
+    if (p->l2 != 0.0) return false;
+    const int64_t n = p->n;
+    if (p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN) {
+        DZO_TIMED("objective_rosenbrock_chain", s);
+        const int vecn = p->dtype == DZO_F64 ? 2 : 4;
+        const int grid = stream_grid(n, vecn * 2);
+        if (p->dtype == DZO_F64) hipLaunchKernelGGL(rosen_chain_eval_kernel<double>, dim3(grid), dim3(kBlock), 0, s, n, (const double *)x, p->scratch);
+        else hipLaunchKernelGGL(rosen_chain_eval_kernel<float>, dim3(grid), dim3(kBlock), 0, s, n, (const float *)x, p->scratch);
+        *partials = p->scratch; *count = grid; *scale = 1.0;
+        return true;
+    }
+    if (p->kind == DZO_PROBLEM_QUADRATIC) {
+        DZO_TIMED("objective_quadratic", s);
+        const int grid = (int)(n < 65535 ? n : 65535);
+        if (p->dtype == DZO_F64) hipLaunchKernelGGL((quadratic_kernel<double, false>), dim3(grid), dim3(kBlock), 0, s, n, (const double *)p->A, (const double *)x, (double *)nullptr, p->scratch);
+        else hipLaunchKernelGGL((quadratic_kernel<float, false>), dim3(grid), dim3(kBlock), 0, s, n, (const float *)p->A, (const float *)x, (float *)nullptr, p->scratch);
+        *partials = p->scratch; *count = n; *scale = 0.5;
+        return true;
+    }
+    return false;
+}
+
 int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev) {
     DZO_DISPATCH(p->dtype, DZO_TRY(eval_async_t<T>(p, s, (const T *)x, result_dev)));
     if (p->l2 != 0.0) {                                      // L2RegularizationWrapper (:231-232)
