@@ -19,6 +19,11 @@
  *   - one HIP stream per optimizer handle; calls on one handle must be serialised by the
  *     caller, different handles may be driven from different host threads (the reference's
  *     "independent optimizers" model, README.md:12).
+ *   - asynchrony: step functions return as soon as the host-side decisions of the step are
+ *     known; kernels that finish the step (delta_point, gradient, delta_gradient, rho) may still
+ *     be running on the handle's stream.  Every getter (get_ptr, get_rho, ...) and
+ *     dzo_synchronize() waits for them; touch an optimizer's device arrays from your own
+ *     streams only after one of those, or enqueue on the handle's stream (dzo_lbfgs_stream).
  *   - there is no CPU fallback: every entry point needs the HIP device selected by dzo_init.
  *
  * All citations are file:line in the reference snapshot (2025-09-05).
