@@ -556,3 +556,35 @@ def test_full_size_step_run_config3_invariants():
             assert np.array_equal(opt.delta_point_history[0].to_host(), x - x_old)
     assert opt.iteration_count == 120 and opt.history_count == m
     assert trials <= 2 * 120
+
+
+def test_handles_release_their_device_memory():
+    """Constructors allocate (rings, workspaces, streams); destroy must give everything back."""
+    import gc
+    import torch
+    n, m = 1_000_000, 10
+    x0 = orc.rosenbrock_chain_x0(n)
+
+    def cycle():
+        x = dzo.DeviceArray.from_host(x0)
+        p = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+        o = dzo.LBFGSOptimizer(None, p, None, x, 1.0, m)
+        for _ in range(3):
+            o.step()
+        b = dzo.BFGSOptimizer(dzo.Problem(dzo.ROSENBROCK_CHAIN, 256), None, dzo.DeviceArray.from_host(x0[:256]), 1.0)
+        b.step()
+        a = dzo.AdGDOptimizer(None, p, None, dzo.DeviceArray.from_host(x0), 0.1)
+        a.step()
+        bb = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, np.stack([x0[:64]] * 16), 1.0)
+        bb.step(2)
+        for h in (o, b, a, bb):
+            h.close()
+        del o, b, a, bb, p, x
+
+    cycle(); gc.collect(); dzo.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    gc.collect(); dzo.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"leaked {(free0 - free1) >> 20} MiB over 20 create/destroy cycles"
