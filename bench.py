@@ -199,6 +199,21 @@ def secondary_workload(args):
             dzo.update_inverse_hessian_(Hd, lam, dd, yd, scratch, g, dnext)
             times.append(time.perf_counter() - t1)
         upd = float(np.median(times[2:]))
+        # the MFMA form of the rank-2 update (no fused direction), same inputs
+        times_m = []
+        Hm = dzo.DeviceArray.from_host(np.eye(n))
+        dzo.profile_reset(); dzo.profile_enable(2)
+        for it in range(12):
+            d, y = rng.standard_normal(n), rng.standard_normal(n)
+            lam = 0.1 if d @ y > 0 else -0.1
+            dd, yd = dzo.DeviceArray.from_host(d), dzo.DeviceArray.from_host(y)
+            dzo.synchronize()
+            t1 = time.perf_counter()
+            dzo.update_inverse_hessian_mfma_(Hm, lam, dd, yd, scratch)
+            times_m.append(time.perf_counter() - t1)
+        dzo.profile_enable(0)
+        tabm = dzo.profile_table()
+        mfma_us = 1e3 * tabm["bfgs_update_mfma"][1] / tabm["bfgs_update_mfma"][0] if "bfgs_update_mfma" in tabm else None
         kern = {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in tab.items()}
         kbytes = {"bfgs_symv": n * n * 8, "bfgs_update": 2 * n * n * 8}
         for k, b in kbytes.items():
@@ -213,6 +228,9 @@ def secondary_workload(args):
                                "device": info["name"]},
                     "update_plus_direction": {"host_wall_us": round(upd * 1e6, 1), "algorithmic_bytes": 3 * n * n * 8,
                                               "algorithmic_GBps": round(3 * n * n * 8 / upd / 1e9, 1)},
+                    "mfma_update_variant": {"kernel_us": None if mfma_us is None else round(mfma_us, 2),
+                                            "algorithmic_GBps": None if mfma_us is None else round(2 * n * n * 8 / (mfma_us * 1e-6) / 1e9, 1),
+                                            "note": "v_mfma_f64_16x16x4_f64 rank-2 update of H only (2 n^2 T); compare with kernels.bfgs_update, which also produces the next direction"},
                     "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern.get(dom, {}).get("algorithmic_GBps"),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(kern.get(dom, {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4),

@@ -179,6 +179,7 @@ ABI = {
     "dzo_bfgs_convert_callbacks": [_vp, _i32, OBJECTIVE_FN, GRADIENT_FN, CONSTRAINT_FN, _vp, _P(_vp)],
     "dzo_bfgs_update": [_i64, _i32, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "dzo_symv": [_i64, _i32, _vp, _vp, _vp],
+    "dzo_bfgs_update_mfma": [_i64, _i32, _vp, _dbl, _vp, _vp, _vp],
     "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32],
     "dzo_bfgs_get_i": [_vp, _i32, _P(_i64)], "dzo_bfgs_get_s": [_vp, _i32, _P(_dbl)],
     "dzo_bfgs_get_ptr": [_vp, _i32, _P(_vp)],
@@ -772,6 +773,12 @@ def update_inverse_hessian_(H, step_length, d, dg, scratch, g=None, d_next=None)
     return H
 
 
+def update_inverse_hessian_mfma_(H, step_length, d, dg, scratch):
+    """``update_inverse_hessian!`` with the rank-2 term on MFMA (fp64, n % 16 == 0); see dzo.h."""
+    _check(lib().dzo_bfgs_update_mfma(d.size, _dt(d.dtype), H.ptr, step_length, d.ptr, dg.ptr, scratch.ptr))
+    return H
+
+
 def symv_(out, H, v):
     _check(lib().dzo_symv(v.size, _dt(v.dtype), H.ptr, v.ptr, out.ptr))
     return out
@@ -839,6 +846,6 @@ def step_(opt):
 __all__ = [
     "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
     "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
-    "update_inverse_hessian_", "symv_", "init", "build", "lib", "device_info", "synchronize",
+    "update_inverse_hessian_", "update_inverse_hessian_mfma_", "symv_", "init", "build", "lib", "device_info", "synchronize",
     "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",
 ]

@@ -19,35 +19,42 @@
 // HBM, not by the 2 fma per element; the VALU form below also keeps the reference's rounding
 // order, which the MFMA accumulate order would not.  See DESIGN.md.
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 #include "dzo_optcore.h"
 
 namespace dzo {
 
-constexpr int kColsPerBlock = 4;
+constexpr int kColsPerBlock = 4;     // default column group per block (symv / update)
+
+static int bfgs_cols_knob() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DZO_TUNE_BFGS_COLS"); v = e ? atoi(e) : kColsPerBlock; if (v != 8 && v != 16) v = 4; }
+    return v;
+}
 
 // t_j = H[:,j] . v for a group of columns per block
 // With `dvec` non-null the kernel also emits, per column group, the partial sums of
 // overlap = d.v (:873) and v.t (:876) over its own columns (v = delta_gradient, t = H*v), so the
 // update kernel can form the scalars itself and the single-block scalars launch disappears.
-template <typename T, bool VEC>
+template <typename T, bool VEC, int C>
 __global__ __launch_bounds__(kBlock) void symv_kernel(int64_t n, const T *__restrict__ H, const T *__restrict__ v,
                                                       T *__restrict__ out, const T *__restrict__ dvec,
                                                       double *__restrict__ part_ov, double *__restrict__ part_vt) {
     constexpr int N = VEC ? Vec16<T>::N : 1;
     __shared__ double lds[kWaves];
-    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    const int64_t groups = (n + C - 1) / C;
     for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const int64_t j0 = grp * kColsPerBlock;
-        double acc[kColsPerBlock];
+        const int64_t j0 = grp * C;
+        double acc[C];
 #pragma unroll
-        for (int c = 0; c < kColsPerBlock; ++c) acc[c] = 0;
+        for (int c = 0; c < C; ++c) acc[c] = 0;
         for (int64_t i = (int64_t)threadIdx.x * N; i < n; i += (int64_t)kBlock * N) {
             T vv[N];
             if constexpr (VEC) load16(v + i, vv); else vv[0] = v[i];
 #pragma unroll
-            for (int c = 0; c < kColsPerBlock; ++c) {
+            for (int c = 0; c < C; ++c) {
                 if (j0 + c < n) {
                     T hv[N];
                     if constexpr (VEC) load16(H + (j0 + c) * n + i, hv); else hv[0] = H[(j0 + c) * n + i];
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void symv_kernel(int64_t n, const T *__rest
         }
         double pov = 0, pvt = 0;
 #pragma unroll
-        for (int c = 0; c < kColsPerBlock; ++c) {
+        for (int c = 0; c < C; ++c) {
             const double r = block_sum(acc[c], lds);
             if (threadIdx.x == 0 && j0 + c < n) {
                 const T tj = (T)r;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void bfgs_scalars_kernel(int64_t n, T *__re
 // overlap and dg.t written by symv_kernel (fixed order, identical in every block), forms
 // inv = 1/overlap (:874) and delta (:876) itself, and scales d on the fly -- the same rounded
 // values the reference stores before using them.
-template <typename T, bool VEC, bool DIRECTION, bool FUSED>
+template <typename T, bool VEC, bool DIRECTION, bool FUSED, int C>
 __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__restrict__ H, const T *__restrict__ dp,
                                                              const T *__restrict__ t, const double *__restrict__ scalars,
                                                              const T *__restrict__ g, T *__restrict__ d_next,
@@ -121,13 +128,13 @@ __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__res
     } else {
         delta = (T)scalars[1];
     }
-    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    const int64_t groups = (n + C - 1) / C;
     for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const int64_t j0 = grp * kColsPerBlock;
-        T sj[kColsPerBlock], tj[kColsPerBlock];
-        double acc[kColsPerBlock];
+        const int64_t j0 = grp * C;
+        T sj[C], tj[C];
+        double acc[C];
 #pragma unroll
-        for (int c = 0; c < kColsPerBlock; ++c) {
+        for (int c = 0; c < C; ++c) {
             const int64_t j = j0 + c < n ? j0 + c : n - 1;
             sj[c] = FUSED ? dp[j] * inv : dp[j];             // :879 (:874 applied on the fly when FUSED)
             tj[c] = t[j];                                    // :880
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__res
                 for (int q = 0; q < N; ++q) di[q] = di[q] * inv;
             }
 #pragma unroll
-            for (int c = 0; c < kColsPerBlock; ++c) {
+            for (int c = 0; c < C; ++c) {
                 if (j0 + c < n) {
                     T *col = H + (j0 + c) * n + i;
                     T hv[N];
@@ -159,10 +166,65 @@ __global__ __launch_bounds__(kBlock) void bfgs_update_kernel(int64_t n, T *__res
         }
         if (DIRECTION) {
 #pragma unroll
-            for (int c = 0; c < kColsPerBlock; ++c) {
+            for (int c = 0; c < C; ++c) {
                 const double r = block_sum(acc[c], lds);
                 if (threadIdx.x == 0 && j0 + c < n) d_next[j0 + c] = (T)r;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA form of the rank-2 update (fp64, n % 16 == 0): H += U V^T with U = [d' t 0 0] and
+// V = [delta*d'-t, -d', 0, 0], one v_mfma_f64_16x16x4_f64 per 16x16 tile (K = 2 padded to 4).
+// The tile is held TRANSPOSED in the accumulator (C/D column index = lane & 15 runs along the
+// memory-contiguous row index of the column-major H), so a load instruction touches four 128-B
+// column segments.  Kept as a measured alternative, off by default.  Measured at n = 4096
+// (profiles/r01_bench_bfgs_dense.json): 44 us for the 2 n^2 T of the H update alone (6.1 TB/s out
+// of the Infinity Cache) against 53 us for the VALU kernel, which in the same pass also forms the
+// next direction H_new*g.  The MFMA form cannot fuse that direction without cross-lane sums, so
+// step! would need a second symv (+28 us): 101 us against 82 us per update.  It also rounds
+// differently from the reference's expression (:882-884), and H_ij / H_ji are no longer
+// bit-identical.  See DESIGN.md section 4.
+// ---------------------------------------------------------------------------------------------
+typedef double mfma_v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBlock) void bfgs_update_mfma_kernel(int64_t n, double *__restrict__ H,
+                                                                  const double *__restrict__ dp,
+                                                                  const double *__restrict__ t,
+                                                                  const double *__restrict__ scalars) {
+    const double delta = scalars[1];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+    const int64_t tiles = n / 16;                       // per dimension
+    const int il = lane & 15, kq = lane >> 4;
+    // a wave owns a strip of 16 rows (i-tile) and walks the column tiles 4 at a time
+    for (int64_t job = wave; job < tiles * ((tiles + 3) / 4); job += nwaves) {
+        const int64_t it = job % tiles, jq = job / tiles;
+        const int64_t i0 = it * 16;
+        // B[k][col = il] = U[i0 + il][k]
+        const double di = dp[i0 + il], ti = t[i0 + il];
+        const double bval = kq == 0 ? di : (kq == 1 ? ti : 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t jt = jq * 4 + u;
+            if (jt >= tiles) break;
+            const int64_t j0 = jt * 16;
+            // A[row = il][k] = V[j0 + il][k]
+            const double dj = dp[j0 + il], tj = t[j0 + il];
+            const double aval = kq == 0 ? (delta * dj - tj) : (kq == 1 ? -dj : 0.0);
+            mfma_v4f64 c;
+            double *base = H + (i0 + il) + (j0 + kq) * n;      // D[row = kq + 4r][col = il] = H[i0+il][j0+kq+4r]
+            c.x = base[0];
+            c.y = base[4 * n];
+            c.z = base[8 * n];
+            c.w = base[12 * n];
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, c, 0, 0, 0);
+            base[0] = c.x;
+            base[4 * n] = c.y;
+            base[8 * n] = c.z;
+            base[12 * n] = c.w;
         }
     }
 }
@@ -210,13 +272,23 @@ __global__ __launch_bounds__(kBlock) void bfgs_move_kernel(int64_t n, T *__restr
 
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// run `body` with the constexpr column-group width CC selected by DZO_TUNE_BFGS_COLS
+#define DZO_BFGS_COLS(body)                                                     \
+    switch (bfgs_cols_knob()) {                                                 \
+    case 16: { constexpr int CC = 16; body; } break;                            \
+    case 8: { constexpr int CC = 8; body; } break;                              \
+    default: { constexpr int CC = 4; body; } break;                             \
+    }
+
 template <typename T> void launch_symv(hipStream_t s, int64_t n, const T *H, const T *v, T *out) {
     DZO_TIMED("bfgs_symv", s);
     const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(v);
-    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    const int cols = bfgs_cols_knob();
+    const int64_t groups = (n + cols - 1) / cols;
     const int grid = (int)(groups < 65535 ? groups : 65535);
-    if (vec) hipLaunchKernelGGL((symv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out, (const T *)nullptr, (double *)nullptr, (double *)nullptr);
-    else hipLaunchKernelGGL((symv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out, (const T *)nullptr, (double *)nullptr, (double *)nullptr);
+    DZO_BFGS_COLS(
+        if (vec) hipLaunchKernelGGL((symv_kernel<T, true, CC>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out, (const T *)nullptr, (double *)nullptr, (double *)nullptr);
+        else hipLaunchKernelGGL((symv_kernel<T, false, CC>), dim3(grid), dim3(kBlock), 0, s, n, H, v, out, (const T *)nullptr, (double *)nullptr, (double *)nullptr));
 }
 
 // update_inverse_hessian! + next direction in TWO launches (step! path): the scalars ride on
@@ -226,18 +298,21 @@ template <typename T>
 void launch_bfgs_update_fused(hipStream_t s, int64_t n, T *H, T lambda, const T *d, const T *dg, T *scratch, const T *g,
                               T *d_next, double *part) {
     const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(d) && al16(dg) && al16(scratch) && al16(g);
-    const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+    const int cols = bfgs_cols_knob();
+    const int64_t groups = (n + cols - 1) / cols;
     const int grid = (int)(groups < 65535 ? groups : 65535);
     double *part_ov = part, *part_vt = part + groups;
     {
         DZO_TIMED("bfgs_symv", s);
-        if (vec) hipLaunchKernelGGL((symv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)H, dg, scratch, d, part_ov, part_vt);
-        else hipLaunchKernelGGL((symv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)H, dg, scratch, d, part_ov, part_vt);
+        DZO_BFGS_COLS(
+            if (vec) hipLaunchKernelGGL((symv_kernel<T, true, CC>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)H, dg, scratch, d, part_ov, part_vt);
+            else hipLaunchKernelGGL((symv_kernel<T, false, CC>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)H, dg, scratch, d, part_ov, part_vt));
     }
     {
         DZO_TIMED("bfgs_update", s);
-        if (vec) hipLaunchKernelGGL((bfgs_update_kernel<T, true, true, true>), dim3(grid), dim3(kBlock), 0, s, n, H, d, (const T *)scratch, (const double *)nullptr, g, d_next, (const double *)part_ov, (const double *)part_vt, (int)groups, lambda);
-        else hipLaunchKernelGGL((bfgs_update_kernel<T, false, true, true>), dim3(grid), dim3(kBlock), 0, s, n, H, d, (const T *)scratch, (const double *)nullptr, g, d_next, (const double *)part_ov, (const double *)part_vt, (int)groups, lambda);
+        DZO_BFGS_COLS(
+            if (vec) hipLaunchKernelGGL((bfgs_update_kernel<T, true, true, true, CC>), dim3(grid), dim3(kBlock), 0, s, n, H, d, (const T *)scratch, (const double *)nullptr, g, d_next, (const double *)part_ov, (const double *)part_vt, (int)groups, lambda);
+            else hipLaunchKernelGGL((bfgs_update_kernel<T, false, true, true, CC>), dim3(grid), dim3(kBlock), 0, s, n, H, d, (const T *)scratch, (const double *)nullptr, g, d_next, (const double *)part_ov, (const double *)part_vt, (int)groups, lambda));
     }
 }
 
@@ -254,12 +329,14 @@ void launch_bfgs_update(hipStream_t s, int64_t n, T *H, T lambda, T *d, const T 
     {
         DZO_TIMED("bfgs_update", s);
         const bool vec = (n % Vec16<T>::N == 0) && al16(H) && al16(d) && al16(scratch) && (!g || al16(g));
-        const int64_t groups = (n + kColsPerBlock - 1) / kColsPerBlock;
+        const int cols = bfgs_cols_knob();
+        const int64_t groups = (n + cols - 1) / cols;
         const int grid = (int)(groups < 65535 ? groups : 65535);
         const bool dir = g != nullptr && d_next != nullptr;
-#define L(V, D) hipLaunchKernelGGL((bfgs_update_kernel<T, V, D, false>), dim3(grid), dim3(kBlock), 0, s, n, H, (const T *)d, (const T *)scratch, (const double *)scalars_dev, g, d_next, (const double *)nullptr, (const double *)nullptr, 0, (T)0)
-        if (vec) { if (dir) L(true, true); else L(true, false); }
-        else { if (dir) L(false, true); else L(false, false); }
+#define L(V, D) hipLaunchKernelGGL((bfgs_update_kernel<T, V, D, false, CC>), dim3(grid), dim3(kBlock), 0, s, n, H, (const T *)d, (const T *)scratch, (const double *)scalars_dev, g, d_next, (const double *)nullptr, (const double *)nullptr, 0, (T)0)
+        DZO_BFGS_COLS(
+            if (vec) { if (dir) L(true, true); else L(true, false); }
+            else { if (dir) L(false, true); else L(false, false); })
 #undef L
     }
 }
@@ -832,6 +909,34 @@ int32_t dzo_bfgs_update(int64_t n, int32_t dtype, void *H_dev, double step_lengt
     hipStream_t s = ctx().stream;
     DZO_DISPATCH(dtype, launch_bfgs_update<T>(s, n, (T *)H_dev, (T)step_length, (T *)d_dev, (const T *)dg_dev,
                                               (T *)scratch_dev, (const T *)g_dev, (T *)d_next_dev, ctx().scratch + kMaxPartialBlocks));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(s));
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_update_mfma(int64_t n, int32_t dtype, void *H_dev, double step_length, void *d_dev, const void *dg_dev,
+                             void *scratch_dev) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(n >= 16 && H_dev && d_dev && dg_dev && scratch_dev, DZO_ERR_INVALID, "bad argument");
+    DZO_REQUIRE(dtype == DZO_F64 && n % 16 == 0, DZO_ERR_UNSUPPORTED,
+                "the MFMA update is fp64 only (v_mfma_f64_16x16x4_f64) and needs n %% 16 == 0");
+    hipStream_t s = ctx().stream;
+    double *scal = ctx().scratch + kMaxPartialBlocks;
+    launch_symv<double>(s, n, (const double *)H_dev, (const double *)dg_dev, (double *)scratch_dev);       // :875
+    {
+        DZO_TIMED("bfgs_scalars", s);
+        hipLaunchKernelGGL(bfgs_scalars_kernel<double>, dim3(1), dim3(kBlock), 0, s, n, (double *)d_dev,
+                           (const double *)dg_dev, (const double *)scratch_dev, step_length, scal);        // :873-876
+    }
+    {
+        DZO_TIMED("bfgs_update_mfma", s);
+        const int64_t tiles = n / 16;
+        const int64_t jobs = tiles * ((tiles + 3) / 4);
+        int64_t blocks = (jobs + kWaves - 1) / kWaves;
+        if (blocks > (int64_t)ctx().cus * 16) blocks = (int64_t)ctx().cus * 16;
+        hipLaunchKernelGGL(bfgs_update_mfma_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, n, (double *)H_dev,
+                           (const double *)d_dev, (const double *)scratch_dev, (const double *)scal);
+    }
     DZO_HIP(hipGetLastError());
     DZO_HIP(hipStreamSynchronize(s));
     return DZO_OK;

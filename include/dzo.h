@@ -283,6 +283,12 @@ int32_t dzo_bfgs_step(dzo_bfgs_t opt);
 int32_t dzo_bfgs_update(int64_t n, int32_t dtype, void *H_dev, double step_length, void *d_dev,
                         const void *dg_dev, void *scratch_dev, const void *g_dev,
                         void *d_next_dev);
+/* The same update with the rank-2 term on the matrix cores (v_mfma_f64_16x16x4_f64, K = 2 padded
+ * to 4): fp64, n % 16 == 0, H only (no fused direction).  A measured alternative, NOT the default:
+ * the kernel is HBM-bound either way, rounding follows an fma chain instead of :882-884 and H loses
+ * bit-exact symmetry. */
+int32_t dzo_bfgs_update_mfma(int64_t n, int32_t dtype, void *H_dev, double step_length, void *d_dev,
+                             const void *dg_dev, void *scratch_dev);
 /* out = H*v for symmetric H (mul!, :875,:958-960) */
 int32_t dzo_symv(int64_t n, int32_t dtype, const void *H_dev, const void *v_dev, void *out_dev);
 /* quadratic_line_search(functor, f0, t0) as defined in DESIGN.md from

@@ -297,3 +297,27 @@ def test_legacy_gradient_descent_matches_oracle():
         assert rel(opt.next_step_direction.to_host(), ref.next_step_direction) <= 1e-9
     with pytest.raises(dzo.DzoError):
         dzo._check(dzo.lib().dzo_bfgs_step(opt.h))          # a GD handle is not a BFGS handle
+
+
+# ------------------------------------------------------------------------------ MFMA variant of K9
+@pytest.mark.parametrize("n", [16, 64, 256, 1024])
+def test_mfma_update_matches_oracle_within_rounding(n):
+    """v_mfma_f64_16x16x4_f64 form of the rank-2 update: same mathematics, fma-chain rounding;
+    asymmetric tiles make a deliberately NON-symmetric V to catch a row/column swap."""
+    rng = np.random.default_rng(n)
+    H0 = _spd(n, n)
+    d, y = rng.standard_normal(n), rng.standard_normal(n)
+    lam = -0.37 if d @ y < 0 else 0.37
+    H_ref, d_ref = np.asfortranarray(H0.copy()), d.copy()
+    t_ref = orc.bfgs_update(H_ref, lam, d_ref, y.copy())
+    Hd, dd, yd = (dzo.DeviceArray.from_host(a) for a in (H0, d, y))
+    scratch = dzo.DeviceArray(n)
+    dzo.update_inverse_hessian_mfma_(Hd, lam, dd, yd, scratch)
+    H_gpu = Hd.to_host()
+    assert rel(H_gpu, np.ascontiguousarray(H_ref)) <= 1e-13
+    assert rel(H_gpu, H_gpu.T) <= 1e-15                       # symmetric to rounding, not bit-exact
+    assert rel(dd.to_host(), d_ref) <= 1e-14 and rel(scratch.to_host(), t_ref) <= 1e-13
+    assert np.allclose(H_gpu @ y, lam * d, rtol=1e-9, atol=1e-11)      # secant equation
+    with pytest.raises(dzo.DzoError):
+        dzo.update_inverse_hessian_mfma_(dzo.DeviceArray.from_host(np.eye(24)), 1.0, dzo.DeviceArray(24),
+                                         dzo.DeviceArray(24), dzo.DeviceArray(24))         # n % 16 != 0
