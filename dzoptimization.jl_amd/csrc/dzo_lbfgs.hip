@@ -21,6 +21,7 @@
 //          then the rmul! scale, then the second fma chain).  Moves (4k+3)*n elements --
 //          the algorithmic floor of SURVEY.md 8(d) plus one re-read of g.
 #include <cstdlib>
+#include <map>
 #include <type_traits>
 #include <utility>
 
@@ -62,12 +63,13 @@ struct dzo_lbfgs_s {
     bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
     int gram_variant = 1;           // 1 = lane-distributed accumulators
     int gram_peel = 1;              // predicate-free path for full tiles
+    int gram_fresh_plain = 1, gram_skip0 = 1, combine_fresh_plain = 1;
     bool rho_pending = false;       // rho partials of the newest pair await their final sum
     int tail_grid = 0;              // grid of the last speculative tail (its partial count)
     int rho_pending_count = 0, rho_pending_slot = 0;
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
-    int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 8;   // tuning knobs (DZO_TUNE_* env, dev only)
+    int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 0, gram_bpc = 0;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
     int spare() const { return (newest + 1) % (m + 1); }
@@ -237,6 +239,8 @@ template <typename T> struct GramParams {
     const T *yp;
     int k;
     int peel;                   // 1: full tiles run the predicate-free path
+    int fresh_plain;            // 1: g / pivot pair (written by the previous kernel) with plain loads
+    int pivot_first;            // 1: pivot == logical pair 0 -> pair 0 is served from the pivot registers
     const T *s[kMaxHistory];    // logical pair -> slot base (wave-uniform index -> scalar loads)
     const T *y[kMaxHistory];
     double *partials;           // [kGramValues * k][gridDim.x]
@@ -318,9 +322,15 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
             ok[u] = FULL || vi < nvec;
             if (ok[u]) {
-                L::load_nt(p.g + vi * N, gv[u]);
-                L::load_nt(sp + vi * N, spv[u]);
-                L::load_nt(yp + vi * N, ypv[u]);
+                if (p.fresh_plain) {
+                    L::load(p.g + vi * N, gv[u]);
+                    L::load(sp + vi * N, spv[u]);
+                    L::load(yp + vi * N, ypv[u]);
+                } else {
+                    L::load_nt(p.g + vi * N, gv[u]);
+                    L::load_nt(sp + vi * N, spv[u]);
+                    L::load_nt(yp + vi * N, ypv[u]);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) { gv[u][j] = 0; spv[u][j] = 0; ypv[u][j] = 0; }
@@ -366,7 +376,16 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
                 for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
             }
         };
-        if (k > 0) fetch(0, sA, yA);
+        if (k > 0) {
+            if (p.pivot_first) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { sA[u][j] = spv[u][j]; yA[u][j] = ypv[u][j]; }
+            } else {
+                fetch(0, sA, yA);
+            }
+        }
         for (int i = 0; i < k; i += 2) {
             if (i + 1 < k) fetch(i + 1, sB, yB);
             consume(i, sA, yA);
@@ -376,10 +395,13 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
     };
     const int64_t tile_v = (int64_t)kBlock * U;
     const int64_t full_tiles = nvec / tile_v;
+    // ragged last tile: taken FIRST, by the last block (which has the fewest full tiles).  Run
+    // after the full tiles it was a slow predicated tile at the very end of one block's work:
+    // the whole launch waited ~50 us for it (the Gram pass measured 579 us in step! against
+    // 526 us for the same code without a ragged tile in tools/grambench.hip).
+    if (full_tiles * tile_v < nvec && blockIdx.x == gridDim.x - 1) do_tile(full_tiles * tile_v, std::false_type{});
     if (p.peel) { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::true_type{}); }
     else { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::false_type{}); }
-    // ragged last tile: the block that would have taken tile index `full_tiles`
-    if (full_tiles * tile_v < nvec && (int64_t)blockIdx.x == full_tiles % gridDim.x) do_tile(full_tiles * tile_v, std::false_type{});
     (void)nthreads;
     // scalar tail (n not a multiple of the vector width): lane i of wave 0 in block 0 owns pair i
     if (VEC && blockIdx.x == 0 && wave == 0 && lane < k) {
@@ -519,6 +541,7 @@ template <typename T> struct CombineParams {
     const T *g;
     T *d;
     int k;
+    int fresh_plain;            // 1: newest pair (written by the previous step's tail) with plain loads
     const double *alpha, *coef, *scale;
     const T *s[kMaxHistory];    // logical pair -> slot base
     const T *y[kMaxHistory];
@@ -560,7 +583,10 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
             T v[U][N];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) L::load_nt(yi + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                if (ok[u]) {
+                    if (p.fresh_plain && i == 0) L::load(yi + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                    else L::load_nt(yi + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -579,7 +605,10 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
             T v[U][N];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) L::load_nt(si + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                if (ok[u]) {
+                    if (p.fresh_plain && i == 0) L::load(si + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                    else L::load_nt(si + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -727,6 +756,17 @@ template <typename T> static int32_t direction_chain(dzo_lbfgs_s *o) {
 }
 
 // ---------------------------------------------------------------------------- GRAM driver
+// blocks of `kernel` (kBlock threads, static LDS only) that fit on one CU at once; cached
+static int resident_blocks(const void *kernel) {
+    static std::map<const void *, int> cache;
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+    cache[kernel] = nb;
+    return nb;
+}
+
 static int tune(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -758,6 +798,8 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     for (int i = 0; i < k; ++i) { gp.s[i] = o->s_slot<T>(o->slot_of(i)); gp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     gp.partials = o->gram_partials;
     gp.peel = o->gram_peel;
+    gp.fresh_plain = o->gram_fresh_plain;
+    gp.pivot_first = (o->gram_skip0 && pivot == 0) ? 1 : 0;
     const bool vec = al16(c.g);
     if (o->gram_variant == 1) {
         // lane-distributed accumulators: one launch shape for every k (the pair-per-wave
@@ -770,18 +812,22 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         while (gu > 1 && (c.n + vec_elems * gu - 1) / (vec_elems * gu) < (int64_t)ctx().cus * 4) gu >>= 1;
         int64_t per_block = vec_elems * gu;
         int64_t blocks = (c.n + per_block - 1) / per_block;
-        if (blocks > o->gram_grid) blocks = o->gram_grid;
-        const int lgrid = (int)(blocks < 1 ? 1 : blocks);
-        {
-            DZO_TIMED("lbfgs_gram_pass", s);
+        // grid = the blocks that are resident at once (occupancy x CUs): every block then walks
+        // the same number of tiles (+-1) and there is no second, partially filled round of
+        // blocks.  Measured at n = 1e7, k = 20: 494 us against 527 us with 8 blocks per CU.
 #define GL(UU)                                                                                                  \
     do {                                                                                                        \
-        if (vec) hipLaunchKernelGGL((gram_pass_lanes_kernel<T, true, UU>), dim3(lgrid), dim3(kBlock), 0, s, gp); \
-        else hipLaunchKernelGGL((gram_pass_lanes_kernel<T, false, UU>), dim3(lgrid), dim3(kBlock), 0, s, gp);    \
+        auto kern = vec ? gram_pass_lanes_kernel<T, true, UU> : gram_pass_lanes_kernel<T, false, UU>;           \
+        int64_t cap = o->gram_grid;                                                                             \
+        if (o->gram_bpc <= 0) { const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern); if (res < cap) cap = res; } \
+        if (blocks > cap) blocks = cap;                                                                         \
+        lgrid = (int)(blocks < 1 ? 1 : blocks);                                                                 \
+        DZO_TIMED("lbfgs_gram_pass", s);                                                                        \
+        hipLaunchKernelGGL(kern, dim3(lgrid), dim3(kBlock), 0, s, gp);                                          \
     } while (0)
-            if (gu == 1) GL(1); else if (gu == 2) GL(2); else if (gu == 8) GL(8); else GL(4);
+        int lgrid = 1;
+        if (gu == 1) GL(1); else if (gu == 2) GL(2); else if (gu == 8) GL(8); else GL(4);
 #undef GL
-        }
         const int pcount = lgrid;
         double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
         {
@@ -816,21 +862,22 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     cp.n = c.n; cp.g = (const T *)c.g; cp.d = (T *)o->d; cp.k = k;
     for (int i = 0; i < k; ++i) { cp.s[i] = o->s_slot<T>(o->slot_of(i)); cp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     cp.alpha = o->alpha; cp.coef = o->coef; cp.scale = o->scale;
+    cp.fresh_plain = o->combine_fresh_plain;
     const bool vec = al16(c.g);
     int u = o->combine_u;
     while (u > 1 && (c.n + (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u - 1) / ((int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u) < (int64_t)ctx().cus * 4) u >>= 1;
     int64_t per_block = (int64_t)kBlock * (vec ? Vec16<T>::N : 1) * u;
     int64_t blocks = (c.n + per_block - 1) / per_block;
-    const int64_t cap = (int64_t)ctx().cus * o->combine_blocks_per_cu;
-    if (blocks > cap) blocks = cap;
-    const int grid = (int)(blocks < 1 ? 1 : blocks);
     {
         DZO_TIMED("lbfgs_combine", s);
 #define CB(UU)                                                                                                   \
     do {                                                                                                         \
-        if (vec && o->combine_nts) hipLaunchKernelGGL((combine_kernel<T, true, UU, true>), dim3(grid), dim3(kBlock), 0, s, cp);  \
-        else if (vec) hipLaunchKernelGGL((combine_kernel<T, true, UU, false>), dim3(grid), dim3(kBlock), 0, s, cp);  \
-        else hipLaunchKernelGGL((combine_kernel<T, false, UU, false>), dim3(grid), dim3(kBlock), 0, s, cp);      \
+        auto kern = (vec && o->combine_nts) ? combine_kernel<T, true, UU, true>                                  \
+                    : vec ? combine_kernel<T, true, UU, false> : combine_kernel<T, false, UU, false>;            \
+        const int bpc = o->combine_blocks_per_cu > 0 ? o->combine_blocks_per_cu : resident_blocks((const void *)kern); \
+        const int64_t cap = (int64_t)ctx().cus * bpc;                                                            \
+        if (blocks > cap) blocks = cap;                                                                          \
+        hipLaunchKernelGGL(kern, dim3((int)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0, s, cp);                 \
     } while (0)
         if (u == 1) CB(1); else if (u == 4) CB(4); else CB(2);
 #undef CB
@@ -1016,11 +1063,15 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
     o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
     o->gram_peel = tune("DZO_TUNE_GRAM_PEEL", 1);
+    o->gram_fresh_plain = tune("DZO_TUNE_GRAM_FRESH_PLAIN", 1);
+    o->gram_skip0 = tune("DZO_TUNE_GRAM_SKIP0", 1);
+    o->combine_fresh_plain = tune("DZO_TUNE_COMBINE_FRESH_PLAIN", 1);
     o->fused_post = tune("DZO_TUNE_FUSED_POST", 1) != 0;
     o->combine_nts = tune("DZO_TUNE_COMBINE_NTS", 1) != 0;
     o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
-    o->combine_blocks_per_cu = tune("DZO_TUNE_COMBINE_BPC", 8);
-    o->gram_grid = ctx().cus * tune("DZO_TUNE_GRAM_BPC", 8);
+    o->combine_blocks_per_cu = tune("DZO_TUNE_COMBINE_BPC", 0);   // 0: resident blocks
+    o->gram_bpc = tune("DZO_TUNE_GRAM_BPC", 0);                 // 0: as many blocks as are resident at once
+    o->gram_grid = ctx().cus * (o->gram_bpc > 0 ? o->gram_bpc : 8);   // upper bound (sizes the partials)
     if (o->gram_grid > kMaxPartialBlocks) o->gram_grid = kMaxPartialBlocks;
     {
         const int64_t tile_v = 64 * (int64_t)o->gram_u;
