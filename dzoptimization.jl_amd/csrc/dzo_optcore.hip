@@ -64,8 +64,8 @@ __global__ __launch_bounds__(kBlock) void trial_kernel(int64_t n, T *x, T *__res
 // fewer per trial) and publishes f_new in result[0].
 __global__ __launch_bounds__(kBlock) void decide_kernel(double *__restrict__ result, const double *__restrict__ partials,
                                                         int64_t count, double scale,
-                                                        const int32_t *__restrict__ changed, double f_cur, int to_f32,
-                                                        int32_t *__restrict__ status) {
+                                                        int32_t *__restrict__ changed, double f_cur, int to_f32,
+                                                        int32_t *__restrict__ status, double *__restrict__ host_out) {
     __shared__ double lds[kWaves];
     double f_new;
     if (partials) {
@@ -77,11 +77,19 @@ __global__ __launch_bounds__(kBlock) void decide_kernel(double *__restrict__ res
         f_new = result[0];
     }
     if (threadIdx.x == 0) {
+        const double f_raw = f_new;
         if (to_f32) f_new = (double)(float)f_new;
+        const int32_t ch = *changed;
         int32_t st = 0;
-        if (*changed == 0) st = 2;                               // :128 isequal -> stuck
+        if (ch == 0) st = 2;                                     // :128 isequal -> stuck
         else if (f_new < f_cur) st = 1;                          // :139 strict decrease
         *status = st;
+        *changed = 0;                                            // armed for the next trial (saves a memset launch)
+        // outcome straight into the pinned host mirror: no D->H blit kernel on the critical path
+        host_out[0] = f_raw;
+        reinterpret_cast<int32_t *>(host_out + 3)[0] = st;
+        reinterpret_cast<int32_t *>(host_out + 4)[0] = ch;
+        __threadfence_system();
     }
 }
 
@@ -103,7 +111,8 @@ int32_t core_alloc(OptCore &c) {
     DZO_HIP(hipMalloc((void **)&c.ws, sizeof(double) * (2 * kMaxPartialBlocks + 16)));
     DZO_HIP(hipMemset(c.ws, 0, sizeof(double) * (2 * kMaxPartialBlocks + 16)));
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
-    DZO_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * 8, hipHostMallocDefault));
+    DZO_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    DZO_HIP(hipHostGetDevicePointer((void **)&c.host_dev, c.host, 0));
     DZO_HIP(hipEventCreateWithFlags(&c.decided, hipEventDisableTiming));
     return DZO_OK;
 }
@@ -127,7 +136,8 @@ int32_t core_begin_search(OptCore &c) {
 int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, int32_t *changed, double *f_new,
                    bool *f_valid) {
     hipStream_t s = c.stream;
-    DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
+    if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));   // decide_kernel re-arms it itself
+    c.flag_armed = false;
     const bool first = c.search_open;
     DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)c.dx, (const T *)dir, (T)t, first, c.flag()));
     DZO_HIP(hipGetLastError());
@@ -145,18 +155,16 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
             DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
         }
         hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kBlock), 0, s, c.result(), partials, count, scale,
-                           (const int32_t *)c.flag(), c.f, c.dtype == DZO_F32 ? 1 : 0, c.status());
+                           c.flag(), c.f, c.dtype == DZO_F32 ? 1 : 0, c.status(), c.host_dev);
         DZO_HIP(hipGetLastError());
-    } else if (fused) {
-        DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
-    }
-    // one D->H copy brings back {f_new, misc, status, flag}
-    DZO_HIP(hipMemcpyAsync(c.host, c.result(), sizeof(double) * 5, hipMemcpyDeviceToHost, s));
-    if (speculate) {
+        c.flag_armed = true;
         DZO_HIP(hipEventRecord(c.decided, s));
         DZO_TRY(c.speculative_tail(c.speculative_self, c.status()));   // gated kernels, enqueued blind
         DZO_HIP(hipEventSynchronize(c.decided));
     } else {
+        if (fused) DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
+        // one D->H copy brings back {f_new, misc, status, flag}
+        DZO_HIP(hipMemcpyAsync(c.host, c.result(), sizeof(double) * 5, hipMemcpyDeviceToHost, s));
         DZO_HIP(hipStreamSynchronize(s));
     }
     *changed = reinterpret_cast<int32_t *>(c.host + 4)[0] != 0;
