@@ -33,6 +33,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 F32, F64 = 0, 1
 ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE = 0, 1, 2, 3
 TWOLOOP_CHAIN, TWOLOOP_GRAM = 0, 1
+LINE_SEARCH_BACKTRACKING, LINE_SEARCH_WOLFE = 0, 1
 STEP_NULL, STEP_GRADIENT_DESCENT, STEP_BFGS = 0, 1, 2
 
 _ERR = {1: "invalid argument", 2: "HIP runtime error", 3: "reference @assert", 4: "out of memory",
@@ -156,7 +157,9 @@ ABI = {
     "dzo_lbfgs_create_problem": [_vp, _i32, _vp, _dbl, _P(_vp)], "dzo_lbfgs_destroy": [_vp],
     "dzo_lbfgs_set_callbacks": [_vp, CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp],
     "dzo_lbfgs_set_problem": [_vp, _vp], "dzo_lbfgs_set_two_loop_mode": [_vp, _i32],
-    "dzo_lbfgs_set_max_halvings": [_vp, _i64], "dzo_lbfgs_step": [_vp], "dzo_lbfgs_direction": [_vp],
+    "dzo_lbfgs_set_max_halvings": [_vp, _i64],
+    "dzo_lbfgs_set_safeguards": [_vp, _i32, _i32], "dzo_lbfgs_set_line_search": [_vp, _i32, _dbl, _dbl, _i32],
+    "dzo_lbfgs_step": [_vp], "dzo_lbfgs_direction": [_vp],
     "dzo_lbfgs_begin_search": [_vp], "dzo_lbfgs_trial": [_vp, _dbl, _P(_i32)],
     "dzo_lbfgs_accept": [_vp, _dbl], "dzo_lbfgs_reject": [_vp], "dzo_lbfgs_pre_gradient": [_vp],
     "dzo_lbfgs_post_gradient": [_vp], "dzo_lbfgs_get_i": [_vp, _i32, _P(_i64)],
@@ -571,6 +574,22 @@ class LBFGSOptimizer(_OptBase):
     def set_max_halvings(self, v):
         _check(lib().dzo_lbfgs_set_max_halvings(self.h, v))
 
+    # optional safeguards (off = the live reference); include/dzo.h, SURVEY.md 8(f) rows 2 and 4
+    def set_safeguards(self, descent_check=False, steepest_descent_fallback=False):
+        """Legacy descent check (legacy/DZOptimization.jl:682-692) and steepest-descent
+        fallback with history reset (:588-610)."""
+        _check(lib().dzo_lbfgs_set_safeguards(self.h, int(descent_check), int(steepest_descent_fallback)))
+
+    def set_line_search(self, kind, c1=0.0, c2=0.0, max_evals=0):
+        """LINE_SEARCH_BACKTRACKING (reference) or LINE_SEARCH_WOLFE (strong Wolfe on the
+        LineSearchEvaluator quotients, src/DZOptimization.jl:65-92)."""
+        _check(lib().dzo_lbfgs_set_line_search(self.h, int(kind), c1, c2, int(max_evals)))
+
+    last_step_length = property(lambda s: s._s(2))
+    history_resets = property(lambda s: s._i(8))
+    descent_resets = property(lambda s: s._i(9))
+    last_step_kind = property(lambda s: s._i(10))
+
     def compute_step_direction(self):
         """``compute_lbfgs_step_direction!`` (:430-451)."""
         _check(lib().dzo_lbfgs_direction(self.h))
@@ -604,6 +623,9 @@ class LBFGSOptimizer(_OptBase):
 
     def set_objective_value(self, f):
         _check(lib().dzo_lbfgs_set_s(self.h, 0, f))
+
+    def set_last_step_length(self, v):
+        _check(lib().dzo_lbfgs_set_s(self.h, 2, v))
 
 
 class AdGDOptimizer(_OptBase):

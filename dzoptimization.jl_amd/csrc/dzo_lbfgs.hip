@@ -20,6 +20,7 @@
 //          2k+1 coefficients per element IN THE REFERENCE'S ELEMENTWISE ORDER (fma chain,
 //          then the rmul! scale, then the second fma chain).  Moves (4k+3)*n elements --
 //          the algorithmic floor of SURVEY.md 8(d) plus one re-read of g.
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <type_traits>
@@ -67,6 +68,17 @@ struct dzo_lbfgs_s {
     bool rho_pending = false;       // rho partials of the newest pair await their final sum
     int tail_grid = 0;              // grid of the last speculative tail (its partial count)
     int rho_pending_count = 0, rho_pending_slot = 0;
+    // optional safeguards, off by default (= the live reference); SURVEY.md 8(f) rows 2 and 4
+    bool descent_check = false;     // legacy/DZOptimization.jl:682-692
+    bool sd_fallback = false;       // legacy/DZOptimization.jl:588-610 (steepest descent + history reset)
+    int32_t line_search = 0;        // 0 take_backtracking_step!, 1 strong Wolfe on the evaluator quotients
+    double wolfe_c1 = 1e-4, wolfe_c2 = 0.9;
+    int32_t wolfe_max_evals = 40;
+    double last_step_length = 0;    // legacy :625-627
+    int64_t history_resets = 0, descent_resets = 0;
+    int32_t last_step_kind = 0;     // 0 quasi-Newton, 1 descent-check replacement, 2 fallback
+    bool reset_on_push = false;
+    void *xt = nullptr, *gt = nullptr;   // LineSearchEvaluator trial_point / trial_gradient (:26-27)
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 0, gram_bpc = 0;   // tuning knobs (DZO_TUNE_* env, dev only)
@@ -902,7 +914,7 @@ static int32_t lbfgs_direction(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
-static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done);
+static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done, bool rho_final = false);
 
 static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
@@ -959,10 +971,17 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
     return lbfgs_rho_finish(o, grid, gate);
 }
 
-static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done) {
+static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done, bool rho_final) {
     OptCore &c = o->core;
     const int sp = o->spare();
-    if (o->mode == DZO_TWOLOOP_GRAM) {
+    if (o->reset_on_push) {                               // legacy :609  _history_count[] = 0
+        o->k = 0;
+        o->reset_on_push = false;
+        o->history_resets += 1;
+    }
+    if (rho_final) {
+        o->rho_pending = false;                           // rho[spare] already holds s.y
+    } else if (o->mode == DZO_TWOLOOP_GRAM) {
         // defer the final sum of rho to the next direction's gram_reduce launch
         o->rho_pending = true;
         o->rho_pending_count = rho_done ? o->tail_grid : grid;
@@ -981,13 +1000,135 @@ static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done) {
     return DZO_OK;
 }
 
-static int32_t lbfgs_step(dzo_lbfgs_s *o) {
+// scratch for the safeguards' dot products: the upper half of the workspace partials (the lower
+// half may still hold the pending rho partials); the result lands in result()[0]
+static int32_t lbfgs_aux_dot(dzo_lbfgs_s *o, const void *a, const void *b, double *out) {
     OptCore &c = o->core;
-    if (c.is_stuck) return DZO_OK;                        // :456-458
-    DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
-                "step! needs objective and gradient (callbacks or a built-in problem)");
-    if (c.iteration_count > 0) DZO_TRY(lbfgs_direction(o));   // :463-471
+    double v = 0;
+    DZO_TRY(dot_blocking(c.stream, c.n, c.dtype, a, b, c.partials() + kMaxPartialBlocks, c.host, &v));
+    *out = round_to_dtype(c.dtype, v);
+    return DZO_OK;
+}
+
+// d = -(last_step_length / ||g||) g   (legacy/DZOptimization.jl:594-596, :688-690)
+static int32_t lbfgs_steepest(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    double ss = 0;
+    DZO_TRY(lbfgs_aux_dot(o, c.g, c.g, &ss));
+    const double inv = c.dtype == DZO_F32 ? (double)(1.0f / sqrtf((float)ss)) : 1.0 / sqrt(ss);   // Kernels.jl:141
+    const double sc = round_to_dtype(c.dtype, -o->last_step_length * inv);
+    DZO_DISPATCH(c.dtype, launch_scal_oop<T>(c.stream, c.n, (T *)o->d, (T)sc, (const T *)c.g));
+    DZO_HIP(hipGetLastError());
+    return DZO_OK;
+}
+
+static int32_t lbfgs_eval_at(OptCore &c, void *x, double *f) {
+    if (c.objective) {
+        DZO_HIP(hipStreamSynchronize(c.stream));
+        *f = round_to_dtype(c.dtype, c.objective(c.cb_ctx, x));
+        return DZO_OK;
+    }
+    DZO_TRY(problem_eval_async(c.problem, c.stream, x, c.result()));
+    DZO_HIP(hipMemcpyAsync(c.host, c.result(), sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    DZO_HIP(hipStreamSynchronize(c.stream));
+    *f = round_to_dtype(c.dtype, c.host[0]);
+    return DZO_OK;
+}
+
+static int32_t lbfgs_grad_at(OptCore &c, void *g, void *x) {
+    if (c.gradient) {
+        DZO_HIP(hipStreamSynchronize(c.stream));
+        c.gradient(c.cb_ctx, g, x);
+        return DZO_OK;
+    }
+    return problem_grad_async(c.problem, c.stream, g, x);
+}
+
+// Strong-Wolfe search by bisection / doubling on the LineSearchEvaluator quotients
+// (src/DZOptimization.jl:65-92): improvement_ratio >= c1, |slope_ratio| <= c2.  Host-driven:
+// every evaluation ends in a scalar read-back, like the reference's evaluator call.  On
+// success x, f, df, dx, g, dg are all final (the trial gradient is reused).
+static int32_t lbfgs_wolfe_search(dzo_lbfgs_s *o, bool *accepted) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int32_t dt = c.dtype;
+    const size_t bytes = (size_t)c.n * dtype_size(dt);
+    *accepted = false;
+    if (!o->xt) {
+        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * dtype_size(dt);
+        DZO_HIP(hipMalloc(&o->xt, padded));
+        DZO_HIP(hipMalloc(&o->gt, padded));
+    }
+    c.last_trials = 0;
+    double overlap = 0;
+    DZO_TRY(lbfgs_aux_dot(o, c.g, o->d, &overlap));                  // the evaluator's `overlap` = g.d
+    if (!(overlap < 0.0)) { c.is_stuck = true; return DZO_OK; }      // not a descent direction (or NaN)
+    const double tmax = dt == DZO_F32 ? 3.4028234663852886e38 : 1.7976931348623157e308;
+    double t = 1.0, lo = 0.0, hi = -1.0;                             // hi < 0: no upper bound yet
+    for (int32_t it = 0; it < o->wolfe_max_evals; ++it) {
+        DZO_DISPATCH(dt, launch_axpy_oop<T>(s, c.n, (T *)o->xt, (T)t, (const T *)o->d, (const T *)c.x));   // :69-70
+        DZO_HIP(hipGetLastError());
+        bool feasible = true;
+        if (c.constraint) {                                          // :71-79
+            DZO_HIP(hipStreamSynchronize(s));
+            feasible = c.constraint(c.cb_ctx, o->xt) != 0;
+        } else if (c.box_on) {
+            DZO_TRY(box_clamp_async(s, c.n, dt, o->xt, c.box_lo, c.box_hi));
+        }
+        double f_t = tmax, ir = -tmax, sr = tmax;
+        if (feasible) {
+            DZO_TRY(lbfgs_eval_at(c, o->xt, &f_t));                  // :80-81
+            ir = round_to_dtype(dt, round_to_dtype(dt, f_t - c.f) / round_to_dtype(dt, t * overlap));   // :84
+            DZO_TRY(lbfgs_grad_at(c, o->gt, o->xt));                 // :87
+            double gd = 0;
+            DZO_TRY(lbfgs_aux_dot(o, o->gt, o->d, &gd));
+            sr = round_to_dtype(dt, gd / overlap);                   // :88-89
+        }
+        c.last_trials += 1;
+        if (!(ir >= o->wolfe_c1) || !(f_t < c.f)) hi = t;            // Armijo fails (NaN counts as failure)
+        else if (sr > o->wolfe_c2) lo = t;                           // still descending steeply
+        else if (sr < -o->wolfe_c2) hi = t;                          // overshot the minimiser
+        else {
+            DZO_HIP(hipMemcpyAsync(c.dx, o->xt, bytes, hipMemcpyDeviceToDevice, s));
+            DZO_DISPATCH(dt, launch_axpby<T>(s, c.n, (T)-1, (const T *)c.x, (T)1, (T *)c.dx));     // dx = x_new - x_old
+            DZO_HIP(hipMemcpyAsync(c.x, o->xt, bytes, hipMemcpyDeviceToDevice, s));
+            c.df = round_to_dtype(dt, f_t - c.f);
+            c.f = f_t;
+            DZO_HIP(hipMemcpyAsync(c.dg, o->gt, bytes, hipMemcpyDeviceToDevice, s));
+            DZO_DISPATCH(dt, launch_axpby<T>(s, c.n, (T)-1, (const T *)c.g, (T)1, (T *)c.dg));     // dg = g_new - g_old
+            DZO_HIP(hipMemcpyAsync(c.g, o->gt, bytes, hipMemcpyDeviceToDevice, s));
+            DZO_HIP(hipGetLastError());
+            *accepted = true;
+            return DZO_OK;
+        }
+        const double t_next = round_to_dtype(dt, hi < 0.0 ? t + t : (lo + hi) * 0.5);
+        if (t_next == lo || t_next == hi || !(t_next > 0.0)) break;  // interval exhausted
+        t = t_next;
+    }
+    c.is_stuck = true;
+    return DZO_OK;
+}
+
+// one line search along o->d followed, when it succeeds, by the post-gradient phase and the push
+static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
+    const bool safeguards = o->descent_check || o->sd_fallback;
+    if (o->line_search == 1) {
+        bool accepted = false;
+        DZO_TRY(lbfgs_wolfe_search(o, &accepted));
+        if (!accepted) return DZO_OK;
+        if (safeguards) {
+            double ss = 0;
+            DZO_TRY(lbfgs_aux_dot(o, c.dx, c.dx, &ss));
+            o->last_step_length = c.dtype == DZO_F32 ? (double)sqrtf((float)ss) : sqrt(ss);
+        }
+        double r = 0;
+        DZO_TRY(lbfgs_aux_dot(o, c.dx, c.dg, &r));                   // :505
+        DZO_HIP(hipMemcpyAsync(o->rho + o->spare(), &r, sizeof(double), hipMemcpyHostToDevice, c.stream));
+        DZO_HIP(hipStreamSynchronize(c.stream));
+        return lbfgs_finish_push(o, 0, true, true);
+    }
     const bool fused = o->fused_post && !c.objective && !c.gradient && !c.constraint &&
                        problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
     c.defer_delta = fused;
@@ -999,16 +1140,60 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     c.speculative_tail = nullptr;
     DZO_TRY(rc);
     if (c.is_stuck) return DZO_OK;                        // :474-476
-    if (fused && speculated) return lbfgs_finish_push(o, 0, true);   // the gated tail already ran
-    if (fused) {
+    int32_t done = -1;
+    if (fused && speculated) {
+        done = lbfgs_finish_push(o, 0, true);             // the gated tail already ran
+    } else if (fused) {
         // :145 + :478-480 + partials of :505 in one pass
         int grid = 0;
         DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid));
-        return lbfgs_finish_push(o, grid, false);
+        done = lbfgs_finish_push(o, grid, false);
+    } else {
+        DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
+        DZO_TRY(core_gradient(c));                        // :479
+        done = lbfgs_post_gradient(o);                    // :480-507
     }
-    DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
-    DZO_TRY(core_gradient(c));                            // :479
-    return lbfgs_post_gradient(o);                        // :480-507
+    DZO_TRY(done);
+    if (safeguards) {                                     // legacy :625-627 (delta_point stays valid after the push)
+        double ss = 0;
+        DZO_TRY(lbfgs_aux_dot(o, c.dx, c.dx, &ss));
+        o->last_step_length = c.dtype == DZO_F32 ? (double)sqrtf((float)ss) : sqrt(ss);
+    }
+    return DZO_OK;
+}
+
+static int32_t lbfgs_step(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    if (c.is_stuck) return DZO_OK;                        // :456-458
+    DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
+                "step! needs objective and gradient (callbacks or a built-in problem)");
+    bool quasi = false;
+    o->last_step_kind = 0;
+    if (c.iteration_count > 0) {
+        DZO_TRY(lbfgs_direction(o));                      // :463-471
+        quasi = o->k > 0;
+        if (o->descent_check) {                           // legacy :682-692
+            double gd = 0;
+            DZO_TRY(lbfgs_aux_dot(o, o->d, c.g, &gd));
+            if (!std::isfinite(gd)) { c.is_stuck = true; return DZO_OK; }
+            if (gd >= 0.0) {
+                DZO_TRY(lbfgs_steepest(o));
+                o->descent_resets += 1;
+                o->last_step_kind = 1;
+                quasi = false;
+            }
+        }
+    }
+    DZO_TRY(lbfgs_search_and_post(o));
+    if (c.is_stuck && o->sd_fallback && quasi) {          // legacy :588-610
+        c.is_stuck = false;
+        DZO_TRY(lbfgs_steepest(o));
+        o->last_step_kind = 2;
+        o->reset_on_push = true;
+        DZO_TRY(lbfgs_search_and_post(o));
+        o->reset_on_push = false;                         // (stays set only if the retry failed too)
+    }
+    return DZO_OK;
 }
 
 }  // namespace dzo
@@ -1040,6 +1225,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         if ((sb / 1024) % 2 == 0 && tune("DZO_TUNE_STRIDE_SKEW", 1)) sb += 1024;
         o->stride = (int64_t)(sb / es);
     }
+    o->last_step_length = round_to_dtype(dtype, initial_step_length);   // as legacy BFGS :779
     int32_t rc = core_alloc(c);
     if (rc != DZO_OK) { delete o; return rc; }
     const int m1 = o->m + 1;
@@ -1127,6 +1313,8 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (o->S) (void)hipFree(o->S);
     if (o->Y && !o->interleaved) (void)hipFree(o->Y);
     if (o->d) (void)hipFree(o->d);
+    if (o->xt) (void)hipFree(o->xt);
+    if (o->gt) (void)hipFree(o->gt);
     if (o->rho) (void)hipFree(o->rho);
     core_free(o->core);
     delete o;
@@ -1266,6 +1454,9 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 5: *value = o->core.last_trials; break;
     case 6: *value = o->mode; break;
     case 7: *value = o->core.dtype; break;
+    case 8: *value = o->history_resets; break;
+    case 9: *value = o->descent_resets; break;
+    case 10: *value = o->last_step_kind; break;
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;
@@ -1273,15 +1464,35 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
 
 int32_t dzo_lbfgs_get_s(dzo_lbfgs_t o, int32_t what, double *value) {
     DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
-    DZO_REQUIRE(what == 0 || what == 1, DZO_ERR_INVALID, "unknown field %d", what);
-    *value = what == 0 ? o->core.f : o->core.df;
+    DZO_REQUIRE(what >= 0 && what <= 2, DZO_ERR_INVALID, "unknown field %d", what);
+    *value = what == 0 ? o->core.f : what == 1 ? o->core.df : o->last_step_length;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t o, int32_t descent_check, int32_t steepest_descent_fallback) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    o->descent_check = descent_check != 0;
+    o->sd_fallback = steepest_descent_fallback != 0;
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_set_line_search(dzo_lbfgs_t o, int32_t kind, double c1, double c2, int32_t max_evals) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(kind == DZO_LINE_SEARCH_BACKTRACKING || kind == DZO_LINE_SEARCH_WOLFE, DZO_ERR_INVALID,
+                "unknown line search %d", kind);
+    DZO_REQUIRE(!(c1 > 0 && c2 > 0) || c1 < c2, DZO_ERR_INVALID, "Wolfe constants need 0 < c1 < c2 < 1");
+    DZO_REQUIRE(c2 < 1.0, DZO_ERR_INVALID, "Wolfe constants need 0 < c1 < c2 < 1");
+    o->line_search = kind;
+    if (c1 > 0) o->wolfe_c1 = round_to_dtype(o->core.dtype, c1);
+    if (c2 > 0) o->wolfe_c2 = round_to_dtype(o->core.dtype, c2);
+    if (max_evals > 0) o->wolfe_max_evals = max_evals;
     return DZO_OK;
 }
 
 int32_t dzo_lbfgs_set_s(dzo_lbfgs_t o, int32_t what, double value) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
-    DZO_REQUIRE(what == 0 || what == 1, DZO_ERR_INVALID, "unknown field %d", what);
-    (what == 0 ? o->core.f : o->core.df) = round_to_dtype(o->core.dtype, value);
+    DZO_REQUIRE(what >= 0 && what <= 2, DZO_ERR_INVALID, "unknown field %d", what);
+    (what == 0 ? o->core.f : what == 1 ? o->core.df : o->last_step_length) = round_to_dtype(o->core.dtype, value);
     return DZO_OK;
 }
 

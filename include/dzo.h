@@ -62,6 +62,9 @@ extern "C" {
 #define DZO_TWOLOOP_CHAIN 0 /* 2k+1 fused axpy+dot links in the reference's op order */
 #define DZO_TWOLOOP_GRAM 1  /* one Gram pass + O(k^2) scalar recurrence + one combine pass */
 
+#define DZO_LINE_SEARCH_BACKTRACKING 0 /* take_backtracking_step! (src/DZOptimization.jl:107-154), the reference */
+#define DZO_LINE_SEARCH_WOLFE 1        /* strong Wolfe on the LineSearchEvaluator quotients (:65-92) */
+
 /* dense BFGS last_step_type (legacy/DZOptimization.jl:727-731) */
 #define DZO_STEP_NULL 0
 #define DZO_STEP_GRADIENT_DESCENT 1
@@ -180,6 +183,28 @@ int32_t dzo_lbfgs_set_callbacks(dzo_lbfgs_t opt, dzo_constraint_fn constraint,
 int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t opt, dzo_problem_t problem);
 int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t opt, int32_t mode);
 int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
+
+/* Optional safeguards, OFF by default (off = the live reference's step!).  SURVEY.md 8(f):
+ *   descent_check  -- legacy/DZOptimization.jl:682-692: after the two-loop, if g.d is not
+ *       finite the optimizer stops (is_stuck); if g.d >= 0 the direction is replaced by
+ *       -(last_step_length/||g||) g, last_step_length = ||delta_point|| of the last step (:625-627).
+ *   steepest_descent_fallback -- legacy :588-610: when the search along a quasi-Newton direction
+ *       fails, retry along -(last_step_length/||g||) g; success clears the (s, y) history
+ *       (_history_count[] = 0, :609), failure sets is_stuck.
+ * dzo_lbfgs_get_i fields 8 / 9 / 10: history resets, descent-check replacements, kind of the
+ * last step (0 quasi-Newton, 1 replaced by the descent check, 2 fallback);
+ * dzo_lbfgs_get_s field 2: last_step_length. */
+int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t opt, int32_t descent_check, int32_t steepest_descent_fallback);
+
+/* Line search used by step!: DZO_LINE_SEARCH_BACKTRACKING (reference, default) or
+ * DZO_LINE_SEARCH_WOLFE -- the consumer of the quotients the reference's LineSearchEvaluator
+ * defines but never uses (src/DZOptimization.jl:84 improvement_ratio, :88-89 slope_ratio):
+ * bisection / doubling from t = 1 until improvement_ratio >= c1 and |slope_ratio| <= c2, at most
+ * max_evals evaluator calls (each = objective + gradient at the trial point).  Guarantees
+ * delta_point . delta_gradient > 0 for every pushed pair.  The accepted trial gradient becomes
+ * current_gradient (no extra gradient call).  c1, c2, max_evals <= 0 keep the defaults
+ * (1e-4, 0.9, 40). */
+int32_t dzo_lbfgs_set_line_search(dzo_lbfgs_t opt, int32_t kind, double c1, double c2, int32_t max_evals);
 
 /* step!(opt) (:454-509) -- the whole step, callbacks invoked from inside. */
 int32_t dzo_lbfgs_step(dzo_lbfgs_t opt);

@@ -321,6 +321,20 @@ typedef struct {
     int32_t n_rho;
     int64_t max_halvings;             /* build-added escape from the NaN loop */
     int64_t last_trials;              /* number of objective evaluations in the last step */
+    /* Optional safeguards (all off by default = the live reference).  SURVEY.md 8(f) rows 2, 4:
+     * the legacy optimizer's descent check and steepest-descent fallback with history reset
+     * (legacy/DZOptimization.jl:588-610, :682-692) and a strong-Wolfe search driven by the
+     * LineSearchEvaluator quotients (src/DZOptimization.jl:65-92). */
+    int32_t descent_check;
+    int32_t sd_fallback;
+    int32_t line_search;              /* 0 = take_backtracking_step!, 1 = strong Wolfe */
+    T wolfe_c1, wolfe_c2;
+    int32_t wolfe_max_evals;
+    T last_step_length;               /* legacy :625-627 sqrt(norm2(delta_point)) */
+    int64_t history_resets;
+    int64_t descent_resets;
+    int32_t last_step_kind;           /* 0 quasi-Newton, 1 descent-check replacement, 2 fallback */
+    T *xt, *gt;                       /* LineSearchEvaluator trial_point / trial_gradient (:26-27) */
 } FN(orc_lbfgs);
 
 /* compute_lbfgs_step_direction!  src/DZOptimization.jl:430-451 */
@@ -366,6 +380,8 @@ FN(orc_lbfgs) *FN(orc_lbfgs_create_full)(FN(orc_constraint_fn) cf, FN(orc_object
     o->rho = (T *)calloc((size_t)(m > 0 ? m : 1), sizeof(T));
     o->k = 0; o->n_alpha = 0; o->n_rho = 0;
     o->max_halvings = 4096;
+    o->wolfe_c1 = (T)1e-4; o->wolfe_c2 = (T)0.9; o->wolfe_max_evals = 40;
+    o->last_step_length = initial_step_length;               /* as legacy BFGS :779 */
     return o;
 }
 
@@ -389,7 +405,7 @@ void FN(orc_lbfgs_destroy)(FN(orc_lbfgs) *o) {
     if (!o) return;
     for (int32_t i = 0; i < o->k; ++i) { free(o->S[i]); free(o->Y[i]); }
     free(o->S); free(o->Y); free(o->alpha); free(o->rho);
-    free(o->dx); free(o->dg); free(o->d);
+    free(o->dx); free(o->dg); free(o->d); free(o->xt); free(o->gt);
     free(o);
 }
 
@@ -430,20 +446,114 @@ static void FN(backtracking_step)(FN(orc_constraint_fn) cf, FN(orc_objective_fn)
     }
 }
 
+/* LineSearchEvaluator call (src/DZOptimization.jl:65-92) on the optimizer's own buffers. */
+static void FN(lbfgs_ls_eval)(FN(orc_lbfgs) *o, const T *dir, T overlap, T t, T *f_t, T *ir, T *sr) {
+    const int64_t n = o->n;
+    FN(orc_copy)(o->xt, o->x, n);                            /* :69 */
+    FN(orc_axpy)(t, dir, o->xt, n);                          /* :70 */
+    if (o->constraint && !o->constraint(o->ctx, o->xt, n)) { /* :71-79 */
+        *f_t = T_MAXVAL; *ir = -T_MAXVAL; *sr = T_MAXVAL;
+        return;
+    }
+    *f_t = o->objective(o->ctx, o->xt, n);                   /* :80-81 */
+    *ir = (*f_t - o->f) / (t * overlap);                     /* :84 */
+    o->gradient(o->ctx, o->gt, o->xt, n);                    /* :87 */
+    *sr = FN(orc_dot)(o->gt, dir, n) / overlap;              /* :88-89 */
+}
+
+/* Strong-Wolfe search by bisection / doubling on the evaluator's quotients:
+ *   improvement_ratio >= c1  (Armijo),  |slope_ratio| <= c2  (curvature).
+ * On success x, f, df, dx = x_new - x_old, g, dg = g_new - g_old are all updated (the trial
+ * gradient is reused) and 1 is returned; otherwise nothing moves and is_stuck is set. */
+static int FN(lbfgs_wolfe_search)(FN(orc_lbfgs) *o, const T *dir) {
+    const int64_t n = o->n;
+    if (!o->xt) { o->xt = (T *)malloc((size_t)n * sizeof(T)); o->gt = (T *)malloc((size_t)n * sizeof(T)); }
+    o->last_trials = 0;
+    const T overlap = FN(orc_dot)(o->g, dir, n);             /* g.d, the evaluator's `overlap` */
+    if (!(overlap < (T)0)) { o->is_stuck = 1; return 0; }    /* not a descent direction (or NaN) */
+    const T half = (T)1 / ((T)1 + (T)1);
+    T t = (T)1, lo = (T)0, hi = (T)-1;                       /* hi < 0: no upper bound yet */
+    for (int32_t it = 0; it < o->wolfe_max_evals; ++it) {
+        T f_t, ir, sr;
+        FN(lbfgs_ls_eval)(o, dir, overlap, t, &f_t, &ir, &sr);
+        o->last_trials += 1;
+        if (!(ir >= o->wolfe_c1) || !(f_t < o->f)) hi = t;   /* Armijo fails (NaN counts as failure) */
+        else if (sr > o->wolfe_c2) lo = t;                   /* still descending steeply: move right */
+        else if (sr < -o->wolfe_c2) hi = t;                  /* overshot the minimiser */
+        else {
+            FN(orc_copy)(o->dx, o->xt, n);
+            FN(orc_axpby)((T)-1, o->x, (T)1, o->dx, n);      /* dx = x_new - x_old */
+            FN(orc_copy)(o->x, o->xt, n);
+            o->df = f_t - o->f;
+            o->f = f_t;
+            FN(orc_copy)(o->dg, o->gt, n);
+            FN(orc_axpby)((T)-1, o->g, (T)1, o->dg, n);      /* dg = g_new - g_old */
+            FN(orc_copy)(o->g, o->gt, n);
+            return 1;
+        }
+        const T t_next = hi < (T)0 ? t + t : (lo + hi) * half;
+        if (t_next == lo || t_next == hi || !(t_next > (T)0)) break;   /* interval exhausted */
+        t = t_next;
+    }
+    o->is_stuck = 1;
+    return 0;
+}
+
+/* one line search along `dir`; returns 1 when the gradient (and dg) is already up to date */
+static int FN(lbfgs_search)(FN(orc_lbfgs) *o, const T *dir) {
+    if (o->line_search == 1) return FN(lbfgs_wolfe_search)(o, dir);
+    FN(backtracking_step)(o->constraint, o->objective, o->ctx, o->n, o->x, o->dx, &o->f, &o->df,
+                          &o->is_stuck, (T)1, dir, o->max_halvings, &o->last_trials); /* :473 */
+    return 0;
+}
+
+/* d = -(last_step_length / ||g||) g   (legacy :594-596, :688-690) */
+static void FN(lbfgs_steepest)(FN(orc_lbfgs) *o) {
+    const T inv = (T)1 / T_SQRT(FN(orc_norm2)(o->g, o->n));  /* Kernels.jl:141 */
+    FN(orc_copy)(o->d, o->g, o->n);
+    FN(orc_scal)(o->d, -o->last_step_length * inv, o->n);
+}
+
 /* step!(::LBFGSOptimizer)  src/DZOptimization.jl:454-509 */
 void FN(orc_lbfgs_step)(FN(orc_lbfgs) *o) {
     if (o->is_stuck) return;                                 /* :456-458 */
     const int64_t n = o->n;
+    int quasi = 0;
+    o->last_step_kind = 0;
     if (o->iteration_count > 0) {                            /* :463 */
         FN(orc_lbfgs_direction)(o->d, o->g, o->S, o->Y, o->alpha, o->rho, o->k, n);
+        quasi = o->k > 0;
+        if (o->descent_check) {                              /* legacy :682-692 */
+            const T gd = FN(orc_dot)(o->d, o->g, n);
+            if (!T_ISFINITE(gd)) { o->is_stuck = 1; return; }
+            if (gd >= (T)0) {
+                FN(lbfgs_steepest)(o);
+                o->descent_resets += 1;
+                o->last_step_kind = 1;
+                quasi = 0;
+            }
+        }
     }
-    FN(backtracking_step)(o->constraint, o->objective, o->ctx, n, o->x, o->dx, &o->f, &o->df,
-                          &o->is_stuck, (T)1, o->d, o->max_halvings, &o->last_trials); /* :473 */
+    int have_gradient = FN(lbfgs_search)(o, o->d);
+    if (o->is_stuck && o->sd_fallback && quasi) {            /* legacy :588-610 */
+        o->is_stuck = 0;
+        FN(lbfgs_steepest)(o);
+        o->last_step_kind = 2;
+        have_gradient = FN(lbfgs_search)(o, o->d);
+        if (o->is_stuck) return;
+        for (int32_t i = 0; i < o->k; ++i) { free(o->S[i]); free(o->Y[i]); o->S[i] = NULL; o->Y[i] = NULL; }
+        o->k = 0; o->n_rho = 0;                              /* legacy :609 _history_count[] = 0 */
+        o->history_resets += 1;
+    }
     if (o->is_stuck) return;                                 /* :474-476 */
+    if (o->descent_check || o->sd_fallback)
+        o->last_step_length = T_SQRT(FN(orc_norm2)(o->dx, n));   /* legacy :625-627 */
 
+    if (!have_gradient) {
     FN(orc_copy)(o->dg, o->g, n);                            /* :478 */
     o->gradient(o->ctx, o->g, o->x, n);                      /* :479 */
     FN(orc_axpby)((T)1, o->g, (T)-1, o->dg, n);              /* :480 */
+    }
 
     if (o->m > 0) {
         /* :482-496  pushfirst! a copy, recycling the oldest buffer once full */
@@ -914,10 +1024,24 @@ int64_t FN(orc_lbfgs_get_i)(const FN(orc_lbfgs) *o, int what) {
     case 5: return o->n_alpha;
     case 6: return o->n_rho;
     case 7: return o->last_trials;
+    case 8: return o->history_resets;
+    case 9: return o->descent_resets;
+    case 10: return o->last_step_kind;
     }
     return -1;
 }
-T FN(orc_lbfgs_get_s)(const FN(orc_lbfgs) *o, int what) { return what == 0 ? o->f : o->df; }
+T FN(orc_lbfgs_get_s)(const FN(orc_lbfgs) *o, int what) {
+    return what == 0 ? o->f : what == 1 ? o->df : o->last_step_length;
+}
+void FN(orc_lbfgs_set_safeguards)(FN(orc_lbfgs) *o, int32_t descent_check, int32_t sd_fallback) {
+    o->descent_check = descent_check; o->sd_fallback = sd_fallback;
+}
+void FN(orc_lbfgs_set_line_search)(FN(orc_lbfgs) *o, int32_t kind, T c1, T c2, int32_t max_evals) {
+    o->line_search = kind;
+    if (c1 > (T)0) o->wolfe_c1 = c1;
+    if (c2 > (T)0) o->wolfe_c2 = c2;
+    if (max_evals > 0) o->wolfe_max_evals = max_evals;
+}
 T *FN(orc_lbfgs_get_v)(const FN(orc_lbfgs) *o, int what, int idx) {
     switch (what) {
     case 0: return o->x;

@@ -105,6 +105,8 @@ def _declare(L):
         f("orc_lbfgs_get_v", vp, [vp, C.c_int, C.c_int])
         f("orc_lbfgs_set_max_halvings", None, [vp, i64])
         f("orc_lbfgs_set_history", None, [vp, i32, vp, vp, vp, i64])
+        f("orc_lbfgs_set_safeguards", None, [vp, i32, i32])
+        f("orc_lbfgs_set_line_search", None, [vp, i32, ct, ct, i32])
         f("orc_adgd_create_problem", vp, [vp, vp, vp, ct])
         f("orc_adgd_destroy", None, [vp])
         f("orc_adgd_step", None, [vp])
@@ -325,6 +327,20 @@ class LBFGS:
 
     def set_max_halvings(self, v):
         getattr(lib(), "orc_lbfgs_set_max_halvings" + self.suf)(self.h, v)
+
+    # optional safeguards (off = the live reference), SURVEY.md 8(f) rows 2 and 4
+    def set_safeguards(self, descent_check=False, steepest_descent_fallback=False):
+        getattr(lib(), "orc_lbfgs_set_safeguards" + self.suf)(self.h, int(descent_check), int(steepest_descent_fallback))
+
+    def set_line_search(self, kind, c1=0.0, c2=0.0, max_evals=0):
+        """kind 0 = take_backtracking_step! (reference), 1 = strong Wolfe on the
+        LineSearchEvaluator quotients; zero c1 / c2 / max_evals keep the defaults (1e-4, 0.9, 40)."""
+        getattr(lib(), "orc_lbfgs_set_line_search" + self.suf)(self.h, int(kind), c1, c2, int(max_evals))
+
+    last_step_length = property(lambda s: getattr(lib(), "orc_lbfgs_get_s" + s.suf)(s.h, 2))
+    history_resets = property(lambda s: s._i(8))
+    descent_resets = property(lambda s: s._i(9))
+    last_step_kind = property(lambda s: s._i(10))
 
 
 class AdGD:
