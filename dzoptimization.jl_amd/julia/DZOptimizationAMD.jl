@@ -21,6 +21,7 @@ import LinearAlgebra: axpy!, axpby!, dot, norm, rmul!
 
 export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentOptimizer, QuadraticLineSearch,
        UniformBoxConstraint, with_l2!, with_box_gradient!, with_box_constraint!, step!,
+       set_safeguards!, set_line_search!, BACKTRACKING, STRONG_WOLFE,
        RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem
 
 const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
@@ -248,6 +249,22 @@ end
 """`step!(opt)` (src/DZOptimization.jl:454-509)."""
 step!(opt::LBFGSOptimizer) = (check(ccall((:dzo_lbfgs_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
 
+const BACKTRACKING, STRONG_WOLFE = Cint(0), Cint(1)
+
+"""`set_safeguards!(opt; descent_check=false, steepest_descent_fallback=false)`: the legacy
+optimizer's descent check (legacy/DZOptimization.jl:682-692) and steepest-descent fallback with
+history reset (:588-610) as options of the live `step!`; both off = the reference."""
+set_safeguards!(opt::LBFGSOptimizer; descent_check::Bool=false, steepest_descent_fallback::Bool=false) =
+    (check(ccall((:dzo_lbfgs_set_safeguards, libdzo), Cint, (Ptr{Cvoid}, Cint, Cint), getfield(opt, :handle),
+                 descent_check, steepest_descent_fallback)); opt)
+
+"""`set_line_search!(opt, STRONG_WOLFE; c1=1e-4, c2=0.9, max_evals=40)`: strong-Wolfe search on the
+`LineSearchEvaluator` quotients (src/DZOptimization.jl:84, :88-89); `BACKTRACKING` restores
+`take_backtracking_step!` (:107-154)."""
+set_line_search!(opt::LBFGSOptimizer, kind::Integer; c1::Real=0.0, c2::Real=0.0, max_evals::Integer=0) =
+    (check(ccall((:dzo_lbfgs_set_line_search, libdzo), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cint),
+                 getfield(opt, :handle), kind, c1, c2, max_evals)); opt)
+
 _lb_i(o, w) = (v = Ref{Int64}(0); check(ccall((:dzo_lbfgs_get_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), getfield(o, :handle), w, v)); v[])
 _lb_s(o, w) = (v = Ref{Cdouble}(0); check(ccall((:dzo_lbfgs_get_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), getfield(o, :handle), w, v)); v[])
 function _lb_p(o::LBFGSOptimizer{T}, w, idx=0) where {T}
@@ -276,6 +293,9 @@ function Base.getproperty(o::LBFGSOptimizer{T}, s::Symbol) where {T}
     s === :delta_gradient_history && return [_lb_p(o, 6, i - 1) for i in 1:_lb_i(o, 4)]
     s === :rho_history && return _lb_hist(o, :dzo_lbfgs_get_rho)
     s === :alpha_history && return _lb_hist(o, :dzo_lbfgs_get_alpha)
+    s === :last_step_length && return fill(T(_lb_s(o, 2)))
+    s === :history_resets && return Int(_lb_i(o, 8))
+    s === :descent_resets && return Int(_lb_i(o, 9))
     return getfield(o, s)
 end
 
