@@ -4,6 +4,8 @@
 // (:151) and re-applies axpy! (:124) on every halving; here each trial recomputes
 // x = fma(t, d, x_old) from the saved point, which is the same arithmetic bit for bit and
 // removes the restore pass from the loop.
+#include <cstdlib>
+
 #include "dzo_optcore.h"
 
 namespace dzo {
@@ -139,18 +141,28 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));   // decide_kernel re-arms it itself
     c.flag_armed = false;
     const bool first = c.search_open;
-    DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)c.dx, (const T *)dir, (T)t, first, c.flag()));
-    DZO_HIP(hipGetLastError());
     c.search_open = false;
     const bool fused = fuse_objective && c.problem && !c.objective && !c.constraint;
+    const bool speculate = fused && c.speculative_tail != nullptr;
+    const double *partials = nullptr;
+    int64_t count = 0;
+    double scale = 1.0;
+    // Trial point and objective in one pass (dev knob, off by default).  It removes the objective
+    // kernel's pass over x, but that pass hits the Infinity Cache (x was written one kernel
+    // earlier), so no HBM traffic disappears: interleaved A/B at n = 1e7 gave -13 us in the small
+    // kernels and +11 us in the two-loop kernels, which then absorb the write-back of the dirty
+    // lines that the objective kernel used to overlap (792 vs 791 step!()/s, noise +-4).
+    static const bool fuse_trial = getenv("DZO_TUNE_FUSED_TRIAL") ? atoi(getenv("DZO_TUNE_FUSED_TRIAL")) != 0 : false;
+    const bool trial_fused = speculate && fuse_trial && !c.box_on &&
+                             problem_trial_eval_async(c.problem, s, c.x, c.dx, dir, t, first, c.flag(), &partials, &count, &scale);
+    if (!trial_fused) {
+        DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)c.dx, (const T *)dir, (T)t, first, c.flag()));
+        DZO_HIP(hipGetLastError());
+    }
     // built-in box constraint: projection is always feasible, so it can ride in the stream (:134-135)
     if (fused && c.box_on) DZO_TRY(box_clamp_async(s, c.n, c.dtype, c.x, c.box_lo, c.box_hi));
-    const bool speculate = fused && c.speculative_tail != nullptr;
     if (speculate) {
-        const double *partials = nullptr;
-        int64_t count = 0;
-        double scale = 1.0;
-        if (!problem_eval_partials_async(c.problem, s, c.x, &partials, &count, &scale)) {
+        if (!trial_fused && !problem_eval_partials_async(c.problem, s, c.x, &partials, &count, &scale)) {
             partials = nullptr;
             DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
         }

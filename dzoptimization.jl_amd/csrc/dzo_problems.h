@@ -24,6 +24,10 @@ int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, doubl
 // Objective partials only (no final sum); false if this objective needs its own finish kernel.
 bool problem_eval_partials_async(dzo_problem_s *p, hipStream_t s, const void *x, const double **partials,
                                  int64_t *count, double *scale);
+// x = fma(t, d, x_old) + changed flag + objective partials of the new point in ONE pass; false when
+// this objective / these operands have no fused kernel (the caller then runs trial + objective).
+bool problem_trial_eval_async(dzo_problem_s *p, hipStream_t s, void *x, void *backup, const void *d, double t,
+                              bool first, int32_t *changed, const double **partials, int64_t *count, double *scale);
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).

@@ -174,6 +174,103 @@ __global__ __launch_bounds__(kBlock) void rosen_accept_grad_delta_kernel(int64_t
     if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
+// Trial point + objective in one pass (K2 + K12): x = fma(t, d, x_old) (src/DZOptimization.jl:124,
+// bit-identical to trial_kernel), the "any element changed" flag (:128), the backup of x_old on
+// the first trial (:118) and the per-block partial sums of every objective term f_i(x_i, x_{i+1})
+// whose two elements are held by one wave-row (64 lanes x 16 B): the right-hand neighbour of a
+// lane's last element comes from the next lane by shuffle.  The terms that straddle two rows
+// (one per 64 vectors) and the scalar tail are summed by rosen_edge_terms_kernel afterwards --
+// they cannot be formed here because on the first trial x is overwritten in place by other
+// waves.  Saves the objective kernel's own pass over x (n T per trial).
+template <typename T, bool FIRST>
+__global__ __launch_bounds__(kBlock) void rosen_trial_eval_kernel(int64_t n, T *x, T *__restrict__ backup,
+                                                                  const T *__restrict__ d, T t,
+                                                                  int32_t *__restrict__ changed,
+                                                                  double *__restrict__ partials) {
+    constexpr int N = Vec16<T>::N;
+    constexpr int U = 4;
+    __shared__ double lds[kWaves];
+    __shared__ int lds_flag;
+    const int lane = threadIdx.x & 63;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    const T *src = FIRST ? x : backup;
+    bool diff = false;
+    double acc = 0;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
+        T xo[U][N], dv[U][N];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
+            ok[u] = v < nvec;
+            if (ok[u]) {
+                load16(src + v * N, xo[u]);
+                load16(d + v * N, dv[u]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) { xo[u][j] = (T)0; dv[u][j] = (T)0; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
+            T xn[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                xn[j] = dfma(t, dv[u][j], xo[u][j]);                 // :124
+                diff |= ok[u] && !is_equal(xn[j], xo[u][j]);         // :128
+            }
+            const T xnext = __shfl_down(xn[0], 1, 64);
+            // the row's last vector (lane 63, or the last vector of x) leaves its final term to the edge kernel
+            const bool has_next = lane != 63 && v + 1 < nvec;
+            if (ok[u]) {
+#pragma unroll
+                for (int j = 0; j + 1 < N; ++j) acc += rosen_term<T>(xn[j], xn[j + 1]);
+                if (has_next) acc += rosen_term<T>(xn[N - 1], xnext);
+                store16(x + v * N, xn);
+                if (FIRST) store16(backup + v * N, xo[u]);           // :118
+            }
+        }
+    }
+    // scalar tail (n not a multiple of the vector width): the point only; its terms are edge terms
+    const int64_t e = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e < n) {
+        const T xo = src[e];
+        const T xn = dfma(t, d[e], xo);
+        diff |= !is_equal(xn, xo);
+        if (FIRST) backup[e] = xo;
+        x[e] = xn;
+    }
+    block_raise_flag(diff, changed, &lds_flag);
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// Objective terms that straddle two wave-rows of rosen_trial_eval_kernel, one thread per row, plus
+// the terms of the scalar tail.  Reads the finished x (2 elements per term).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rosen_edge_terms_kernel(int64_t n, const T *__restrict__ x,
+                                                                  double *__restrict__ partials) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[kWaves];
+    const int64_t nvec = n / N;
+    const int64_t rows = (nvec + 63) / 64;
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double acc = 0;
+    if (r < rows) {
+        const int64_t vend = (r + 1) * 64 < nvec ? (r + 1) * 64 : nvec;   // one past the row's last vector
+        const int64_t i = vend * N - 1;
+        if (i + 1 < n) acc += rosen_term<T>(x[i], x[i + 1]);
+    }
+    if (r == 0) {
+        for (int64_t e = nvec * N; e + 1 < n; ++e) acc += rosen_term<T>(x[e], x[e + 1]);
+        if (nvec == 0 && n >= 2) { /* all terms are tail terms, handled by the loop above */ }
+    }
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
 // ------------------------------------------------------------------ dense quadratic (config 2)
 // One block per column j of the column-major symmetric A: c_j = A[:,j].x (coalesced along
 // the column), g_j = c_j, and the objective partial is x_j*c_j.  No cross-block reduction.
@@ -451,6 +548,34 @@ int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x,
     *grid_out = grid;
     DZO_HIP(hipGetLastError());
     return DZO_OK;
+}
+
+// Fused trial point + objective partials (chained Rosenbrock, 16-B aligned operands, no decorators).
+bool problem_trial_eval_async(dzo_problem_s *p, hipStream_t s, void *x, void *backup, const void *d, double t,
+                              bool first, int32_t *changed, const double **partials, int64_t *count, double *scale) {
+    if (!p || p->kind != DZO_PROBLEM_ROSENBROCK_CHAIN || p->l2 != 0.0 || p->cons_on) return false;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(backup) | reinterpret_cast<uintptr_t>(d)) & 15u) != 0) return false;
+    const int64_t n = p->n;
+    const int vecn = p->dtype == DZO_F64 ? 2 : 4;
+    const int grid = stream_grid(n, vecn * 4);
+    const int64_t rows = (n / vecn + 63) / 64;
+    int egrid = (int)((rows + kBlock - 1) / kBlock);
+    if (egrid < 1) egrid = 1;
+    if ((int64_t)grid + egrid > 2 * kMaxPartialBlocks) return false;    // partials live in p->scratch
+    {
+        DZO_TIMED("lbfgs_trial_objective", s);
+#define L(TT, F) hipLaunchKernelGGL((rosen_trial_eval_kernel<TT, F>), dim3(grid), dim3(kBlock), 0, s, n, (TT *)x, (TT *)backup, (const TT *)d, (TT)t, changed, p->scratch)
+        if (p->dtype == DZO_F64) { if (first) L(double, true); else L(double, false); }
+        else { if (first) L(float, true); else L(float, false); }
+#undef L
+    }
+    {
+        DZO_TIMED("objective_edge_terms", s);
+        if (p->dtype == DZO_F64) hipLaunchKernelGGL(rosen_edge_terms_kernel<double>, dim3(egrid), dim3(kBlock), 0, s, n, (const double *)x, p->scratch + grid);
+        else hipLaunchKernelGGL(rosen_edge_terms_kernel<float>, dim3(egrid), dim3(kBlock), 0, s, n, (const float *)x, p->scratch + grid);
+    }
+    *partials = p->scratch; *count = grid + egrid; *scale = 1.0;
+    return true;
 }
 
 // Objective WITHOUT its final one-block sum: leaves per-block partials so that the caller's
