@@ -152,7 +152,7 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     // earlier), so no HBM traffic disappears: interleaved A/B at n = 1e7 gave -13 us in the small
     // kernels and +11 us in the two-loop kernels, which then absorb the write-back of the dirty
     // lines that the objective kernel used to overlap (792 vs 791 step!()/s, noise +-4).
-    static const bool fuse_trial = getenv("DZO_TUNE_FUSED_TRIAL") ? atoi(getenv("DZO_TUNE_FUSED_TRIAL")) != 0 : false;
+    const bool fuse_trial = getenv("DZO_TUNE_FUSED_TRIAL") ? atoi(getenv("DZO_TUNE_FUSED_TRIAL")) != 0 : false;
     const bool trial_fused = speculate && fuse_trial && !c.box_on &&
                              problem_trial_eval_async(c.problem, s, c.x, c.dx, dir, t, first, c.flag(), &partials, &count, &scale);
     if (!trial_fused) {

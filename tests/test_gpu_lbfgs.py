@@ -591,3 +591,24 @@ def test_handles_release_their_device_memory():
     gc.collect(); dzo.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"leaked {(free0 - free1) >> 20} MiB over 20 create/destroy cycles"
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [2, 3, 5, 127, 128, 129, 257, 4099, 100_003, 1_000_001])
+def test_fused_trial_objective_kernel_equals_separate_kernels(n, dtype, monkeypatch):
+    """DZO_TUNE_FUSED_TRIAL=1 (trial point + objective in one pass, edge terms in a second tiny
+    kernel) is a re-scheduling: same x bit for bit, same objective up to summation order."""
+    m = 3
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("DZO_TUNE_FUSED_TRIAL", fused)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        trials = 0
+        for _ in range(6):
+            opt.step(); trials += opt.last_trials
+        outs.append((opt.current_point.to_host(), opt.current_objective_value, trials, opt.current_gradient.to_host()))
+    (xa, fa, ta, ga), (xb, fb, tb, gb) = outs
+    assert ta == tb
+    assert np.array_equal(xa, xb) and np.array_equal(ga, gb)
+    assert fb == pytest.approx(fa, rel=1e-6 if dtype == np.float32 else 1e-13)
