@@ -251,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void phi_point_kernel(int64_t n, T *__restr
         changed |= (xi != nw);
         nonzero |= (di != (T)0);
     }
+    if (!flags) return;                                          // only the bracket's first point needs them
     __shared__ int lds_flag;
     block_raise_flag(changed, flags, &lds_flag);
     __syncthreads();
@@ -372,6 +373,7 @@ struct dzo_bfgs_s {
     double *upd_part = nullptr;                 // device: 2*ceil(n/4) partials of the fused update scalars
     double *ws = nullptr;                       // device: partials + scalars + flags
     double *host = nullptr;                     // pinned
+    double *host_dev = nullptr;                 // the same buffer as the device sees it
     double *partials() const { return ws; }
     double *scalars() const { return ws + dzo::kMaxPartialBlocks + 8; }       // [overlap, delta]
     double *result() const { return ws + dzo::kMaxPartialBlocks + 16; }       // [f]
@@ -386,9 +388,16 @@ static int32_t bfgs_eval(dzo_bfgs_s *o, const void *point, double *f) {
         *f = round_to_dtype(o->dtype, o->objective(o->cb_ctx, point));
         return DZO_OK;
     }
-    DZO_TRY(problem_eval_async(o->problem, o->stream, point, o->result()));
-    DZO_HIP(hipMemcpyAsync(o->host, o->result(), sizeof(double), hipMemcpyDeviceToHost, o->stream));
-    DZO_HIP(hipStreamSynchronize(o->stream));
+    if (o->problem->kind != DZO_PROBLEM_LSE) {
+        // the objective's finish kernel writes f straight into the pinned host buffer: the D->H copy
+        // of 8 bytes is otherwise a blit kernel plus a gap on the critical path of every trial
+        DZO_TRY(problem_eval_async(o->problem, o->stream, point, o->host_dev));
+        DZO_HIP(hipStreamSynchronize(o->stream));
+    } else {
+        DZO_TRY(problem_eval_async(o->problem, o->stream, point, o->result()));
+        DZO_HIP(hipMemcpyAsync(o->host, o->result(), sizeof(double), hipMemcpyDeviceToHost, o->stream));
+        DZO_HIP(hipStreamSynchronize(o->stream));
+    }
     *f = round_to_dtype(o->dtype, o->host[0]);
     return DZO_OK;
 }
@@ -412,12 +421,15 @@ static int32_t bfgs_norm(dzo_bfgs_s *o, const void *v, double *out) {
 // scratch = x - t*dir, returns the two bracket flags
 static int32_t bfgs_point(dzo_bfgs_s *o, const void *dir, double t, bool *changed, bool *nonzero) {
     hipStream_t s = o->stream;
-    DZO_HIP(hipMemsetAsync(o->flags(), 0, 2 * sizeof(int32_t), s));
+    const bool want_flags = changed || nonzero;
+    // the flag words are cleared (a fill kernel + its launch gap) only when somebody reads them
+    if (want_flags) DZO_HIP(hipMemsetAsync(o->flags(), 0, 2 * sizeof(int32_t), s));
     {
         DZO_TIMED("bfgs_trial_point", s);
         const int grid = stream_grid(o->n, 1);
         DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(phi_point_kernel<T>, dim3(grid), dim3(kBlock), 0, s, o->n, (T *)o->scratch,
-                                                  (T)(o->sign * t), (const T *)dir, (const T *)o->x, o->flags()));
+                                                  (T)(o->sign * t), (const T *)dir, (const T *)o->x,
+                                                  want_flags ? o->flags() : (int32_t *)nullptr));
     }
     DZO_HIP(hipGetLastError());
     if (changed || nonzero) {
@@ -645,7 +657,8 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
     DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));
     DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 32)));
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 32)));
-    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocDefault));
+    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    DZO_HIP(hipHostGetDevicePointer((void **)&o->host_dev, o->host, 0));
     DZO_HIP(hipDeviceSynchronize());
     return DZO_OK;
 }
