@@ -27,6 +27,7 @@
 #include <utility>
 
 #include "dzo_optcore.h"
+#include "dzo_rosen.h"
 
 namespace dzo {
 
@@ -79,6 +80,13 @@ struct dzo_lbfgs_s {
     int32_t last_step_kind = 0;     // 0 quasi-Newton, 1 descent-check replacement, 2 fallback
     bool reset_on_push = false;
     void *xt = nullptr, *gt = nullptr;   // LineSearchEvaluator trial_point / trial_gradient (:26-27)
+    // single-pass step (lbfgs_single_pass_kernel)
+    bool single_pass = true;        // DZO_TUNE_SINGLE_PASS
+    bool gram_ready = false;        // gram_partials hold the dots of the CURRENT history (from the last single pass)
+    int gram_ready_grid = 0;
+    bool scalars_ready = false;     // alpha / coef / scale are valid for the current history and gradient
+    void *halo = nullptr, *xbak = nullptr, *gbak = nullptr;
+    int64_t single_pass_steps = 0, single_pass_rejections = 0;
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 0, gram_bpc = 0;   // tuning knobs (DZO_TUNE_* env, dev only)
@@ -266,38 +274,72 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 }
 
 // Wave-wide sums of FIVE values with 9 cross-lane exchanges instead of 5 x 6: a transposed
-// ("reduce-scatter") butterfly -- at the xor-32 / 16 / 8 steps a lane keeps only part of the
-// values and ships the rest to its partner, so after three steps every lane owns ONE value,
-// which the xor-4 / 2 / 1 steps finish.  Totals come back through v_readlane (scalar, no LDS).
+// ("reduce-scatter") butterfly -- at the first three steps a lane keeps only part of the values
+// and ships the rest to its partner, so that afterwards every lane owns ONE value, which three
+// plain pairwise sums finish.  Totals come back through v_readlane (scalar).
+// No LDS anywhere: the exchanges are DPP moves (quad_perm for lane^1 and lane^2, row_ror:8 for
+// lane^8, two bank-masked row shifts for lane^4) and the gfx950 v_permlane16/32_swap for the
+// cross-row sums.  __shfl_xor compiles to ds_bpermute: six dependent LDS round trips per
+// butterfly, which a kernel running one wave per SIMD (the single-pass step) cannot hide.
 // Fixed association order -> deterministic.
+template <int CTRL, int BANK> __device__ __forceinline__ double dpp_f64(double old, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xF, BANK, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_xor1(double v) { return dpp_f64<0xB1, 0xF>(v, v); }    // quad_perm:[1,0,3,2]
+__device__ __forceinline__ double lane_xor2(double v) { return dpp_f64<0x4E, 0xF>(v, v); }    // quad_perm:[2,3,0,1]
+__device__ __forceinline__ double lane_xor8(double v) { return dpp_f64<0x128, 0xF>(v, v); }   // row_ror:8
+__device__ __forceinline__ double lane_xor4(double v) {
+    const double up = dpp_f64<0x104, 0x5>(v, v);        // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
+    return dpp_f64<0x114, 0xA>(up, v);                  // row_shr:4 into banks 1, 3
+}
+// v[l] + v[l ^ 16] (resp. ^ 32) in every lane: the swap leaves {own, own} in one register and
+// {partner, partner} in the other
+__device__ __forceinline__ double sum_xor16(double v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u2 rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u2 rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
+}
+__device__ __forceinline__ double sum_xor32(double v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u2 rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const u2 rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
+}
+
 __device__ __forceinline__ void wave_sum5(const double (&t)[5], int lane, double (&tot)[5]) {
-    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
-    // xor 32: lanes with b5 = 0 keep {t0,t1,t2}, lanes with b5 = 1 keep {t3,t4}
-    const double r0 = __shfl_xor(b5 ? t[0] : t[3], 32, 64);
-    const double r1 = __shfl_xor(b5 ? t[1] : t[4], 32, 64);
-    const double r2 = __shfl_xor(b5 ? t[2] : 0.0, 32, 64);
-    const double a0 = (b5 ? t[3] : t[0]) + r0;      // t0 | t3
-    const double a1 = (b5 ? t[4] : t[1]) + r1;      // t1 | t4
+    const bool A = (lane & 1) != 0, B = (lane & 2) != 0, C = (lane & 8) != 0;
+    // lane^1: lanes with A = 0 keep {t0,t1,t2}, lanes with A = 1 keep {t3,t4}
+    const double r0 = lane_xor1(A ? t[0] : t[3]);
+    const double r1 = lane_xor1(A ? t[1] : t[4]);
+    const double r2 = lane_xor1(A ? t[2] : 0.0);
+    const double a0 = (A ? t[3] : t[0]) + r0;       // t0 | t3
+    const double a1 = (A ? t[4] : t[1]) + r1;       // t1 | t4
     const double a2 = t[2] + r2;                    // t2 | (unused)
-    // xor 16: (b5,b4) = 00 keeps {t0,t1}, 01 keeps {t2}, 10 keeps {t3}, 11 keeps {t4}
-    const double u0 = b5 ? (b4 ? a0 : a1) : (b4 ? a0 : a2);
-    const double u1 = (!b5 && b4) ? a1 : 0.0;
-    const double v0 = __shfl_xor(u0, 16, 64);
-    const double v1 = __shfl_xor(u1, 16, 64);
-    const double c0 = (b5 ? (b4 ? a1 : a0) : (b4 ? a2 : a0)) + v0;   // t0 | t2 | t3 | t4
+    // lane^2: (A,B) = 00 keeps {t0,t1}, 01 keeps {t2}, 10 keeps {t3}, 11 keeps {t4}
+    const double u0 = A ? (B ? a0 : a1) : (B ? a0 : a2);
+    const double u1 = (!A && B) ? a1 : 0.0;
+    const double v0 = lane_xor2(u0);
+    const double v1 = lane_xor2(u1);
+    const double c0 = (A ? (B ? a1 : a0) : (B ? a2 : a0)) + v0;   // t0 | t2 | t3 | t4
     const double c1 = a1 + v1;                                         // t1 (group 00 only)
-    // xor 8: group 00 splits {t0,t1} by b3; the other groups hold one value already
-    const bool g00 = !b5 && !b4;
-    const double x = __shfl_xor(g00 ? (b3 ? c0 : c1) : c0, 8, 64);
-    double e = (g00 ? (b3 ? c1 : c0) : c0) + x;
-    e += __shfl_xor(e, 4, 64);
-    e += __shfl_xor(e, 2, 64);
-    e += __shfl_xor(e, 1, 64);
+    // lane^8: group 00 splits {t0,t1} by C; the other groups hold one value already
+    const bool g00 = !A && !B;
+    const double x = lane_xor8(g00 ? (C ? c0 : c1) : c0);
+    double e = (g00 ? (C ? c1 : c0) : c0) + x;
+    e += lane_xor4(e);
+    e = sum_xor16(e);
+    e = sum_xor32(e);
     tot[0] = readlane_f64(e, 0);
     tot[1] = readlane_f64(e, 8);
-    tot[2] = readlane_f64(e, 16);
-    tot[3] = readlane_f64(e, 32);
-    tot[4] = readlane_f64(e, 48);
+    tot[2] = readlane_f64(e, 2);
+    tot[3] = readlane_f64(e, 1);
+    tot[4] = readlane_f64(e, 3);
 }
 
 // Gram pass, lane-distributed accumulators (the default).  All waves of all blocks walk the
@@ -451,7 +493,9 @@ struct GramFinishParams {
     int do_recurrence;
     SlotMap map;
     const double *partials;     // reduced values [kGramValues * k]
-    const double *rho;          // by slot
+    double *rho;                // by slot
+    int rho_from_vals;          // 1: rho[pivot] = s_p.y_p taken from the reduced values (single-pass step)
+    int rho_to_f32;
     double *Gyy, *Gsy;
     double *sg, *yg;
     double *alpha, *coef, *scale;
@@ -503,6 +547,10 @@ __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p)
     }
     __syncthreads();
     const int pv = p.pivot, ps = p.map.slot[pv];
+    if (p.rho_from_vals && threadIdx.x == 0) {                     // :505 for the pair pushed by the single pass
+        const double r = vals[pv * kGramValues + 4];
+        p.rho[ps] = p.rho_to_f32 ? (double)(float)r : r;
+    }
     if (threadIdx.x < k) {
         const int i = threadIdx.x, si = p.map.slot[i];
         const double *v = vals + i * kGramValues;
@@ -645,6 +693,261 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
     }
 }
 
+// ============================================================================ single-pass step
+// ONE pass over the history per accepted step (built-in chained Rosenbrock objective).
+//
+// The two-loop needs two dependent sweeps over (S, Y): the dot products with the new gradient
+// (Gram pass) and the combine pass that forms d.  They cannot be fused WITHIN a step, but the
+// combine pass of step t and the Gram pass of step t+1 can: with the history of a tile held in
+// registers the kernel forms d (:438-449), the first trial point x + 1*d (:124), the objective
+// terms of that point, its gradient (the stencil needs one neighbour on each side, taken from
+// overlapping wave-rows), delta_point (:145), delta_gradient (:478-480) and -- still from the
+// same registers -- every dot product the NEXT two-loop needs against the new g / s / y.  If the
+// device-side decision then accepts the trial (the common case: 1.18 objective evaluations per
+// step at config 3) the step is complete and the next direction's scalars follow from a
+// reduce + finish launch; if it rejects, the host falls back to the ordinary kernels with the
+// halved step.  Traffic per accepted step: (2k+2) reads + 7 writes instead of (4k+8) + 6.
+//
+// Layout: a wave owns a row of 64 consecutive 16-B vectors of which the two end vectors are
+// halos (recomputed, not stored), rows overlap by two vectors.  x and g are updated in place by
+// their owner lanes; the halo lanes take x_old / g_old from a snapshot of the row-boundary
+// vectors made by halo_snapshot_kernel just before (so no wave reads an element another wave
+// may already have overwritten).  x_old (:118) and g_old are also written to backups, needed
+// when the trial is rejected.
+constexpr int kFusedMaxK = 20;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
+
+template <typename T> struct FusedParams {
+    int64_t n;
+    int k;                                     // pairs read (history before the push)
+    int k_next;                                // pairs after the push = min(k + 1, m)
+    T t;                                       // first trial step size (1)
+    T *x, *g;                                  // current_point / current_gradient, updated in place
+    const T *halo;                             // [rows][2 sides][x, g] boundary vectors of x_old / g_old
+    T *xbak, *gbak;                            // x_old / g_old for a rejected trial
+    T *d;                                      // step_direction
+    T *s_new, *y_new;                          // delta_point / delta_gradient (spare slots)
+    const double *alpha, *coef, *scale;
+    const T *s[kFusedMaxK];                    // logical pair -> slot base, newest first
+    const T *y[kFusedMaxK];
+    double *gram_partials;                     // [kGramValues * k_next][gridDim.x], post-push order
+    double *obj_partials;                      // [gridDim.x]
+    int32_t *changed;
+    int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain
+};
+
+// boundary vectors of every wave-row (left halo = vector 62 r - 1, right halo = 62 r + 62)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void halo_snapshot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ g,
+                                                               T *__restrict__ halo) {
+    constexpr int N = Vec16<T>::N;
+    const int64_t nvec = n / N;
+    const int64_t rows = (nvec + 61) / 62;
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= rows * 2) return;
+    const int64_t row = id >> 1;
+    const int64_t v = (id & 1) ? row * 62 + 62 : row * 62 - 1;
+    if (v < 0 || v >= nvec) return;
+    T xv[N], gv[N];
+    load16(x + v * N, xv);
+    load16(g + v * N, gv);
+    store16(halo + id * 2 * N, xv);
+    store16(halo + id * 2 * N + N, gv);
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParams<T> p) {
+    constexpr int N = Vec16<T>::N;
+    constexpr int kOwn = 62;                   // vectors owned per wave-row (64 - 2 halos)
+    __shared__ T a_s[kFusedMaxK], c_s[kFusedMaxK];
+    __shared__ double wacc[kWaves][kFusedMaxK + 1][kGramValues];
+    __shared__ double lds[kWaves];
+    __shared__ int lds_flag;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int k = p.k, kn = p.k_next;          // k <= K
+    // pairs i >= k (history not full yet) get a zero coefficient and the host points their table
+    // entries at pair 0, so that every load below is unconditional straight-line code
+    if (threadIdx.x < K) {
+        a_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.alpha[threadIdx.x]) : (T)0;
+        c_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.coef[threadIdx.x]) : (T)0;
+    }
+    __syncthreads();
+    const T scale = k > 0 ? (T)p.scale[0] : (T)1;
+    const int64_t nvec = p.n / N;
+    const int64_t rows = (nvec + kOwn - 1) / kOwn;
+    const int64_t stride = (int64_t)gridDim.x * kWaves;
+    const bool halo_lane = lane == 0 || lane == 63;
+    double acc[kGramValues];
+#pragma unroll
+    for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
+    double fobj = 0;
+    bool diff = false;
+
+    // Lanes beyond either end of x read a clamped (valid) address: their values only ever act as
+    // the outer neighbour of x[0] / x[n-1], which the stencil ignores, and never reach a dot.
+    // 32-bit byte offsets from wave-uniform bases (scalar base + vector offset addressing).
+    auto byte_offset = [&](int64_t row) -> uint32_t {
+        const int64_t v = row * kOwn - 1 + lane;
+        const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);
+        return (uint32_t)(vc * (int64_t)sizeof(T) * N);
+    };
+    auto at = [](const T *base, uint32_t boff) { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + boff); };
+    auto atw = [](T *base, uint32_t boff) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff); };
+    auto load_xg = [&](int64_t row, uint32_t boff, T (&xo)[N], T (&go)[N]) {
+        // halo lanes take x_old / g_old from the snapshot (their owners may already have moved on)
+        const T *h = p.halo + ((row * 2 + (lane == 63 ? 1 : 0)) * 2) * N;
+        load16(halo_lane ? h : at(p.x, boff), xo);
+        load16(halo_lane ? h + N : at(p.g, boff), go);
+    };
+
+    // TWO register sets for the 2K history vectors of a row: all loads of row r+1 are in flight
+    // while row r is computed (the kernel runs one wave per SIMD -- 2 x 2K x 16 B per lane leave no
+    // room for a second resident wave -- so the overlap has to come from inside the wave).  Issuing
+    // the next row's loads BEFORE this row's stores also keeps the store acknowledgements off the
+    // critical path: vmcnt retires in issue order.  Measured at n = 1e7, k = 20: 845 us with one
+    // register set refilled pair by pair during the dots, 537 us for the loads alone.
+    auto issue = [&](int64_t row, uint32_t boff, T (&sv)[K][N], T (&yv)[K][N], T (&xo)[N], T (&go)[N]) {
+        load_xg(row, boff, xo, go);
+#pragma unroll
+        for (int i = 0; i < K; ++i) load16_nt(at(p.y[i], boff), yv[i]);
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) load16_nt(at(p.s[i], boff), sv[i]);
+    };
+    auto compute = [&](int64_t row, uint32_t boff, const T (&sv)[K][N], const T (&yv)[K][N], const T (&xo)[N], const T (&go)[N]) {
+        const int64_t v = row * kOwn - 1 + lane;
+        const bool valid = v >= 0 && v < nvec;
+        const bool owner = valid && lane >= 1 && lane <= kOwn;
+        const int64_t e0 = v * N;
+        // ---- d = the reference's elementwise recurrence (:438-449), as combine_kernel
+        T q[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) q[j] = go[j];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const T a = a_s[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) q[j] = dfma(a, yv[i][j], q[j]);
+        }
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) q[j] = scale * q[j];
+        }
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+            const T c = c_s[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) q[j] = dfma(c, sv[i][j], q[j]);
+        }
+        // ---- first trial point (:124), change flag (:128)
+        T xn[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            xn[j] = dfma(p.t, q[j], xo[j]);
+            diff |= owner && !is_equal(xn[j], xo[j]);
+        }
+        // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
+        const T xprev = __shfl_up(xn[N - 1], 1, 64);
+        const T xnext = __shfl_down(xn[0], 1, 64);
+        T gn[N], sn[N], yn[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T xp = j > 0 ? xn[(j + N - 1) % N] : xprev;
+            const T xq = j + 1 < N ? xn[(j + 1) % N] : xnext;
+            gn[j] = rosen_grad_elem<T>(e0 + j, p.n, xp, xn[j], xq);
+            sn[j] = xn[j] - xo[j];                                  // :145
+            yn[j] = gn[j] - go[j];                                  // :478-480
+            if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
+        }
+        if (owner && !(p.debug_skip & 2)) {
+            store16_nt(atw(p.d, boff), q);
+            store16(atw(p.x, boff), xn);
+            store16(atw(p.xbak, boff), xo);                         // :118
+            store16(atw(p.g, boff), gn);
+            store16(atw(p.gbak, boff), go);
+            store16(atw(p.s_new, boff), sn);
+            store16(atw(p.y_new, boff), yn);
+        }
+        if (!owner) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { gn[j] = (T)0; sn[j] = (T)0; yn[j] = (T)0; }   // halos add nothing to the dots
+        }
+        // ---- dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1)
+        {
+            double t5[kGramValues] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double sx = (double)sn[j], yx = (double)yn[j], gx = (double)gn[j];
+                t5[0] = __builtin_fma(sx, gx, t5[0]);
+                t5[1] = __builtin_fma(yx, gx, t5[1]);
+                t5[2] = __builtin_fma(yx, yx, t5[2]);
+                t5[3] = __builtin_fma(yx, sx, t5[3]);
+                t5[4] = __builtin_fma(sx, yx, t5[4]);
+            }
+            double tot[kGramValues];
+            wave_sum5(t5, lane, tot);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if (i + 1 < kn && !(p.debug_skip & 1)) {
+                double t5[kGramValues] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const double sx = (double)sv[i][j], yx = (double)yv[i][j];
+                    t5[0] = __builtin_fma(sx, (double)gn[j], t5[0]);
+                    t5[1] = __builtin_fma(yx, (double)gn[j], t5[1]);
+                    t5[2] = __builtin_fma(yx, (double)yn[j], t5[2]);
+                    t5[3] = __builtin_fma(yx, (double)sn[j], t5[3]);
+                    t5[4] = __builtin_fma(sx, (double)yn[j], t5[4]);
+                }
+                double tot[kGramValues];
+                wave_sum5(t5, lane, tot);
+                if (lane == i + 1) {
+#pragma unroll
+                    for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
+                }
+            }
+        }
+    };
+    T sA[K][N], yA[K][N], xA[N], gA[N];
+    T sB[K][N], yB[K][N], xB[N], gB[N];
+    int64_t row = (int64_t)blockIdx.x * kWaves + wave;
+    uint32_t boff = row < rows ? byte_offset(row) : 0u;
+    if (row < rows) issue(row, boff, sA, yA, xA, gA);
+    while (row < rows) {
+        int64_t nrow = row + stride;
+        uint32_t nboff = nrow < rows ? byte_offset(nrow) : 0u;
+        if (nrow < rows) issue(nrow, nboff, sB, yB, xB, gB);
+        compute(row, boff, sA, yA, xA, gA);
+        row = nrow; boff = nboff;
+        if (row >= rows) break;
+        nrow = row + stride;
+        nboff = nrow < rows ? byte_offset(nrow) : 0u;
+        if (nrow < rows) issue(nrow, nboff, sA, yA, xA, gA);
+        compute(row, boff, sB, yB, xB, gB);
+        row = nrow; boff = nboff;
+    }
+    // ---- block results: Gram partials (fixed wave order), objective partial, change flag
+    if (lane < kn) {
+#pragma unroll
+        for (int c = 0; c < kGramValues; ++c) wacc[wave][lane][c] = acc[c];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < kn) {
+#pragma unroll
+        for (int c = 0; c < kGramValues; ++c) {
+            const double r = (wacc[0][lane][c] + wacc[1][lane][c]) + (wacc[2][lane][c] + wacc[3][lane][c]);
+            p.gram_partials[(int64_t)(lane * kGramValues + c) * gridDim.x + blockIdx.x] = r;
+        }
+    }
+    block_raise_flag(diff, p.changed, &lds_flag);
+    const double fo = block_sum(fobj, lds);
+    if (threadIdx.x == 0) p.obj_partials[blockIdx.x] = fo;
+}
+
 // ============================================================================ post-gradient
 // :480 delta_gradient = g - delta_gradient, fused with the partials of
 // rho = dot(delta_point, delta_gradient) (:505).
@@ -784,11 +1087,12 @@ static int tune(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals) {
+static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals, bool rho_from_vals = false) {
     hipStream_t s = o->core.stream;
     GramFinishParams fp;
     fp.k = o->k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = 0; fp.do_recurrence = recurrence ? 1 : 0;
     fp.map = make_map(o); fp.partials = vals; fp.rho = o->rho;
+    fp.rho_from_vals = rho_from_vals ? 1 : 0; fp.rho_to_f32 = o->core.dtype == DZO_F32 ? 1 : 0;
     fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     {
@@ -857,18 +1161,41 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     return DZO_ERR_INVALID;
 }
 
+// alpha / coef / scale of the current history and gradient: from the dots the last single-pass step
+// left behind (reduce + finish only), or from Gram passes over the history
+template <typename T> static int32_t gram_scalars(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    const int k = o->k;
+    if (o->scalars_ready) return DZO_OK;
+    if (o->gram_ready) {
+        double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
+        {
+            DZO_TIMED("lbfgs_gram_reduce", c.stream);
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * k), dim3(kBlock), 0, c.stream, o->gram_partials,
+                               o->gram_ready_grid, vals, kGramValues * k, (const double *)nullptr, 0, (double *)nullptr, 0);
+        }
+        DZO_TRY(gram_finish_launch(o, 0, true, vals, true));
+        o->gram_ready = false;
+    } else {
+        if (o->gram_rebuild || o->gram_stale > 1) {
+            // history installed from outside (or pushes without a direction in between): rebuild
+            // every row/column of the caches, oldest pivot first, newest last
+            for (int pv = k - 1; pv >= 1; --pv) DZO_TRY(gram_pass<T>(o, pv, false));
+        }
+        DZO_TRY(gram_pass<T>(o, 0, true));
+    }
+    o->gram_rebuild = false;
+    o->gram_stale = 0;
+    o->scalars_ready = true;
+    return DZO_OK;
+}
+
 template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     const int k = o->k;
-    if (o->gram_rebuild || o->gram_stale > 1) {
-        // history installed from outside (or pushes without a direction in between): rebuild
-        // every row/column of the caches, oldest pivot first, newest last
-        for (int pv = k - 1; pv >= 1; --pv) DZO_TRY(gram_pass<T>(o, pv, false));
-    }
-    DZO_TRY(gram_pass<T>(o, 0, true));
-    o->gram_rebuild = false;
-    o->gram_stale = 0;
+    DZO_TRY(gram_scalars<T>(o));
+    o->scalars_ready = false;          // (a later direction call may see a different gradient)
     CombineParams<T> cp;
     memset(&cp, 0, sizeof(cp));
     cp.n = c.n; cp.g = (const T *)c.g; cp.d = (T *)o->d; cp.k = k;
@@ -939,6 +1266,19 @@ static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
 // rho of the newest pair is summed lazily: in GRAM mode the next direction's gram_reduce launch
 // carries it; anything else that needs rho on the device or host flushes it first.
 static int32_t lbfgs_flush_rho(dzo_lbfgs_s *o) {
+    if (o->gram_ready) {
+        // rho of the newest pair still sits in the single pass's dots (value 4 of pair 0 = s_p.y_p).
+        // Sum it exactly as the coming gram_reduce launch will (same kernel, same order), so that
+        // reading rho_history never changes what the optimizer computes next.
+        OptCore &c = o->core;
+        double *tmp = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves + kGramValues * kMaxHistory - 1;   // last, unused slot of the reduced values
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3(1), dim3(kBlock), 0, c.stream,
+                           o->gram_partials + (size_t)4 * o->gram_ready_grid, o->gram_ready_grid, tmp, 1,
+                           (const double *)nullptr, 0, (double *)nullptr, 0);
+        hipLaunchKernelGGL(finish_to_kernel, dim3(1), dim3(kBlock), 0, c.stream, (const double *)tmp, 1, o->rho + o->newest,
+                           c.dtype == DZO_F32 ? 1 : 0, (const int32_t *)nullptr);
+        DZO_HIP(hipGetLastError());
+    }
     if (!o->rho_pending) return DZO_OK;
     OptCore &c = o->core;
     DZO_TIMED("lbfgs_rho_finish", c.stream);
@@ -1110,9 +1450,10 @@ static int32_t lbfgs_wolfe_search(dzo_lbfgs_s *o, bool *accepted) {
 }
 
 // one line search along o->d followed, when it succeeds, by the post-gradient phase and the push
-static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o) {
+static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected = false) {
     OptCore &c = o->core;
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
+    o->scalars_ready = false; o->gram_ready = false;      // x, g and the history are about to change
     const bool safeguards = o->descent_check || o->sd_fallback;
     if (o->line_search == 1) {
         bool accepted = false;
@@ -1134,7 +1475,7 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o) {
     c.defer_delta = fused;
     c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
     c.speculative_self = o;
-    int32_t rc = core_backtracking_step(c, 1.0, o->d);    // :473
+    int32_t rc = core_backtracking_step(c, 1.0, o->d, first_trial_rejected);    // :473
     const bool speculated = c.speculative_tail != nullptr;
     c.defer_delta = false;
     c.speculative_tail = nullptr;
@@ -1162,6 +1503,102 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
+static inline bool al16v(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// can this step run as one pass over the history?  (built-in chained Rosenbrock, plain options)
+static bool single_pass_ok(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    if (!o->single_pass || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
+    if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post) return false;
+    if (c.iteration_count == 0 || o->k < 1 || o->k > kFusedMaxK) return false;
+    const int vecn = 16 / (int)dtype_size(c.dtype);
+    if (c.n % vecn != 0 || c.n < 4 * vecn || (uint64_t)c.n * dtype_size(c.dtype) >= (1ull << 32)) return false;   // 32-bit byte offsets
+    o->refresh_delta_ptrs();
+    if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg) || !al16v(o->d)) return false;
+    return true;
+}
+
+template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    constexpr int N = Vec16<T>::N;
+    const int k = o->k;
+    const int64_t nvec = c.n / N;
+    const int64_t rows = (nvec + 61) / 62;
+    if (!o->halo) {
+        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
+        DZO_HIP(hipMalloc(&o->halo, (size_t)rows * 2 * 2 * 16));
+        DZO_HIP(hipMalloc(&o->xbak, padded));
+        DZO_HIP(hipMalloc(&o->gbak, padded));
+    }
+    DZO_TRY(gram_scalars<T>(o));                          // alpha / coef / scale of THIS step (:438-448 on scalars)
+    o->scalars_ready = false;
+    o->refresh_delta_ptrs();                              // deltas move to the spare slots
+    FusedParams<T> fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.n = c.n; fp.k = k; fp.k_next = k < o->m ? k + 1 : o->m; fp.t = (T)1;
+    fp.x = (T *)c.x; fp.g = (T *)c.g; fp.halo = (const T *)o->halo; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
+    fp.d = (T *)o->d; fp.s_new = (T *)c.dx; fp.y_new = (T *)c.dg;
+    fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
+    for (int i = 0; i < kFusedMaxK; ++i) {                // entries >= k: any valid vector (zero coefficient)
+        const int slot = o->slot_of(i < k ? i : 0);
+        fp.s[i] = o->s_slot<T>(slot); fp.y[i] = o->y_slot<T>(slot);
+    }
+    fp.gram_partials = o->gram_partials;
+    fp.obj_partials = c.problem->scratch;
+    fp.changed = c.flag();
+    fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
+    // register footprint follows the history length: pick the smallest instantiation that holds m pairs
+    void (*kern)(FusedParams<T>) = o->m <= 8 ? lbfgs_single_pass_kernel<T, 8>
+                                   : o->m <= 16 ? lbfgs_single_pass_kernel<T, 16>
+                                   : lbfgs_single_pass_kernel<T, 20>;
+    int64_t blocks = (rows + kWaves - 1) / kWaves;
+    const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
+    if (blocks > res) blocks = res;
+    if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
+    if (blocks > 2 * kMaxPartialBlocks) blocks = 2 * kMaxPartialBlocks;      // objective partials live in the problem scratch
+    const int grid = (int)(blocks < 1 ? 1 : blocks);
+    if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
+    c.flag_armed = false;
+    {
+        DZO_TIMED("lbfgs_halo_snapshot", s);
+        const int hgrid = (int)((rows * 2 + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(halo_snapshot_kernel<T>, dim3(hgrid), dim3(kBlock), 0, s, c.n, (const T *)c.x, (const T *)c.g, (T *)o->halo);
+    }
+    {
+        DZO_TIMED("lbfgs_single_pass", s);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
+    }
+    launch_decide(c, fp.obj_partials, grid, 1.0);        // :128 / :139 on the device, outcome to pinned host memory
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipEventRecord(c.decided, s));
+    DZO_HIP(hipEventSynchronize(c.decided));
+    const bool changed = reinterpret_cast<int32_t *>(c.host + 4)[0] != 0;
+    c.last_trials = 0;
+    o->single_pass_steps += 1;
+    if (!changed) {                                       // :128-131 (x_new == x_old everywhere, so x and g are intact)
+        c.is_stuck = true;
+        return DZO_OK;
+    }
+    c.last_trials = 1;
+    const double f_new = round_to_dtype(c.dtype, c.host[0]);
+    if (f_new < c.f) {                                    // :139-146, and the kernel already did :478-480
+        c.df = round_to_dtype(c.dtype, f_new - c.f);
+        c.f = f_new;
+        DZO_TRY(lbfgs_finish_push(o, 0, true, true));     // rho of the new pair arrives with the next gram_finish
+        o->gram_ready = true;
+        o->gram_ready_grid = grid;
+        o->gram_stale = 0;
+        return DZO_OK;
+    }
+    // rejected: put x_old and g_old back, then continue the reference loop at its first halving
+    o->single_pass_rejections += 1;
+    const size_t bytes = (size_t)c.n * sizeof(T);
+    DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
+    DZO_HIP(hipMemcpyAsync(c.dx, o->xbak, bytes, hipMemcpyDeviceToDevice, s));   // the :118 backup where the trial kernels expect it
+    return lbfgs_search_and_post(o, true);
+}
+
 static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (c.is_stuck) return DZO_OK;                        // :456-458
@@ -1169,6 +1606,7 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
                 "step! needs objective and gradient (callbacks or a built-in problem)");
     bool quasi = false;
     o->last_step_kind = 0;
+    if (single_pass_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_single_pass<T>(o)); }
     if (c.iteration_count > 0) {
         DZO_TRY(lbfgs_direction(o));                      // :463-471
         quasi = o->k > 0;
@@ -1252,6 +1690,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->gram_fresh_plain = tune("DZO_TUNE_GRAM_FRESH_PLAIN", 1);
     o->gram_skip0 = tune("DZO_TUNE_GRAM_SKIP0", 1);
     o->combine_fresh_plain = tune("DZO_TUNE_COMBINE_FRESH_PLAIN", 1);
+    o->single_pass = tune("DZO_TUNE_SINGLE_PASS", 1) != 0;
     o->fused_post = tune("DZO_TUNE_FUSED_POST", 1) != 0;
     o->combine_nts = tune("DZO_TUNE_COMBINE_NTS", 1) != 0;
     o->combine_u = tune("DZO_TUNE_COMBINE_U", 4);
@@ -1313,6 +1752,9 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (o->S) (void)hipFree(o->S);
     if (o->Y && !o->interleaved) (void)hipFree(o->Y);
     if (o->d) (void)hipFree(o->d);
+    if (o->halo) (void)hipFree(o->halo);
+    if (o->xbak) (void)hipFree(o->xbak);
+    if (o->gbak) (void)hipFree(o->gbak);
     if (o->xt) (void)hipFree(o->xt);
     if (o->gt) (void)hipFree(o->gt);
     if (o->rho) (void)hipFree(o->rho);
@@ -1405,6 +1847,8 @@ int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_TRY(lbfgs_flush_rho(o));                          // a host-driven step follows: settle what the single pass deferred
+    o->gram_ready = false; o->scalars_ready = false;
     o->refresh_delta_ptrs();
     return core_begin_search(o->core);
 }
@@ -1550,6 +1994,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
     o->rho_pending = false;                              // the whole history (and its rho) is replaced
+    o->gram_ready = false; o->scalars_ready = false;
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     const size_t es = dtype_size(c.dtype);

@@ -73,6 +73,7 @@ int32_t core_objective(OptCore &c, double *f_new);
 int32_t core_constraint(OptCore &c, bool *feasible);
 int32_t core_gradient(OptCore &c);
 // take_backtracking_step!(opt, step_size, dir)  :107-154
-int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir);
+int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, bool first_trial_rejected = false);
+void launch_decide(OptCore &c, const double *partials, int64_t count, double scale);
 
 }  // namespace dzo

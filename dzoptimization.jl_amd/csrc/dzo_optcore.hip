@@ -95,6 +95,13 @@ __global__ __launch_bounds__(kBlock) void decide_kernel(double *__restrict__ res
     }
 }
 
+// device-side :128 / :139 decision; with `partials` it also finishes the objective's sum
+void launch_decide(OptCore &c, const double *partials, int64_t count, double scale) {
+    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kBlock), 0, c.stream, c.result(), partials, count, scale,
+                       c.flag(), c.f, c.dtype == DZO_F32 ? 1 : 0, c.status(), c.host_dev);
+    c.flag_armed = true;
+}
+
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
@@ -166,10 +173,8 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
             partials = nullptr;
             DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
         }
-        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kBlock), 0, s, c.result(), partials, count, scale,
-                           c.flag(), c.f, c.dtype == DZO_F32 ? 1 : 0, c.status(), c.host_dev);
+        launch_decide(c, partials, count, scale);
         DZO_HIP(hipGetLastError());
-        c.flag_armed = true;
         DZO_HIP(hipEventRecord(c.decided, s));
         DZO_TRY(c.speculative_tail(c.speculative_self, c.status()));   // gated kernels, enqueued blind
         DZO_HIP(hipEventSynchronize(c.decided));
@@ -232,10 +237,23 @@ int32_t core_gradient(OptCore &c) {
     return problem_grad_async(c.problem, c.stream, c.g, c.x);
 }
 
-int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir) {
+int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, bool first_trial_rejected) {
     DZO_REQUIRE(c.has_objective(), DZO_ERR_STATE, "step! needs an objective (callbacks or built-in problem)");
-    DZO_TRY(core_begin_search(c));                               // :118
     int64_t halvings = 0;
+    if (!first_trial_rejected) {
+        DZO_TRY(core_begin_search(c));                           // :118
+    } else {
+        // the caller already evaluated x_old + step_size*dir (backup of x_old in delta_point) and
+        // found no decrease: continue the loop at its first halving (:151-152)
+        c.search_open = false;
+        c.last_trials = 1;
+        step_size = round_to_dtype(c.dtype, step_size * 0.5);
+        if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
+            DZO_TRY(core_reject(c));
+            c.is_stuck = true;
+            return DZO_OK;
+        }
+    }
     for (;;) {                                                   // :121
         int32_t changed = 0;
         double f_new = 0;

@@ -6,6 +6,7 @@
 // explicit-fma expressions as oracle/dzo_oracle_impl.h so values agree bit-for-bit per term;
 // only the (deterministic, two-stage) reduction order differs.
 #include "dzo_problems.h"
+#include "dzo_rosen.h"
 
 namespace dzo {
 
@@ -29,12 +30,6 @@ __global__ void rosen2d_grad_kernel(T *__restrict__ g, const T *__restrict__ x) 
 }
 
 // ------------------------------------------------------------------ chained Rosenbrock (config 3)
-template <typename T> __device__ __forceinline__ double rosen_term(T xi, T xn) {
-    T t1 = (T)1 - xi;
-    T t2 = dfma(-xi, xi, xn);
-    return (double)dfma((T)100 * t2, t2, t1 * t1);
-}
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void rosen_chain_eval_kernel(int64_t n, const T *__restrict__ x,
                                                                   double *__restrict__ partials) {
@@ -58,20 +53,6 @@ __global__ __launch_bounds__(kBlock) void rosen_chain_eval_kernel(int64_t n, con
     if (t + 1 < n) acc += rosen_term<T>(x[t], x[t + 1]);
     double r = block_sum(acc, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = r;
-}
-
-template <typename T> __device__ __forceinline__ T rosen_grad_elem(int64_t i, int64_t n, T xp, T xi, T xn) {
-    T gi = (T)0;
-    if (i + 1 < n) {
-        T t2 = dfma(-xi, xi, xn);
-        T t1 = (T)1 - xi;
-        gi = dfma((T)-400 * xi, t2, (T)-2 * t1);
-    }
-    if (i > 0) {
-        T t2p = dfma(-xp, xp, xi);
-        gi = dfma((T)200, t2p, gi);
-    }
-    return gi;
 }
 
 template <typename T>
