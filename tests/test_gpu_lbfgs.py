@@ -612,3 +612,83 @@ def test_fused_trial_objective_kernel_equals_separate_kernels(n, dtype, monkeypa
     assert ta == tb
     assert np.array_equal(xa, xb) and np.array_equal(ga, gb)
     assert fb == pytest.approx(fa, rel=1e-6 if dtype == np.float32 else 1e-13)
+
+
+# ------------------------------------------------------------------------------ single-pass step
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m", [(8, 1), (124, 3), (128, 5), (250, 2), (1000, 5), (4098, 20), (100_004, 7), (1_000_000, 20)])
+def test_single_pass_step_hands_the_next_two_loop_its_dots(n, m, dtype):
+    """The single-pass step (csrc/dzo_lbfgs.hip lbfgs_single_pass_kernel) also produces every dot
+    product of the NEXT two-loop.  From identical state: step both sides, then ask both for the
+    next direction -- the GPU one comes from those dots (reduce + finish + combine, no Gram pass)."""
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), 1.0, m)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    # fp32: both sides round every elementwise op to fp32, and the oracle also SUMS in fp32
+    # sequentially (its error grows with n), while the device accumulates in fp64
+    if dtype == np.float32 and n > 5000:
+        pytest.skip("the fp32 oracle's sequential sums are too inaccurate at this n to be a reference")
+    tol = 1e-3 if dtype == np.float32 else 1e-10
+    checked = 0
+    for it in range(3 * m + 12):
+        _sync_from_oracle(opt, ref)
+        opt.step(); ref.step()
+        assert opt.is_stuck == ref.is_stuck
+        if ref.is_stuck:
+            break
+        assert opt.last_trials == ref.last_trials
+        S, Y = ref.history_arrays()
+        want = orc.lbfgs_direction(ref.current_gradient.copy(), S, Y, ref.rho_history)[0]
+        got = opt.compute_step_direction().to_host()
+        assert rel(got.astype(np.float64), want.astype(np.float64)) <= tol, (it, opt.history_count)
+        # rho of the pushed pair comes out of the same pass (s_p.y_p); arbiter: the fp64 dot of the
+        # device's own deltas (the fp32 oracle sums sequentially in fp32)
+        exact = float(np.dot(opt.delta_point.to_host().astype(np.float64), opt.delta_gradient.to_host().astype(np.float64)))
+        assert opt.rho_history[0] == pytest.approx(exact, rel=2e-7 if dtype == np.float32 else 1e-11)
+        checked += 1
+    assert checked >= 3
+
+
+def test_single_pass_and_two_pass_paths_agree_step_by_step(monkeypatch):
+    """DZO_TUNE_SINGLE_PASS=0 restores the Gram pass + combine pass per step: from the same state
+    both produce bit-identical x, delta_point, g, delta_gradient (d is the same elementwise
+    recurrence given the same scalars; the scalars come from the same Gram pass here)."""
+    n, m = 4098, 6
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1.0, m)
+    for _ in range(9):
+        ref.step()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DZO_TUNE_SINGLE_PASS", flag)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        _sync_from_oracle(opt, ref)
+        opt.step()
+        outs.append((opt.current_point.to_host(), opt.delta_point.to_host(), opt.current_gradient.to_host(),
+                     opt.delta_gradient.to_host(), opt.step_direction.to_host(), opt.last_trials))
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert np.array_equal(a, b)
+    assert outs[0][5] == outs[1][5]
+
+
+def test_single_pass_free_run_matches_two_pass_free_run(monkeypatch):
+    """Free run of 12 steps (dots handed from pass to pass, rejected trials included): both paths
+    stay within rounding of each other, then both converge."""
+    n, m = 1000, 5
+    x0 = orc.rosenbrock_chain_x0(n)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DZO_TUNE_SINGLE_PASS", flag)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        xs, tr = [], []
+        for _ in range(12):
+            opt.step(); xs.append(opt.current_point.to_host()); tr.append(opt.last_trials)
+        steps = 12
+        while not opt.is_stuck and steps < 20000:
+            opt.step(); steps += 1
+        runs.append((xs, tr, opt.current_objective_value, opt.current_point.to_host()))
+    assert runs[0][1] == runs[1][1]
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert rel(a, b) <= 1e-10
+    for r in runs:
+        assert r[2] < 1e-20 and np.allclose(r[3], 1.0, atol=1e-9)
