@@ -714,6 +714,12 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
 // vectors made by halo_snapshot_kernel just before (so no wave reads an element another wave
 // may already have overwritten).  x_old (:118) and g_old are also written to backups, needed
 // when the trial is rejected.
+// wave-row geometry: kRowOwn owned vectors in lanes [kRowLead, kRowLead + kRowOwn), one halo lane on
+// each side.  62 uses the whole wave.  (56 owned vectors = seven whole 128-B lines per stream, so
+// that rows start on line boundaries, measured slower: 770 vs 757 us -- 11 % more rows and
+// redundant halo loads cost more than the partial first / last line of every row.)
+constexpr int kRowOwn = 62;
+constexpr int kRowLead = (64 - kRowOwn) / 2;
 constexpr int kFusedMaxK = 20;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
 
 template <typename T> struct FusedParams {
@@ -735,17 +741,17 @@ template <typename T> struct FusedParams {
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain
 };
 
-// boundary vectors of every wave-row (left halo = vector 62 r - 1, right halo = 62 r + 62)
+// boundary vectors of every wave-row (left halo = vector kRowOwn r - 1, right halo = kRowOwn r + kRowOwn)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void halo_snapshot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ g,
                                                                T *__restrict__ halo) {
     constexpr int N = Vec16<T>::N;
     const int64_t nvec = n / N;
-    const int64_t rows = (nvec + 61) / 62;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (id >= rows * 2) return;
     const int64_t row = id >> 1;
-    const int64_t v = (id & 1) ? row * 62 + 62 : row * 62 - 1;
+    const int64_t v = (id & 1) ? row * kRowOwn + kRowOwn : row * kRowOwn - 1;
     if (v < 0 || v >= nvec) return;
     T xv[N], gv[N];
     load16(x + v * N, xv);
@@ -757,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void halo_snapshot_kernel(int64_t n, const 
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
-    constexpr int kOwn = 62;                   // vectors owned per wave-row (64 - 2 halos)
+    constexpr int kOwn = kRowOwn, kLead = kRowLead;
     __shared__ T a_s[kFusedMaxK], c_s[kFusedMaxK];
     __shared__ double wacc[kWaves][kFusedMaxK + 1][kGramValues];
     __shared__ double lds[kWaves];
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     const int64_t nvec = p.n / N;
     const int64_t rows = (nvec + kOwn - 1) / kOwn;
     const int64_t stride = (int64_t)gridDim.x * kWaves;
-    const bool halo_lane = lane == 0 || lane == 63;
+    const bool halo_lane = lane == kLead - 1 || lane == kLead + kOwn;
     double acc[kGramValues];
 #pragma unroll
     for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     // the outer neighbour of x[0] / x[n-1], which the stencil ignores, and never reach a dot.
     // 32-bit byte offsets from wave-uniform bases (scalar base + vector offset addressing).
     auto byte_offset = [&](int64_t row) -> uint32_t {
-        const int64_t v = row * kOwn - 1 + lane;
+        const int64_t v = row * kOwn - kLead + lane;
         const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);
         return (uint32_t)(vc * (int64_t)sizeof(T) * N);
     };
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     auto atw = [](T *base, uint32_t boff) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff); };
     auto load_xg = [&](int64_t row, uint32_t boff, T (&xo)[N], T (&go)[N]) {
         // halo lanes take x_old / g_old from the snapshot (their owners may already have moved on)
-        const T *h = p.halo + ((row * 2 + (lane == 63 ? 1 : 0)) * 2) * N;
+        const T *h = p.halo + ((row * 2 + (lane == kLead + kOwn ? 1 : 0)) * 2) * N;
         load16(halo_lane ? h : at(p.x, boff), xo);
         load16(halo_lane ? h + N : at(p.g, boff), go);
     };
@@ -808,15 +814,17 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     // register set refilled pair by pair during the dots, 537 us for the loads alone.
     auto issue = [&](int64_t row, uint32_t boff, T (&sv)[K][N], T (&yv)[K][N], T (&xo)[N], T (&go)[N]) {
         load_xg(row, boff, xo, go);
+        if (p.debug_skip & 16) { load16(at(p.y[0], boff), yv[0]); load16(at(p.s[0], boff), sv[0]); }
+        else { load16_nt(at(p.y[0], boff), yv[0]); load16_nt(at(p.s[0], boff), sv[0]); }
 #pragma unroll
-        for (int i = 0; i < K; ++i) load16_nt(at(p.y[i], boff), yv[i]);
+        for (int i = 1; i < K; ++i) load16_nt(at(p.y[i], boff), yv[i]);
 #pragma unroll
-        for (int i = K - 1; i >= 0; --i) load16_nt(at(p.s[i], boff), sv[i]);
+        for (int i = K - 1; i >= 1; --i) load16_nt(at(p.s[i], boff), sv[i]);
     };
     auto compute = [&](int64_t row, uint32_t boff, const T (&sv)[K][N], const T (&yv)[K][N], const T (&xo)[N], const T (&go)[N]) {
-        const int64_t v = row * kOwn - 1 + lane;
+        const int64_t v = row * kOwn - kLead + lane;
         const bool valid = v >= 0 && v < nvec;
-        const bool owner = valid && lane >= 1 && lane <= kOwn;
+        const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
         const int64_t e0 = v * N;
         // ---- d = the reference's elementwise recurrence (:438-449), as combine_kernel
         T q[N];
@@ -859,13 +867,15 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
         }
         if (owner && !(p.debug_skip & 2)) {
+            // non-temporal stores throughout: 7 n T of fresh dirty lines otherwise sit in the Infinity
+            // Cache and their write-back lands on the next pass (measured inside step!: 910 -> 815 us)
             store16_nt(atw(p.d, boff), q);
-            store16(atw(p.x, boff), xn);
-            store16(atw(p.xbak, boff), xo);                         // :118
-            store16(atw(p.g, boff), gn);
-            store16(atw(p.gbak, boff), go);
-            store16(atw(p.s_new, boff), sn);
-            store16(atw(p.y_new, boff), yn);
+            store16_nt(atw(p.x, boff), xn);
+            store16_nt(atw(p.xbak, boff), xo);                      // :118
+            store16_nt(atw(p.g, boff), gn);
+            store16_nt(atw(p.gbak, boff), go);
+            store16_nt(atw(p.s_new, boff), sn);
+            store16_nt(atw(p.y_new, boff), yn);
         }
         if (!owner) {
 #pragma unroll
@@ -1524,7 +1534,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     constexpr int N = Vec16<T>::N;
     const int k = o->k;
     const int64_t nvec = c.n / N;
-    const int64_t rows = (nvec + 61) / 62;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     if (!o->halo) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
         DZO_HIP(hipMalloc(&o->halo, (size_t)rows * 2 * 2 * 16));
