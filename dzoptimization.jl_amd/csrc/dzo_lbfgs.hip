@@ -57,6 +57,8 @@ struct dzo_lbfgs_s {
     double *alpha = nullptr;        // [kMaxHistory] logical order (newest first)
     double *coef = nullptr;         // [kMaxHistory] alpha_i + beta_i
     double *scale = nullptr;        // [1] -rho_1 / (y_1.y_1)   (:444)
+    double *alpha_sp = nullptr, *coef_sp = nullptr, *scale_sp = nullptr;   // the NEXT step's scalars, computed speculatively
+    bool spec_scalars = false;      // ... and valid (swapped in when that step starts)
     double *Gyy = nullptr, *Gsy = nullptr;  // [(m+1)^2]
     double *sg = nullptr, *yg = nullptr;    // [kMaxHistory]
     double *gram_partials = nullptr;        // [kGramValues*kMaxHistory][gram_grid]
@@ -85,7 +87,9 @@ struct dzo_lbfgs_s {
     bool gram_ready = false;        // gram_partials hold the dots of the CURRENT history (from the last single pass)
     int gram_ready_grid = 0;
     bool scalars_ready = false;     // alpha / coef / scale are valid for the current history and gradient
-    void *halo = nullptr, *xbak = nullptr, *gbak = nullptr;
+    void *halo = nullptr, *xbak = nullptr, *gbak = nullptr;   // halo: two snapshots, ping-pong
+    int halo_cur = 0;               // which half the next pass reads
+    bool halo_valid = false;        // ... and whether the last pass already filled it
     int64_t single_pass_steps = 0, single_pass_rejections = 0;
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
@@ -496,6 +500,7 @@ struct GramFinishParams {
     double *rho;                // by slot
     int rho_from_vals;          // 1: rho[pivot] = s_p.y_p taken from the reduced values (single-pass step)
     int rho_to_f32;
+    const int32_t *gate;        // speculative launch: run only if *gate == 1
     double *Gyy, *Gsy;
     double *sg, *yg;
     double *alpha, *coef, *scale;
@@ -508,8 +513,10 @@ struct GramFinishParams {
 __global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
                                                              double *__restrict__ vals, int nvals,
                                                              const double *__restrict__ rho_partials, int rho_count,
-                                                             double *__restrict__ rho_dst, int rho_to_f32) {
+                                                             double *__restrict__ rho_dst, int rho_to_f32,
+                                                             const int32_t *__restrict__ gate = nullptr) {
     __shared__ double lds[kWaves];
+    if (gate && *gate != 1) return;            // speculative launch: only after an accepted trial
     if ((int)blockIdx.x == nvals) {
         const double r = reduce_partials_all(rho_partials, rho_count, lds);
         if (threadIdx.x == 0) rho_dst[0] = rho_to_f32 ? (double)(float)r : r;
@@ -532,6 +539,7 @@ __global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__res
 //     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
 //     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
 __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p) {
+    if (p.gate && *p.gate != 1) return;
     __shared__ double vals[kGramValues * kMaxHistory];
     __shared__ double yy[kMaxHistory][kMaxHistory + 1];
     __shared__ double sy[kMaxHistory][kMaxHistory + 1];
@@ -729,6 +737,7 @@ template <typename T> struct FusedParams {
     T t;                                       // first trial step size (1)
     T *x, *g;                                  // current_point / current_gradient, updated in place
     const T *halo;                             // [rows][2 sides][x, g] boundary vectors of x_old / g_old
+    T *halo_next;                              // the same for the next pass (boundary vectors of x_new / g_new)
     T *xbak, *gbak;                            // x_old / g_old for a rejected trial
     T *d;                                      // step_direction
     T *s_new, *y_new;                          // delta_point / delta_gradient (spare slots)
@@ -876,6 +885,16 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             store16_nt(atw(p.gbak, boff), go);
             store16_nt(atw(p.s_new, boff), sn);
             store16_nt(atw(p.y_new, boff), yn);
+            // the first / last owned vector of a row is the right / left halo of the neighbouring row
+            // in the NEXT pass: leave it there now and that pass needs no snapshot kernel
+            if (lane == kLead && row > 0) {
+                T *h = p.halo_next + (((row - 1) * 2 + 1) * 2) * N;
+                store16(h, xn); store16(h + N, gn);
+            }
+            if (lane == kLead + kOwn - 1 && row + 1 < rows) {
+                T *h = p.halo_next + (((row + 1) * 2 + 0) * 2) * N;
+                store16(h, xn); store16(h + N, gn);
+            }
         }
         if (!owner) {
 #pragma unroll
@@ -1097,14 +1116,17 @@ static int tune(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals, bool rho_from_vals = false) {
+static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals, bool rho_from_vals = false,
+                                  const int32_t *gate = nullptr) {
     hipStream_t s = o->core.stream;
     GramFinishParams fp;
+    fp.gate = gate;
     fp.k = o->k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = 0; fp.do_recurrence = recurrence ? 1 : 0;
     fp.map = make_map(o); fp.partials = vals; fp.rho = o->rho;
     fp.rho_from_vals = rho_from_vals ? 1 : 0; fp.rho_to_f32 = o->core.dtype == DZO_F32 ? 1 : 0;
     fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
+    if (gate) { fp.alpha = o->alpha_sp; fp.coef = o->coef_sp; fp.scale = o->scale_sp; }   // next step's set
     {
         DZO_TIMED("lbfgs_gram_finish", s);
         hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(kBlock), 0, s, fp);
@@ -1176,6 +1198,12 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
 template <typename T> static int32_t gram_scalars(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     const int k = o->k;
+    if (o->spec_scalars) {                                // computed behind the previous step's decision
+        std::swap(o->alpha, o->alpha_sp); std::swap(o->coef, o->coef_sp); std::swap(o->scale, o->scale_sp);
+        o->spec_scalars = false;
+        o->gram_ready = false; o->gram_rebuild = false; o->gram_stale = 0;
+        return DZO_OK;
+    }
     if (o->scalars_ready) return DZO_OK;
     if (o->gram_ready) {
         double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
@@ -1464,6 +1492,7 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     OptCore &c = o->core;
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
     o->scalars_ready = false; o->gram_ready = false;      // x, g and the history are about to change
+    o->spec_scalars = false; o->halo_valid = false;
     const bool safeguards = o->descent_check || o->sd_fallback;
     if (o->line_search == 1) {
         bool accepted = false;
@@ -1537,7 +1566,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     if (!o->halo) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
-        DZO_HIP(hipMalloc(&o->halo, (size_t)rows * 2 * 2 * 16));
+        DZO_HIP(hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16));
         DZO_HIP(hipMalloc(&o->xbak, padded));
         DZO_HIP(hipMalloc(&o->gbak, padded));
     }
@@ -1547,7 +1576,10 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     FusedParams<T> fp;
     memset(&fp, 0, sizeof(fp));
     fp.n = c.n; fp.k = k; fp.k_next = k < o->m ? k + 1 : o->m; fp.t = (T)1;
-    fp.x = (T *)c.x; fp.g = (T *)c.g; fp.halo = (const T *)o->halo; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
+    const size_t halo_elems = (size_t)rows * 2 * 2 * N;
+    fp.x = (T *)c.x; fp.g = (T *)c.g; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
+    fp.halo = (const T *)o->halo + (size_t)o->halo_cur * halo_elems;
+    fp.halo_next = (T *)o->halo + (size_t)(o->halo_cur ^ 1) * halo_elems;
     fp.d = (T *)o->d; fp.s_new = (T *)c.dx; fp.y_new = (T *)c.dg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     for (int i = 0; i < kFusedMaxK; ++i) {                // entries >= k: any valid vector (zero coefficient)
@@ -1570,11 +1602,13 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int grid = (int)(blocks < 1 ? 1 : blocks);
     if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
     c.flag_armed = false;
-    {
+    if (!o->halo_valid) {                                 // (after an accepted single pass the halos are already there)
         DZO_TIMED("lbfgs_halo_snapshot", s);
         const int hgrid = (int)((rows * 2 + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(halo_snapshot_kernel<T>, dim3(hgrid), dim3(kBlock), 0, s, c.n, (const T *)c.x, (const T *)c.g, (T *)o->halo);
+        hipLaunchKernelGGL(halo_snapshot_kernel<T>, dim3(hgrid), dim3(kBlock), 0, s, c.n, (const T *)c.x, (const T *)c.g,
+                           (T *)o->halo + (size_t)o->halo_cur * halo_elems);
     }
+    o->halo_valid = false;
     {
         DZO_TIMED("lbfgs_single_pass", s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
@@ -1582,6 +1616,22 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     launch_decide(c, fp.obj_partials, grid, 1.0);        // :128 / :139 on the device, outcome to pinned host memory
     DZO_HIP(hipGetLastError());
     DZO_HIP(hipEventRecord(c.decided, s));
+    {
+        // Enqueued BEFORE the host knows the outcome, gated on the device-side decision: the scalar
+        // part of the NEXT two-loop (reduce + recurrence) on the post-push history, so the GPU has
+        // work while the host round-trips and the next step starts with its scalars ready.
+        const int sv_newest = o->newest, sv_k = o->k;
+        o->newest = o->spare(); o->k = fp.k_next;         // as lbfgs_finish_push will leave them
+        double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
+        {
+            DZO_TIMED("lbfgs_gram_reduce", s);
+            hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * o->k), dim3(kBlock), 0, s, o->gram_partials, grid, vals,
+                               kGramValues * o->k, (const double *)nullptr, 0, (double *)nullptr, 0, (const int32_t *)c.status());
+        }
+        int32_t rc = gram_finish_launch(o, 0, true, vals, true, c.status());
+        o->newest = sv_newest; o->k = sv_k;
+        DZO_TRY(rc);
+    }
     DZO_HIP(hipEventSynchronize(c.decided));
     const bool changed = reinterpret_cast<int32_t *>(c.host + 4)[0] != 0;
     c.last_trials = 0;
@@ -1595,10 +1645,12 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     if (f_new < c.f) {                                    // :139-146, and the kernel already did :478-480
         c.df = round_to_dtype(c.dtype, f_new - c.f);
         c.f = f_new;
-        DZO_TRY(lbfgs_finish_push(o, 0, true, true));     // rho of the new pair arrives with the next gram_finish
-        o->gram_ready = true;
-        o->gram_ready_grid = grid;
+        DZO_TRY(lbfgs_finish_push(o, 0, true, true));     // rho of the new pair was set by the gated gram_finish
+        o->spec_scalars = true;                           // alpha_sp / coef_sp / scale_sp hold the next step's scalars
+        o->gram_ready = false;
         o->gram_stale = 0;
+        o->halo_cur ^= 1;
+        o->halo_valid = true;
         return DZO_OK;
     }
     // rejected: put x_old and g_old back, then continue the reference loop at its first halving
@@ -1713,7 +1765,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         const int64_t tiles = (n / (16 / (int64_t)es) + tile_v - 1) / tile_v;
         if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
     }
-    const size_t nscal = (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory +
+    const size_t nscal = (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
                          (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1) + 4 * (size_t)kMaxPartialBlocks;
     double *base = nullptr;
     ALLOC(base, nscal * sizeof(double));
@@ -1724,6 +1776,9 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->alpha = base; base += kMaxHistory;
     o->coef = base; base += kMaxHistory;
     o->scale = base; base += 8;
+    o->alpha_sp = base; base += kMaxHistory;
+    o->coef_sp = base; base += kMaxHistory;
+    o->scale_sp = base; base += 8;
     o->Gyy = base; base += (size_t)m1 * m1;
     o->Gsy = base; base += (size_t)m1 * m1;
     o->sg = base; base += kMaxHistory;
@@ -1858,7 +1913,7 @@ int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_TRY(lbfgs_flush_rho(o));                          // a host-driven step follows: settle what the single pass deferred
-    o->gram_ready = false; o->scalars_ready = false;
+    o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false; o->halo_valid = false;
     o->refresh_delta_ptrs();
     return core_begin_search(o->core);
 }
@@ -2004,7 +2059,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
     o->rho_pending = false;                              // the whole history (and its rho) is replaced
-    o->gram_ready = false; o->scalars_ready = false;
+    o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false; o->halo_valid = false;
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     const size_t es = dtype_size(c.dtype);
