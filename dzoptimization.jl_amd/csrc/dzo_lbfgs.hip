@@ -88,6 +88,7 @@ struct dzo_lbfgs_s {
     int gram_ready_grid = 0;
     bool scalars_ready = false;     // alpha / coef / scale are valid for the current history and gradient
     void *halo = nullptr, *xbak = nullptr, *gbak = nullptr;   // halo: two snapshots, ping-pong
+    void *bak_slab = nullptr, *d_alloc = nullptr;
     int halo_cur = 0;               // which half the next pass reads
     bool halo_valid = false;        // ... and whether the last pass already filled it
     int64_t single_pass_steps = 0, single_pass_rejections = 0;
@@ -878,13 +879,13 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
         if (owner && !(p.debug_skip & 2)) {
             // non-temporal stores throughout: 7 n T of fresh dirty lines otherwise sit in the Infinity
             // Cache and their write-back lands on the next pass (measured inside step!: 910 -> 815 us)
-            store16_nt(atw(p.d, boff), q);
+            if (!(p.debug_skip & 128)) store16_nt(atw(p.d, boff), q);
             store16_nt(atw(p.x, boff), xn);
-            store16_nt(atw(p.xbak, boff), xo);                      // :118
+            if (!(p.debug_skip & 32)) store16_nt(atw(p.xbak, boff), xo);                      // :118
             store16_nt(atw(p.g, boff), gn);
-            store16_nt(atw(p.gbak, boff), go);
-            store16_nt(atw(p.s_new, boff), sn);
-            store16_nt(atw(p.y_new, boff), yn);
+            if (!(p.debug_skip & 32)) store16_nt(atw(p.gbak, boff), go);
+            if (!(p.debug_skip & 64)) store16_nt(atw(p.s_new, boff), sn);
+            if (!(p.debug_skip & 64)) store16_nt(atw(p.y_new, boff), yn);
             // the first / last owned vector of a row is the right / left halo of the neighbouring row
             // in the NEXT pass: leave it there now and that pass needs no snapshot kernel
             if (lane == kLead && row > 0) {
@@ -1567,8 +1568,13 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     if (!o->halo) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
         DZO_HIP(hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16));
-        DZO_HIP(hipMalloc(&o->xbak, padded));
-        DZO_HIP(hipMalloc(&o->gbak, padded));
+        // one slab, the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator
+        // hands out: x, g, d and the backups are written at the same element offset at the same
+        // time, and equal offsets into equally aligned buffers hit the same HBM channel
+        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;
+        DZO_HIP(hipMalloc(&o->bak_slab, 2 * slot + 16 * 1024));
+        o->xbak = (char *)o->bak_slab + 5 * 1024;
+        o->gbak = (char *)o->xbak + slot;
     }
     DZO_TRY(gram_scalars<T>(o));                          // alpha / coef / scale of THIS step (:438-448 on scalars)
     o->scalars_ready = false;
@@ -1744,7 +1750,8 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         ALLOC(o->Y, slab);
         o->pair_stride = o->stride;
     }
-    ALLOC(o->d, (size_t)o->stride * es);
+    ALLOC(o->d_alloc, (size_t)o->stride * es + 4096);
+    o->d = (char *)o->d_alloc + 3 * 1024;             // off the allocator's alignment grid (see xbak / gbak)
     o->gram_u = tune("DZO_TUNE_GRAM_U", 4);
     o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
     o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
@@ -1816,10 +1823,9 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->S) (void)hipFree(o->S);
     if (o->Y && !o->interleaved) (void)hipFree(o->Y);
-    if (o->d) (void)hipFree(o->d);
+    if (o->d_alloc) (void)hipFree(o->d_alloc);
     if (o->halo) (void)hipFree(o->halo);
-    if (o->xbak) (void)hipFree(o->xbak);
-    if (o->gbak) (void)hipFree(o->gbak);
+    if (o->bak_slab) (void)hipFree(o->bak_slab);
     if (o->xt) (void)hipFree(o->xt);
     if (o->gt) (void)hipFree(o->gt);
     if (o->rho) (void)hipFree(o->rho);

@@ -85,6 +85,8 @@ def main():
                 out["lbfgs_gram_pass"] = out[long_name]
             if long_name.startswith("combine_kernel<double"):
                 out["lbfgs_combine"] = out[long_name]
+            if long_name.startswith("lbfgs_single_pass_kernel<double"):
+                out["lbfgs_single_pass"] = out[long_name]
         json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_pmc.json")
