@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1104,6 +1105,8 @@ template <typename T> static int32_t direction_chain(dzo_lbfgs_s *o) {
 // blocks of `kernel` (kBlock threads, static LDS only) that fit on one CU at once; cached
 static int resident_blocks(const void *kernel) {
     static std::map<const void *, int> cache;
+    static std::mutex mu;                      // handles may be driven from different host threads
+    std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(kernel);
     if (it != cache.end()) return it->second;
     int nb = 0;
