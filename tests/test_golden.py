@@ -85,3 +85,36 @@ def test_hip_update_and_trajectories_match_goldens():
     for row in b["steps"]:
         o.step()
         assert rel(o.current_point.to_host(), row["x"]) <= b["tolerance_rel"] and o.last_step_type == row["type"]
+
+
+def _options_opt(make, c):
+    opt = make(c)
+    opt.set_safeguards(True, True)
+    if c["wolfe"]:
+        opt.set_line_search(1, c["c1"], c["c2"], 40)
+    return opt
+
+
+def test_oracle_reproduces_option_goldens():
+    for c in G["lbfgs_options"]:
+        opt = _options_opt(lambda c: orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, c["n"]), np.array(c["x0"]), 1.0, c["m"]), c)
+        for row in c["steps"]:
+            opt.step()
+            assert opt.last_trials == row["trials"] and opt.last_step_kind == row["kind"]
+            assert rel(opt.current_point, row["x"]) <= c["tolerance_rel"]
+            assert opt.last_step_length == pytest.approx(row["last_step_length"], rel=1e-12)
+            assert row["sy"] > 0 or not c["wolfe"]
+
+
+@pytest.mark.gpu
+def test_hip_options_match_goldens():
+    from dzo_loader import dzo
+    for c in G["lbfgs_options"]:
+        x = dzo.DeviceArray.from_host(np.array(c["x0"]))
+        opt = _options_opt(lambda c: dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, c["n"]), None, x, 1.0, c["m"]), c)
+        for row in c["steps"]:
+            opt.step()
+            assert opt.last_trials == row["trials"] and opt.last_step_kind == row["kind"]
+            assert rel(opt.current_point.to_host(), row["x"]) <= c["tolerance_rel"]
+            assert opt.current_objective_value == pytest.approx(row["f"], rel=1e-10)
+            assert opt.last_step_length == pytest.approx(row["last_step_length"], rel=1e-10)
