@@ -77,6 +77,37 @@ __global__ __launch_bounds__(256) void multi_read_write_k(const double2 *__restr
     }
 }
 
+// K nt-read streams + W nt-written streams (the single-pass step's traffic shape: 42 + 7)
+template <int U>
+__global__ __launch_bounds__(256) void multi_read_multi_write_k(const double2 *__restrict__ base, long stride_v, int K, int W, long nv, double2 *__restrict__ out, long ostride_v) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    for (long i = (long)blockIdx.x * 256 * U + threadIdx.x; i < nv; i += (long)gridDim.x * 256 * U) {
+        double2 acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = make_double2(0, 0);
+#pragma unroll 4
+        for (int s = 0; s < K; ++s) {
+            const double2 *p = base + (long)s * stride_v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                long j = i + u * 256;
+                if (j < nv) {
+                    v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(&p[j]));
+                    acc[u].x = __builtin_fma(1.0001, v.x, acc[u].x);
+                    acc[u].y = __builtin_fma(1.0001, v.y, acc[u].y);
+                }
+            }
+        }
+        for (int w = 0; w < W; ++w) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                long j = i + u * 256;
+                if (j < nv) { v2 o; o.x = acc[u].x + w; o.y = acc[u].y; __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(&out[(long)w * ostride_v + j])); }
+            }
+        }
+    }
+}
+
 // blocked layout: [chunk][slot][CHV vectors]; block-iteration handles one chunk of CHV vectors
 template <int CHV>
 __global__ __launch_bounds__(256) void blocked_read_k(const double2 *__restrict__ base, int K, int slots, long nchunks, double *out) {
@@ -134,6 +165,19 @@ int main(int argc, char **argv) {
         double m4n = time_ms([&] { hipLaunchKernelGGL((multi_read_write_k<4, true>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, nv, out2); }, 10);
         printf("read41+write1 grid=%5d  U2 %.1f us (%.0f GB/s)  U4 %.1f us (%.0f GB/s)  U4-ntstore %.1f us (%.0f GB/s)\n", grid,
                m2 * 1e3, 42.0 * n * 8 / m2 / 1e6, m4 * 1e3, 42.0 * n * 8 / m4 / 1e6, m4n * 1e3, 42.0 * n * 8 / m4n / 1e6);
+    }
+    {   // 42 reads + 7 writes (single-pass step)
+        double2 *wout; const long ostride = nv + 64;
+        CK(hipMalloc(&wout, sizeof(double2) * ostride * 7));
+        for (int g : {1, 2, 4, 8}) {
+            int grid = cus * g;
+            double m1 = time_ms([&] { hipLaunchKernelGGL((multi_read_multi_write_k<1>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, 7, nv, wout, ostride); }, 10);
+            double m2 = time_ms([&] { hipLaunchKernelGGL((multi_read_multi_write_k<2>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, 7, nv, wout, ostride); }, 10);
+            double m4 = time_ms([&] { hipLaunchKernelGGL((multi_read_multi_write_k<4>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, 7, nv, wout, ostride); }, 10);
+            printf("read41+write7 grid=%5d  U1 %.1f us (%.0f GB/s)  U2 %.1f us (%.0f GB/s)  U4 %.1f us (%.0f GB/s)\n", grid,
+                   m1 * 1e3, 48.0 * n * 8 / m1 / 1e6, m2 * 1e3, 48.0 * n * 8 / m2 / 1e6, m4 * 1e3, 48.0 * n * 8 / m4 / 1e6);
+        }
+        CK(hipFree(wout));
     }
     {   // blocked layout with 41 of 42 slots
         const int slots = 42;
