@@ -108,6 +108,30 @@ __global__ __launch_bounds__(256) void multi_read_multi_write_k(const double2 *_
     }
 }
 
+// single-pass shape on a BLOCKED history mirror [row][slot][64 vectors]: per wave-row 40 slots read
+// (one contiguous 40 KiB), 2 slots written in place, plus 2 separate read streams (x, g) and
+// 5 + 2 separate written streams (d, x, g, backups + the canonical copies of the new pair)
+__global__ __launch_bounds__(256) void blocked_rw_k(const double2 *__restrict__ hist, int slots, long rows,
+                                                    const double2 *__restrict__ xs, long xstride, double2 *__restrict__ out, long ostride, int W) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const double2 *h = hist + row * (long)slots * 64 + lane;
+        double2 acc = make_double2(0, 0);
+#pragma unroll 8
+        for (int s = 0; s < 40; ++s) {
+            v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(&h[(long)s * 64]));
+            acc.x = __builtin_fma(1.0001, v.x, acc.x); acc.y = __builtin_fma(1.0001, v.y, acc.y);
+        }
+        for (int s = 0; s < 2; ++s) { double2 v = xs[(long)s * xstride + row * 64 + lane]; acc.x += v.x; acc.y += v.y; }
+        v2 o; o.x = acc.x; o.y = acc.y;
+        double2 *hw = const_cast<double2 *>(hist) + row * (long)slots * 64 + lane;
+        __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(&hw[40L * 64]));
+        __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(&hw[41L * 64]));
+        for (int w = 0; w < W; ++w) __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(&out[(long)w * ostride + row * 64 + lane]));
+    }
+}
+
 // blocked layout: [chunk][slot][CHV vectors]; block-iteration handles one chunk of CHV vectors
 template <int CHV>
 __global__ __launch_bounds__(256) void blocked_read_k(const double2 *__restrict__ base, int K, int slots, long nchunks, double *out) {
@@ -176,6 +200,19 @@ int main(int argc, char **argv) {
             double m4 = time_ms([&] { hipLaunchKernelGGL((multi_read_multi_write_k<4>), dim3(grid), dim3(256), 0, 0, buf, stride_v, 41, 7, nv, wout, ostride); }, 10);
             printf("read41+write7 grid=%5d  U1 %.1f us (%.0f GB/s)  U2 %.1f us (%.0f GB/s)  U4 %.1f us (%.0f GB/s)\n", grid,
                    m1 * 1e3, 48.0 * n * 8 / m1 / 1e6, m2 * 1e3, 48.0 * n * 8 / m2 / 1e6, m4 * 1e3, 48.0 * n * 8 / m4 / 1e6);
+        }
+        CK(hipFree(wout));
+    }
+    {   // single-pass shape on a blocked mirror
+        double2 *wout; const long ostride = nv + 64;
+        CK(hipMalloc(&wout, sizeof(double2) * ostride * 7));
+        const long rows = nv / 64;
+        for (int g : {1, 2, 4}) {
+            int grid = cus * g;
+            double m5 = time_ms([&] { hipLaunchKernelGGL(blocked_rw_k, dim3(grid), dim3(256), 0, 0, buf, 42, rows, buf, stride_v, wout, ostride, 5); }, 10);
+            double m7 = time_ms([&] { hipLaunchKernelGGL(blocked_rw_k, dim3(grid), dim3(256), 0, 0, buf, 42, rows, buf, stride_v, wout, ostride, 7); }, 10);
+            printf("blocked mirror 40r(contig)+2r + 2w(in place)+5w grid=%5d  %.1f us (%.0f GB/s);  +7w: %.1f us (%.0f GB/s)\n", grid,
+                   m5 * 1e3, 49.0 * n * 8 / m5 / 1e6, m7 * 1e3, 51.0 * n * 8 / m7 / 1e6);
         }
         CK(hipFree(wout));
     }
