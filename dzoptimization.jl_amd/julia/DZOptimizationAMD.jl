@@ -369,7 +369,20 @@ function GradientDescentOptimizer(objective::BuiltinProblem{T}, ::Any, ls::Quadr
     return GDHandle{T}(h[], length(x0), objective)
 end
 struct GDHandle{T}; handle::Ptr{Cvoid}; n::Int; keep::Any; end
-step!(opt::GDHandle) = (check(ccall((:dzo_gd_step, libdzo), Cint, (Ptr{Cvoid},), opt.handle)); opt)
+step!(opt::GDHandle) = (check(ccall((:dzo_gd_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
+function Base.getproperty(o::GDHandle{T}, s::Symbol) where {T}      # the BFGS-family getters (include/dzo.h)
+    s in (:has_terminated, :has_converged, :is_stuck) && return fill(_bf_i(o, 0) != 0)
+    s === :iteration_count && return fill(Int(_bf_i(o, 1)))
+    s === :current_objective_value && return fill(T(_bf_s(o, 0)))
+    s === :last_step_length && return fill(T(_bf_s(o, 1)))
+    if s in (:current_point, :delta_point, :current_gradient, :delta_gradient, :next_step_direction)
+        w = findfirst(==(s), (:current_point, :delta_point, :current_gradient, :delta_gradient, :next_step_direction)) - 1
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dzo_bfgs_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), getfield(o, :handle), w, p))
+        return HipVector{T}(p[], getfield(o, :n))
+    end
+    return getfield(o, s)
+end
 
 ################################################################################ AdGD
 
@@ -387,5 +400,17 @@ function AdGDOptimizer(::Nothing, objective::BuiltinProblem{T}, ::Any, x0::HipVe
     return AdGDOptimizer{T}(h[], x0, objective)
 end
 step!(opt::AdGDOptimizer) = (check(ccall((:dzo_adgd_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
+_ad_i(o, w) = (v = Ref{Int64}(0); check(ccall((:dzo_adgd_get_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), getfield(o, :handle), w, v)); v[])
+_ad_s(o, w) = (v = Ref{Cdouble}(0); check(ccall((:dzo_adgd_get_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), getfield(o, :handle), w, v)); v[])
+# public fields of src/DZOptimization.jl:179-200
+function Base.getproperty(o::AdGDOptimizer{T}, s::Symbol) where {T}
+    s in (:is_stuck, :has_terminated, :has_converged) && return fill(_ad_i(o, 0) != 0)
+    s === :iteration_count && return fill(Int(_ad_i(o, 1)))
+    s === :current_objective_value && return fill(T(_ad_s(o, 0)))
+    s === :delta_objective_value && return fill(T(_ad_s(o, 1)))
+    s === :current_step_size && return fill(T(_ad_s(o, 2)))
+    s === :previous_step_size && return fill(T(_ad_s(o, 3)))
+    return getfield(o, s)
+end
 
 end # module
