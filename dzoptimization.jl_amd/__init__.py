@@ -589,6 +589,8 @@ class LBFGSOptimizer(_OptBase):
     history_resets = property(lambda s: s._i(8))
     descent_resets = property(lambda s: s._i(9))
     last_step_kind = property(lambda s: s._i(10))
+    single_pass_steps = property(lambda s: s._i(11))          # informational
+    single_pass_rejections = property(lambda s: s._i(12))
 
     def compute_step_direction(self):
         """``compute_lbfgs_step_direction!`` (:430-451)."""

@@ -1975,6 +1975,8 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 8: *value = o->history_resets; break;
     case 9: *value = o->descent_resets; break;
     case 10: *value = o->last_step_kind; break;
+    case 11: *value = o->single_pass_steps; break;
+    case 12: *value = o->single_pass_rejections; break;
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;

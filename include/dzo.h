@@ -192,7 +192,9 @@ int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
  *       fails, retry along -(last_step_length/||g||) g; success clears the (s, y) history
  *       (_history_count[] = 0, :609), failure sets is_stuck.
  * dzo_lbfgs_get_i fields 8 / 9 / 10: history resets, descent-check replacements, kind of the
- * last step (0 quasi-Newton, 1 replaced by the descent check, 2 fallback);
+ * last step (0 quasi-Newton, 1 replaced by the descent check, 2 fallback); fields 11 / 12: steps
+ * taken as one sweep over the history (single-pass step) and how many of those had their first
+ * trial rejected (informational);
  * dzo_lbfgs_get_s field 2: last_step_length. */
 int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t opt, int32_t descent_check, int32_t steepest_descent_fallback);
 

@@ -616,7 +616,7 @@ def test_fused_trial_objective_kernel_equals_separate_kernels(n, dtype, monkeypa
 
 # ------------------------------------------------------------------------------ single-pass step
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("n,m", [(8, 1), (124, 3), (128, 5), (250, 2), (1000, 5), (4098, 20), (100_004, 7), (1_000_000, 20)])
+@pytest.mark.parametrize("n,m", [(8, 1), (124, 3), (128, 5), (248, 4), (250, 2), (372, 6), (1000, 5), (4098, 20), (100_004, 7), (1_000_000, 20)])
 def test_single_pass_step_hands_the_next_two_loop_its_dots(n, m, dtype):
     """The single-pass step (csrc/dzo_lbfgs.hip lbfgs_single_pass_kernel) also produces every dot
     product of the NEXT two-loop.  From identical state: step both sides, then ask both for the
@@ -692,3 +692,23 @@ def test_single_pass_free_run_matches_two_pass_free_run(monkeypatch):
         assert rel(a, b) <= 1e-10
     for r in runs:
         assert r[2] < 1e-20 and np.allclose(r[3], 1.0, atol=1e-9)
+
+
+def test_single_pass_rejected_first_trials_follow_the_reference_loop():
+    """When the single pass's t = 1 trial is rejected, x and g come back from the backups and the
+    halving loop continues on the two-pass kernels (one or more further trials); every such step
+    must still reproduce the oracle's step from the same state."""
+    n, m = 250, 3
+    opt, ref, _ = _gpu_and_oracle(n, m)
+    seen = set()
+    for it in range(60):
+        _sync_from_oracle(opt, ref)
+        opt.step(); ref.step()
+        assert opt.last_trials == ref.last_trials, it
+        seen.add(opt.last_trials)
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-12, it
+        assert np.array_equal(opt.current_gradient.to_host(), orc.Problem(orc.ROSENBROCK_CHAIN, n).grad(opt.current_point.to_host()))
+        assert rel(opt.delta_gradient.to_host(), ref.delta_gradient) <= 1e-9
+        assert np.allclose(opt.rho_history, ref.rho_history, rtol=1e-9)
+    assert opt.single_pass_steps >= 55
+    assert opt.single_pass_rejections >= 3 and {1, 2}.issubset(seen)
