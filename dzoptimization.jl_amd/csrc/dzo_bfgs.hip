@@ -460,6 +460,17 @@ static int32_t bfgs_phi_at_scratch(dzo_bfgs_s *o, double *f, bool *feasible) {
 }
 
 static int32_t bfgs_phi(dzo_bfgs_s *o, const void *dir, double t, double *f) {
+    // built-in dense quadratic: trial point + objective + final sum in one launch, value straight
+    // into pinned host memory (three launches and a D->H copy otherwise, each with its own gap)
+    static const bool fast = getenv("DZO_TUNE_BFGS_PHI_FUSED") ? atoi(getenv("DZO_TUNE_BFGS_PHI_FUSED")) != 0 : true;
+    if (fast && !o->objective && !o->constraint && o->problem &&
+        problem_phi_async(o->problem, o->stream, o->x, dir, round_to_dtype(o->dtype, o->sign * t), o->scratch, nullptr, o->host_dev)) {
+        DZO_HIP(hipGetLastError());
+        DZO_HIP(hipStreamSynchronize(o->stream));
+        o->evals += 1;
+        *f = round_to_dtype(o->dtype, o->host[0]);
+        return DZO_OK;
+    }
     bool feasible;
     DZO_TRY(bfgs_point(o, dir, t, nullptr, nullptr));
     return bfgs_phi_at_scratch(o, f, &feasible);
