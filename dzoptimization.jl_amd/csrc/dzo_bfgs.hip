@@ -378,6 +378,7 @@ struct dzo_bfgs_s {
     double *scalars() const { return ws + dzo::kMaxPartialBlocks + 8; }       // [overlap, delta]
     double *result() const { return ws + dzo::kMaxPartialBlocks + 16; }       // [f]
     int32_t *flags() const { return reinterpret_cast<int32_t *>(ws + dzo::kMaxPartialBlocks + 24); }
+    int32_t *phi_flags() const { return reinterpret_cast<int32_t *>(ws + dzo::kMaxPartialBlocks + 26); }   // [changed, nonzero, differs from ref], kept zero between uses
 };
 
 namespace dzo {
@@ -459,18 +460,31 @@ static int32_t bfgs_phi_at_scratch(dzo_bfgs_s *o, double *f, bool *feasible) {
     return bfgs_eval(o, o->scratch, f);
 }
 
-static int32_t bfgs_phi(dzo_bfgs_s *o, const void *dir, double t, double *f) {
-    // built-in dense quadratic: trial point + objective + final sum in one launch, value straight
-    // into pinned host memory (three launches and a D->H copy otherwise, each with its own gap)
+// Built-in dense quadratic: trial point, objective and the bracket's flags in two launches with ONE
+// host sync (value and flags land in pinned host memory); the plain sequence is trial point,
+// [flags read-back + sync], objective, finish, value read-back + sync, [isequal + read-back + sync].
+// `fused_ok` false: this objective / these options have no such path and nothing was done.
+static int32_t bfgs_phi_fused(dzo_bfgs_s *o, const void *dir, double t, const void *ref, double *f, bool *changed,
+                              bool *nonzero, bool *equal_ref, bool *fused_ok) {
     static const bool fast = getenv("DZO_TUNE_BFGS_PHI_FUSED") ? atoi(getenv("DZO_TUNE_BFGS_PHI_FUSED")) != 0 : true;
-    if (fast && !o->objective && !o->constraint && o->problem &&
-        problem_phi_async(o->problem, o->stream, o->x, dir, round_to_dtype(o->dtype, o->sign * t), o->scratch, nullptr, o->host_dev)) {
-        DZO_HIP(hipGetLastError());
-        DZO_HIP(hipStreamSynchronize(o->stream));
-        o->evals += 1;
-        *f = round_to_dtype(o->dtype, o->host[0]);
-        return DZO_OK;
-    }
+    *fused_ok = fast && !o->objective && !o->constraint && o->problem &&
+                problem_phi_async(o->problem, o->stream, o->x, dir, round_to_dtype(o->dtype, o->sign * t), o->scratch,
+                                  o->phi_flags(), o->host_dev, ref);
+    if (!*fused_ok) return DZO_OK;
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    const int32_t *hf = reinterpret_cast<const int32_t *>(o->host + 4);
+    if (changed) *changed = hf[0] != 0;
+    if (nonzero) *nonzero = hf[1] != 0;
+    if (equal_ref) *equal_ref = hf[2] == 0;
+    *f = round_to_dtype(o->dtype, o->host[0]);
+    return DZO_OK;
+}
+
+static int32_t bfgs_phi(dzo_bfgs_s *o, const void *dir, double t, double *f) {
+    bool fused_ok = false;
+    DZO_TRY(bfgs_phi_fused(o, dir, t, nullptr, f, nullptr, nullptr, nullptr, &fused_ok));
+    if (fused_ok) { o->evals += 1; return DZO_OK; }
     bool feasible;
     DZO_TRY(bfgs_point(o, dir, t, nullptr, nullptr));
     return bfgs_phi_at_scratch(o, f, &feasible);
@@ -499,19 +513,22 @@ static int32_t bfgs_bracket(dzo_bfgs_s *o, const void *dir, double f0, double t0
     if (!finite_t(f0)) return DZO_OK;                            // :64-66
     if (!(t0 > 0) || !finite_t(t0)) return DZO_OK;
     bool changed = false, nonzero = false;
-    DZO_TRY(bfgs_point(o, dir, t0, &changed, &nonzero));         // :71-80
+    double fa = 0;
+    bool feasible = true, have_fa = false;
+    DZO_TRY(bfgs_phi_fused(o, dir, t0, nullptr, &fa, &changed, &nonzero, nullptr, &have_fa));   // :71-80 (+ :104 speculatively)
+    if (!have_fa) DZO_TRY(bfgs_point(o, dir, t0, &changed, &nonzero));
     if (!nonzero) return DZO_OK;                                 // :83-85
     double step = t0;
     bool small = false;
     while (!changed) {                                           // :91-101
         step = round_to_dtype(dt, step + step);
         small = true;
+        have_fa = false;                                         // (the speculative value belonged to a point that did not move)
         if (!finite_t(step)) return DZO_OK;
         DZO_TRY(bfgs_point(o, dir, step, &changed, nullptr));
     }
-    double fa;
-    bool feasible;
-    DZO_TRY(bfgs_phi_at_scratch(o, &fa, &feasible));             // :104,:126
+    if (have_fa) o->evals += 1;
+    else DZO_TRY(bfgs_phi_at_scratch(o, &fa, &feasible));        // :104,:126
     if (small) {                                                 // :107-123
         if (!feasible) return DZO_OK;
         bool eq;
@@ -525,11 +542,13 @@ static int32_t bfgs_bracket(dzo_bfgs_s *o, const void *dir, double f0, double t0
             const double dbl = round_to_dtype(dt, step + step);
             increases += 1;
             double fb;
-            DZO_TRY(bfgs_phi(o, dir, dbl, &fb));
+            bool eq = false, fused_ok = false;
+            DZO_TRY(bfgs_phi_fused(o, dir, dbl, o->ref_point, &fb, nullptr, nullptr, &eq, &fused_ok));   // value and the :150 test together
+            if (fused_ok) o->evals += 1;
+            else DZO_TRY(bfgs_phi(o, dir, dbl, &fb));
             bool stop = (o->max_increases > 0 && increases >= o->max_increases) || !finite_t(fb) || fb > fa;
             if (!stop) {
-                bool eq;
-                DZO_TRY(bfgs_scratch_equals(o, o->ref_point, &eq));  // :150
+                if (!fused_ok) DZO_TRY(bfgs_scratch_equals(o, o->ref_point, &eq));  // :150
                 stop = eq;
             }
             if (stop) { *x1 = step; *f1 = fa; *x2 = dbl; *f2 = fb; return DZO_OK; }   // :151

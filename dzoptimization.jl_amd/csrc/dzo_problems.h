@@ -28,10 +28,12 @@ bool problem_eval_partials_async(dzo_problem_s *p, hipStream_t s, const void *x,
 // this objective / these operands have no fused kernel (the caller then runs trial + objective).
 bool problem_trial_eval_async(dzo_problem_s *p, hipStream_t s, void *x, void *backup, const void *d, double t,
                               bool first, int32_t *changed, const double **partials, int64_t *count, double *scale);
-// f(x + ts*dir) in one launch (dense quadratic): trial point to point_out, bracket flags, value to
-// result_dev[0] (may be pinned host memory).  false when there is no such kernel.
+// f(x + ts*dir) without a trial-point launch (dense quadratic): point to point_out; value to
+// result_dev[0] and, when `flags` (3 zeroed int32 on the device) is given, {point != x, dir != 0,
+// point != ref} to the int32 view of result_dev[4..5] (result_dev may be pinned host memory); the
+// device flags are re-armed.  false when there is no such kernel.
 bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *dir, double ts, void *point_out,
-                       int32_t *flags, double *result_dev);
+                       int32_t *flags, double *result_dev, const void *ref = nullptr);
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void finish_scaled_sum_kernel(const double 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void quadratic_phi_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
                                                                const T *__restrict__ dir, T ts, T *__restrict__ point_out,
-                                                               double *__restrict__ partials, int32_t *__restrict__ flags) {
+                                                               double *__restrict__ partials, int32_t *__restrict__ flags,
+                                                               const T *__restrict__ ref) {
     constexpr int N = Vec16<T>::N;
     __shared__ double lds[kWaves];
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
@@ -327,11 +328,31 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi_kernel(int64_t n, const 
             const T xt = dfma(ts, dj, xo);
             partials[j] = c * (double)xt;
             point_out[j] = xt;
-            if (flags) {
+            if (flags) {                                   // the bracket's flags (:71-80) and its :150 stagnation test
                 if (xo != xt) flags[0] = 1;
                 if (dj != (T)0) flags[1] = 1;
+                if (ref && !is_equal(xt, ref[j])) flags[2] = 1;
             }
         }
+    }
+}
+
+// finish of quadratic_phi_kernel: value and the three flags straight into the pinned host buffer
+// (out[0] = f, int32 view of out[4..5] = flags), flags re-armed for the next evaluation
+__global__ __launch_bounds__(kBlock) void finish_phi_kernel(const double *__restrict__ partials, int64_t count, double scale,
+                                                            double *__restrict__ out, int32_t *__restrict__ flags) {
+    __shared__ double lds[kWaves];
+    double v = 0;
+    for (int64_t i = threadIdx.x; i < count; i += kBlock) v += partials[i];
+    const double r = block_sum(v, lds);
+    if (threadIdx.x == 0) {
+        out[0] = scale * r;
+        if (flags) {
+            int32_t *ho = reinterpret_cast<int32_t *>(out + 4);
+            ho[0] = flags[0]; ho[1] = flags[1]; ho[2] = flags[2];
+            flags[0] = 0; flags[1] = 0; flags[2] = 0;
+        }
+        __threadfence_system();
     }
 }
 
@@ -604,18 +625,18 @@ bool problem_trial_eval_async(dzo_problem_s *p, hipStream_t s, void *x, void *ba
 // f(x + ts*dir) of the dense quadratic in one launch; also materialises the trial point.  false when
 // this objective / these options have no such kernel.
 bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *dir, double ts, void *point_out,
-                       int32_t *flags, double *result_dev) {
+                       int32_t *flags, double *result_dev, const void *ref) {
     if (!p || p->kind != DZO_PROBLEM_QUADRATIC || p->l2 != 0.0 || p->cons_on) return false;
     const int64_t n = p->n;
     DZO_TIMED("objective_quadratic_phi", s);
     const int grid = (int)(n < 65535 ? n : 65535);
     if (p->dtype == DZO_F64)
         hipLaunchKernelGGL(quadratic_phi_kernel<double>, dim3(grid), dim3(kBlock), 0, s, n, (const double *)p->A, (const double *)x,
-                           (const double *)dir, ts, (double *)point_out, p->scratch, flags);
+                           (const double *)dir, ts, (double *)point_out, p->scratch, flags, (const double *)ref);
     else
         hipLaunchKernelGGL(quadratic_phi_kernel<float>, dim3(grid), dim3(kBlock), 0, s, n, (const float *)p->A, (const float *)x,
-                           (const float *)dir, (float)ts, (float *)point_out, p->scratch, flags);
-    hipLaunchKernelGGL(finish_scaled_sum_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, n, 0.5, result_dev);
+                           (const float *)dir, (float)ts, (float *)point_out, p->scratch, flags, (const float *)ref);
+    hipLaunchKernelGGL(finish_phi_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags);
     return true;
 }
 
