@@ -234,8 +234,17 @@ DZO_INSTANTIATE(float)
 
 int32_t dot_blocking(hipStream_t s, int64_t n, int32_t dtype, const void *x, const void *y,
                      double *partials_dev, double *host_pinned, double *out) {
-    DZO_DISPATCH(dtype, launch_dot<T>(s, n, (const T *)x, (const T *)y, partials_dev, partials_dev + kMaxPartialBlocks));
-    DZO_HIP(hipMemcpyAsync(host_pinned, partials_dev + kMaxPartialBlocks, sizeof(double), hipMemcpyDeviceToHost, s));
+    // the finish kernel writes the sum straight into the pinned host scalar when the runtime maps it
+    // for the device (it does for hipHostMalloc memory): an 8-byte D->H copy is a blit kernel plus a
+    // launch gap on the critical path of every blocking reduction
+    double *host_dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&host_dev, host_pinned, 0) == hipSuccess && host_dev) {
+        DZO_DISPATCH(dtype, launch_dot<T>(s, n, (const T *)x, (const T *)y, partials_dev, host_dev));
+    } else {
+        (void)hipGetLastError();
+        DZO_DISPATCH(dtype, launch_dot<T>(s, n, (const T *)x, (const T *)y, partials_dev, partials_dev + kMaxPartialBlocks));
+        DZO_HIP(hipMemcpyAsync(host_pinned, partials_dev + kMaxPartialBlocks, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     DZO_HIP(hipStreamSynchronize(s));
     *out = *host_pinned;
     return DZO_OK;
