@@ -364,6 +364,7 @@ struct dzo_bfgs_s {
     void *d = nullptr;                          // :747 next_step_direction = H*g (not negated)
     void *d_alt = nullptr;                      // second buffer the fused update writes d_next to
     void *scratch = nullptr;                    // :748
+    void *scratch2 = nullptr, *ref_point2 = nullptr;   // trial point / reference point of the second concurrent search
     void *ref_point = nullptr;                  // LineSearchEvaluator.reference_point (:17)
     int32_t max_increases = 0;                  // QuadraticLineSearch.max_increases (:181-188)
     double sign = -1.0;                         // trial point x + sign*t*dir: -1 BFGS (:945), +1 legacy evaluator (:33)
@@ -466,7 +467,7 @@ static int32_t bfgs_phi_at_scratch(dzo_bfgs_s *o, double *f, bool *feasible) {
 // `fused_ok` false: this objective / these options have no such path and nothing was done.
 static int32_t bfgs_phi_fused(dzo_bfgs_s *o, const void *dir, double t, const void *ref, double *f, bool *changed,
                               bool *nonzero, bool *equal_ref, bool *fused_ok) {
-    static const bool fast = getenv("DZO_TUNE_BFGS_PHI_FUSED") ? atoi(getenv("DZO_TUNE_BFGS_PHI_FUSED")) != 0 : true;
+    const bool fast = getenv("DZO_TUNE_BFGS_PHI_FUSED") ? atoi(getenv("DZO_TUNE_BFGS_PHI_FUSED")) != 0 : true;
     *fused_ok = fast && !o->objective && !o->constraint && o->problem &&
                 problem_phi_async(o->problem, o->stream, o->x, dir, round_to_dtype(o->dtype, o->sign * t), o->scratch,
                                   o->phi_flags(), o->host_dev, ref);
@@ -592,6 +593,154 @@ static int32_t bfgs_quadratic_search(dzo_bfgs_s *o, const void *dir, double f0, 
     return DZO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The two line searches of a dense BFGS step (gradient direction :922-925, quasi-Newton direction
+// :929-932) are independent, so they are advanced side by side: each round evaluates the next
+// point of BOTH in one pass over A (quadratic_phi2_kernel) with one host sync.  PhiSearch is
+// bfgs_bracket + bfgs_quadratic_search turned into a resumable state machine: same decisions,
+// same values, same evaluation counts -- only the order in which the two searches' evaluations
+// reach the device changes.
+// ---------------------------------------------------------------------------------------------
+struct PhiSearch {
+    const void *dir = nullptr;
+    void *scratch = nullptr, *ref_point = nullptr;
+    double f0 = 0, t0 = 0;
+    enum { FIRST, DOUBLING, SHRINKING, QUADRATIC, DONE, SEQUENTIAL } state = DONE;
+    double step = 0, fa = 0, req_t = 0, x1 = 0, f1 = 0, x2 = 0, f2 = 0, xb = 0, fb = 0;
+    int32_t increases = 0;
+    bool want = false, req_ref = false;
+    double t_best = 0, f_best = 0;
+};
+
+static void phi_search_to_quadratic(dzo_bfgs_s *o, PhiSearch &q) {      // bfgs_quadratic_search after :195
+    const int32_t dt = o->dtype;
+    q.xb = 0; q.fb = q.f0;                                       // :196
+    if (q.f1 < q.fb) { q.xb = q.x1; q.fb = q.f1; }               // :197-199
+    if (q.f2 < q.fb) { q.xb = q.x2; q.fb = q.f2; }               // :200-202
+    const double d1 = round_to_dtype(dt, q.f0 - q.f1), d2 = round_to_dtype(dt, q.f2 - q.f1);
+    const double sum = round_to_dtype(dt, d1 + d2);              // :203-205
+    if (d1 >= 0 && d2 >= 0 && sum > 0) {                         // :206
+        const double num = round_to_dtype(dt, round_to_dtype(dt, d1 + d1) + sum);
+        const double ratio = round_to_dtype(dt, num / round_to_dtype(dt, sum + sum));   // :207-208
+        q.req_t = round_to_dtype(dt, ratio * q.x1);              // :209
+        q.want = true; q.req_ref = false;
+        q.state = PhiSearch::QUADRATIC;
+    } else {
+        q.t_best = q.xb; q.f_best = q.fb;
+        q.want = false;
+        q.state = PhiSearch::DONE;
+    }
+}
+
+static void phi_search_bracket_done(dzo_bfgs_s *o, PhiSearch &q, double x1, double f1, double x2, double f2) {
+    q.x1 = x1; q.f1 = f1; q.x2 = x2; q.f2 = f2;
+    phi_search_to_quadratic(o, q);
+}
+
+static void phi_search_begin(dzo_bfgs_s *o, PhiSearch &q, const void *dir, double f0, double t0, void *scratch, void *ref_point) {
+    q = PhiSearch();
+    q.dir = dir; q.f0 = f0; q.t0 = t0; q.scratch = scratch; q.ref_point = ref_point;
+    if (!finite_t(f0) || !(t0 > 0) || !finite_t(t0)) {           // :64-66 -> bracket (0, f0, 0, f0)
+        phi_search_bracket_done(o, q, 0, f0, 0, f0);
+        return;
+    }
+    q.state = PhiSearch::FIRST;
+    q.step = t0;
+    q.req_t = t0; q.want = true; q.req_ref = false;
+}
+
+// feed the result of the pending request; may enqueue a device copy (the :136 / :155 reference point)
+static int32_t phi_search_feed(dzo_bfgs_s *o, PhiSearch &q, double f, bool changed, bool nonzero, bool equal_ref) {
+    const int32_t dt = o->dtype;
+    const size_t bytes = (size_t)o->n * dtype_size(dt);
+    q.want = false;
+    switch (q.state) {
+    case PhiSearch::FIRST:
+        if (!nonzero) { phi_search_bracket_done(o, q, 0, q.f0, 0, q.f0); return DZO_OK; }   // :83-85 (the speculative value is dropped)
+        if (!changed) { q.state = PhiSearch::SEQUENTIAL; return DZO_OK; }                  // :91-101 tiny-step path: rare, done sequentially
+        o->evals += 1;
+        q.fa = f;                                                // :104
+        if (q.fa <= q.f0) {                                      // :130
+            q.increases = 0;
+            DZO_HIP(hipMemcpyAsync(q.ref_point, q.scratch, bytes, hipMemcpyDeviceToDevice, o->stream));   // :136
+            q.state = PhiSearch::DOUBLING;
+            q.req_t = round_to_dtype(dt, q.step + q.step); q.increases += 1;
+            q.want = true; q.req_ref = true;
+        } else {
+            q.state = PhiSearch::SHRINKING;
+            q.req_t = round_to_dtype(dt, 0.5 * q.step);
+            q.want = true; q.req_ref = false;
+        }
+        return DZO_OK;
+    case PhiSearch::DOUBLING: {                                  // :143-156
+        o->evals += 1;
+        const double dbl = q.req_t, fb = f;
+        bool stop = (o->max_increases > 0 && q.increases >= o->max_increases) || !finite_t(fb) || fb > q.fa;
+        if (!stop) stop = equal_ref;                             // :150
+        if (stop) { phi_search_bracket_done(o, q, q.step, q.fa, dbl, fb); return DZO_OK; }   // :151
+        q.step = dbl; q.fa = fb;
+        DZO_HIP(hipMemcpyAsync(q.ref_point, q.scratch, bytes, hipMemcpyDeviceToDevice, o->stream));       // :155
+        q.req_t = round_to_dtype(dt, q.step + q.step); q.increases += 1;
+        q.want = true; q.req_ref = true;
+        return DZO_OK;
+    }
+    case PhiSearch::SHRINKING: {                                 // :157-171
+        o->evals += 1;
+        const double hs = q.req_t, fb = f;
+        if (fb <= q.f0) { phi_search_bracket_done(o, q, hs, fb, q.step, q.fa); return DZO_OK; }   // :166
+        if (hs == 0.0) { phi_search_bracket_done(o, q, 0, q.f0, 0, q.f0); return DZO_OK; }
+        q.step = hs; q.fa = fb;
+        q.req_t = round_to_dtype(dt, 0.5 * q.step);
+        q.want = true; q.req_ref = false;
+        return DZO_OK;
+    }
+    case PhiSearch::QUADRATIC:                                   // :210-213
+        o->evals += 1;
+        if (f < q.fb) { q.xb = q.req_t; q.fb = f; }
+        q.t_best = q.xb; q.f_best = q.fb;
+        q.state = PhiSearch::DONE;
+        return DZO_OK;
+    default:
+        return DZO_OK;
+    }
+}
+
+// both searches of a step; false in *done when the objective has no two-request kernel (nothing was evaluated)
+static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, const void *dir_b, double t0_b,
+                                double *t_a, double *f_a, double *t_b, double *f_b, bool *done) {
+    const bool enabled = getenv("DZO_TUNE_BFGS_DUAL_SEARCH") ? atoi(getenv("DZO_TUNE_BFGS_DUAL_SEARCH")) != 0 : true;
+    *done = false;
+    if (!enabled || o->objective || o->constraint || !o->problem || o->problem->kind != DZO_PROBLEM_QUADRATIC ||
+        o->problem->l2 != 0.0 || o->problem->cons_on)
+        return DZO_OK;
+    PhiSearch q[2];
+    phi_search_begin(o, q[0], dir_a, o->f, t0_a, o->scratch, o->ref_point);
+    phi_search_begin(o, q[1], dir_b, o->f, t0_b, o->scratch2, o->ref_point2);
+    while (q[0].want || q[1].want) {
+        const void *dir[2] = {q[0].dir, q[1].dir};
+        const double ts[2] = {round_to_dtype(o->dtype, o->sign * q[0].req_t), round_to_dtype(o->dtype, o->sign * q[1].req_t)};
+        void *out[2] = {q[0].scratch, q[1].scratch};
+        const void *ref[2] = {q[0].want && q[0].req_ref ? q[0].ref_point : nullptr, q[1].want && q[1].req_ref ? q[1].ref_point : nullptr};
+        const bool active[2] = {q[0].want, q[1].want};
+        if (!problem_phi2_async(o->problem, o->stream, o->x, dir, ts, out, ref, active, o->phi_flags(), o->host_dev)) return DZO_OK;
+        DZO_HIP(hipGetLastError());
+        DZO_HIP(hipStreamSynchronize(o->stream));
+        const int32_t *hf = reinterpret_cast<const int32_t *>(o->host + 4);
+        for (int r = 0; r < 2; ++r)
+            if (active[r])
+                DZO_TRY(phi_search_feed(o, q[r], round_to_dtype(o->dtype, o->host[r]), hf[3 * r] != 0, hf[3 * r + 1] != 0, hf[3 * r + 2] == 0));
+    }
+    // the rare tiny-step path (:91-101) is finished with the sequential code
+    double tt[2], ff[2];
+    for (int r = 0; r < 2; ++r) {
+        if (q[r].state == PhiSearch::SEQUENTIAL) DZO_TRY(bfgs_quadratic_search(o, q[r].dir, o->f, q[r].t0, &tt[r], &ff[r]));
+        else { tt[r] = q[r].t_best; ff[r] = q[r].f_best; }
+    }
+    *t_a = tt[0]; *f_a = ff[0]; *t_b = tt[1]; *f_b = ff[1];
+    *done = true;
+    return DZO_OK;
+}
+
 static int32_t bfgs_identity(dzo_bfgs_s *o) {
     DZO_TIMED("bfgs_identity", o->stream);
     const int grid = stream_grid(o->n * o->n, 4);
@@ -632,10 +781,15 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
     const double step_length = o->last_step_length;              // :918
     double grad_norm, bfgs_norm_v;
     DZO_TRY(bfgs_norm(o, o->g, &grad_norm));                     // :921
-    double t_g, f_g, t_b, f_b;
-    DZO_TRY(bfgs_quadratic_search(o, o->g, o->f, round_to_dtype(dt, step_length / grad_norm), &t_g, &f_g));   // :922-925
     DZO_TRY(bfgs_norm(o, o->d, &bfgs_norm_v));                   // :928
-    DZO_TRY(bfgs_quadratic_search(o, o->d, o->f, round_to_dtype(dt, step_length / bfgs_norm_v), &t_b, &f_b)); // :929-932
+    double t_g, f_g, t_b, f_b;
+    bool dual = false;
+    DZO_TRY(bfgs_dual_search(o, o->g, round_to_dtype(dt, step_length / grad_norm), o->d, round_to_dtype(dt, step_length / bfgs_norm_v),
+                             &t_g, &f_g, &t_b, &f_b, &dual));    // :922-925 and :929-932 side by side
+    if (!dual) {
+        DZO_TRY(bfgs_quadratic_search(o, o->g, o->f, round_to_dtype(dt, step_length / grad_norm), &t_g, &f_g));   // :922-925
+        DZO_TRY(bfgs_quadratic_search(o, o->d, o->f, round_to_dtype(dt, step_length / bfgs_norm_v), &t_b, &f_b)); // :929-932
+    }
     if (f_b < o->f && !(f_b > f_g)) {                            // :934
         o->f = f_b;                                              // :937
         o->last_step_length = round_to_dtype(dt, t_b * bfgs_norm_v);   // :938
@@ -671,7 +825,7 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
     const size_t es = dtype_size(o->dtype);
     const size_t vbytes = (size_t)((o->n + 63) / 64 * 64) * es;
     DZO_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
-    void **vecs[] = {&o->x, &o->g, &o->dx, &o->dg, &o->d, &o->d_alt, &o->scratch, &o->ref_point};
+    void **vecs[] = {&o->x, &o->g, &o->dx, &o->dg, &o->d, &o->d_alt, &o->scratch, &o->ref_point, &o->scratch2, &o->ref_point2};
     for (void **v : vecs) {
         hipError_t e = hipMalloc(v, vbytes);
         if (e != hipSuccess) { set_error("out of device memory allocating BFGS vectors"); return DZO_ERR_NOMEM; }
@@ -877,7 +1031,7 @@ int32_t dzo_gd_step(dzo_bfgs_t o) {
 int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
     if (!o) return DZO_OK;
     if (o->stream) (void)hipStreamSynchronize(o->stream);
-    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->H, o->ws, o->upd_part};
+    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->scratch2, o->ref_point2, o->H, o->ws, o->upd_part};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
     if (o->stream) (void)hipStreamDestroy(o->stream);

@@ -14,6 +14,7 @@ struct dzo_problem_s {
     bool bg_on = false; double bg_lo = 0, bg_hi = 0;       // UniformBoxGradientWrapper
     bool cons_on = false; double cons_lo = 0, cons_hi = 0; // UniformBoxConstraint as constraint_function!
     double *scratch = nullptr; // device partials
+    int64_t scratch_doubles = 0;   // usable partials in scratch
     double *result = nullptr;  // device: [f, ...] inside scratch
     double *host = nullptr;    // pinned host scalars
 };
@@ -34,6 +35,9 @@ bool problem_trial_eval_async(dzo_problem_s *p, hipStream_t s, void *x, void *ba
 // device flags are re-armed.  false when there is no such kernel.
 bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *dir, double ts, void *point_out,
                        int32_t *flags, double *result_dev, const void *ref = nullptr);
+bool problem_phi2_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *const dir[2], const double ts[2],
+                        void *const point_out[2], const void *const ref[2], const bool active[2], int32_t *flags,
+                        double *result_dev);
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).

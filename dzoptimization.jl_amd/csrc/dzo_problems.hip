@@ -337,6 +337,87 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi_kernel(int64_t n, const 
     }
 }
 
+// Two line-search evaluations in one pass over A (the two searches of the dense BFGS step run
+// side by side, legacy/DZOptimization.jl:922-932): request r evaluates f(x + ts[r]*dir[r]); each A
+// column is loaded once and used for both.  Per request the arithmetic is that of
+// quadratic_phi_kernel, so every value is bit-identical to a separate evaluation.
+template <typename T> struct PhiRequest {
+    const T *dir;
+    const T *ref;          // may be null
+    T *point_out;
+    T ts;
+    int active;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void quadratic_phi2_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
+                                                                PhiRequest<T> r0, PhiRequest<T> r1,
+                                                                double *__restrict__ partials, int32_t *__restrict__ flags) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[kWaves];
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const T *col = A + j * n;
+        double acc0 = 0, acc1 = 0;
+        const bool vec = ((n % N) == 0);
+        if (vec) {
+            for (int64_t i = (int64_t)threadIdx.x * N; i < n; i += (int64_t)kBlock * N) {
+                T av[N], xv[N], d0[N], d1[N];
+                load16(col + i, av);
+                load16(x + i, xv);
+                load16(r0.dir + i, d0);
+                load16(r1.dir + i, d1);
+#pragma unroll
+                for (int q = 0; q < N; ++q) {
+                    acc0 = __builtin_fma((double)av[q], (double)dfma(r0.ts, d0[q], xv[q]), acc0);
+                    acc1 = __builtin_fma((double)av[q], (double)dfma(r1.ts, d1[q], xv[q]), acc1);
+                }
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+                acc0 = __builtin_fma((double)col[i], (double)dfma(r0.ts, r0.dir[i], x[i]), acc0);
+                acc1 = __builtin_fma((double)col[i], (double)dfma(r1.ts, r1.dir[i], x[i]), acc1);
+            }
+        }
+        const double c0 = block_sum(acc0, lds);
+        const double c1 = block_sum(acc1, lds);
+        if (threadIdx.x == 0) {
+            const T xo = x[j];
+            if (r0.active) {
+                const T dj = r0.dir[j], xt = dfma(r0.ts, dj, xo);
+                partials[j] = c0 * (double)xt;
+                r0.point_out[j] = xt;
+                if (xo != xt) flags[0] = 1;
+                if (dj != (T)0) flags[1] = 1;
+                if (r0.ref && !is_equal(xt, r0.ref[j])) flags[2] = 1;
+            }
+            if (r1.active) {
+                const T dj = r1.dir[j], xt = dfma(r1.ts, dj, xo);
+                partials[n + j] = c1 * (double)xt;
+                r1.point_out[j] = xt;
+                if (xo != xt) flags[3] = 1;
+                if (dj != (T)0) flags[4] = 1;
+                if (r1.ref && !is_equal(xt, r1.ref[j])) flags[5] = 1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void finish_phi2_kernel(const double *__restrict__ partials, int64_t count, double scale,
+                                                             double *__restrict__ out, int32_t *__restrict__ flags) {
+    __shared__ double lds[kWaves];
+    double v0 = 0, v1 = 0;
+    for (int64_t i = threadIdx.x; i < count; i += kBlock) { v0 += partials[i]; v1 += partials[count + i]; }
+    const double s0 = block_sum(v0, lds);
+    const double s1 = block_sum(v1, lds);
+    if (threadIdx.x == 0) {
+        out[0] = scale * s0;
+        out[1] = scale * s1;
+        int32_t *ho = reinterpret_cast<int32_t *>(out + 4);
+        for (int q = 0; q < 6; ++q) { ho[q] = flags[q]; flags[q] = 0; }
+        __threadfence_system();
+    }
+}
+
 // finish of quadratic_phi_kernel: value and the three flags straight into the pinned host buffer
 // (out[0] = f, int32 view of out[4..5] = flags), flags re-armed for the next evaluation
 __global__ __launch_bounds__(kBlock) void finish_phi_kernel(const double *__restrict__ partials, int64_t count, double scale,
@@ -640,6 +721,33 @@ bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const voi
     return true;
 }
 
+// Two evaluations f(x + ts_r*dir_r), r = 0, 1, in one pass over A (either may be inactive); values
+// to result_dev[0..1], flags {changed, nonzero, differs from ref} of request r to the int32 view of
+// result_dev[4..6] at 3r.  `flags` are 6 zeroed int32 on the device, re-armed on return.
+bool problem_phi2_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *const dir[2], const double ts[2],
+                        void *const point_out[2], const void *const ref[2], const bool active[2], int32_t *flags,
+                        double *result_dev) {
+    if (!p || p->kind != DZO_PROBLEM_QUADRATIC || p->l2 != 0.0 || p->cons_on) return false;
+    const int64_t n = p->n;
+    if (p->scratch_doubles < 2 * n) return false;
+    DZO_TIMED("objective_quadratic_phi", s);
+    const int grid = (int)(n < 65535 ? n : 65535);
+    auto launch = [&](auto tag) {
+        using T = decltype(tag);
+        PhiRequest<T> r[2];
+        for (int q = 0; q < 2; ++q) {
+            const int src = active[q] ? q : (active[0] ? 0 : 1);      // an inactive request re-reads the other one's vectors
+            r[q].dir = (const T *)dir[src]; r[q].ref = (const T *)ref[q]; r[q].point_out = (T *)point_out[q];
+            r[q].ts = (T)ts[src]; r[q].active = active[q] ? 1 : 0;
+        }
+        hipLaunchKernelGGL(quadratic_phi2_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, r[0], r[1],
+                           p->scratch, flags);
+    };
+    if (p->dtype == DZO_F64) launch(double{}); else launch(float{});
+    hipLaunchKernelGGL(finish_phi2_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags);
+    return true;
+}
+
 // Objective WITHOUT its final one-block sum: leaves per-block partials so that the caller's
 // decision kernel can do the sum itself (one launch fewer per trial).  Returns false for the
 // objectives whose finish is not a plain scaled sum.
@@ -711,8 +819,9 @@ int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A
     DZO_REQUIRE(kind != DZO_PROBLEM_LSE || c_dev, DZO_ERR_INVALID, "LSE problem needs c");
     dzo_problem_s *p = new dzo_problem_s();
     p->kind = kind; p->n = n; p->dtype = dtype; p->A = A_dev; p->c = c_dev; p->lambda = lambda;
-    const int64_t scratch = (kind == DZO_PROBLEM_QUADRATIC ? (n > 2 * kMaxPartialBlocks ? n : 2 * kMaxPartialBlocks)
+    const int64_t scratch = (kind == DZO_PROBLEM_QUADRATIC ? (2 * n > 2 * kMaxPartialBlocks ? 2 * n : 2 * kMaxPartialBlocks)
                                                            : 2 * kMaxPartialBlocks) + 16;
+    p->scratch_doubles = scratch - 16;
     hipError_t e = hipMalloc((void **)&p->scratch, sizeof(double) * (size_t)scratch);
     if (e != hipSuccess) { delete p; return hip_fail(e, "hipMalloc(problem scratch)", __FILE__, __LINE__); }
     e = hipHostMalloc((void **)&p->host, sizeof(double) * 4, hipHostMallocDefault);

@@ -321,3 +321,29 @@ def test_mfma_update_matches_oracle_within_rounding(n):
     with pytest.raises(dzo.DzoError):
         dzo.update_inverse_hessian_mfma_(dzo.DeviceArray.from_host(np.eye(24)), 1.0, dzo.DeviceArray(24),
                                          dzo.DeviceArray(24), dzo.DeviceArray(24))         # n % 16 != 0
+
+
+@pytest.mark.parametrize("n", [16, 200, 513])
+def test_side_by_side_line_searches_equal_the_sequential_ones(n, monkeypatch):
+    """The dense BFGS step advances its two line searches (gradient and quasi-Newton direction)
+    side by side, two evaluations per pass over A, and forms trial points inside the objective
+    kernel.  Both are re-schedulings: same values, same decisions, same evaluation counts."""
+    A = orc.quadratic_matrix(n)
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    runs = []
+    for dual, fused in (("1", "1"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("DZO_TUNE_BFGS_DUAL_SEARCH", dual)
+        monkeypatch.setenv("DZO_TUNE_BFGS_PHI_FUSED", fused)
+        opt = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+        rows = []
+        for _ in range(20):
+            opt.step()
+            rows.append((opt.current_point.to_host(), opt.current_objective_value, opt.last_step_type,
+                         opt.last_step_length, opt.objective_evaluations))
+            if opt.has_terminated:
+                break
+        runs.append(rows)
+    for other in runs[1:]:
+        assert len(other) == len(runs[0])
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
