@@ -420,6 +420,19 @@ static int32_t bfgs_norm(dzo_bfgs_s *o, const void *v, double *out) {
     return DZO_OK;
 }
 
+// two norms with one host sync (:921 and :928 of the BFGS step): the finish kernels write straight
+// into the pinned host scalars
+static int32_t bfgs_norm_pair(dzo_bfgs_s *o, const void *a, const void *b, double *na, double *nb) {
+    DZO_DISPATCH(o->dtype, launch_dot<T>(o->stream, o->n, (const T *)a, (const T *)a, o->partials(), o->host_dev));
+    DZO_DISPATCH(o->dtype, launch_dot<T>(o->stream, o->n, (const T *)b, (const T *)b, o->upd_part, o->host_dev + 1));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(o->stream));
+    const double sa = o->host[0], sb = o->host[1];
+    *na = o->dtype == DZO_F32 ? (double)sqrtf((float)sa) : sqrt(sa);
+    *nb = o->dtype == DZO_F32 ? (double)sqrtf((float)sb) : sqrt(sb);
+    return DZO_OK;
+}
+
 // scratch = x - t*dir, returns the two bracket flags
 static int32_t bfgs_point(dzo_bfgs_s *o, const void *dir, double t, bool *changed, bool *nonzero) {
     hipStream_t s = o->stream;
@@ -780,8 +793,7 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
     const size_t bytes = (size_t)o->n * dtype_size(dt);
     const double step_length = o->last_step_length;              // :918
     double grad_norm, bfgs_norm_v;
-    DZO_TRY(bfgs_norm(o, o->g, &grad_norm));                     // :921
-    DZO_TRY(bfgs_norm(o, o->d, &bfgs_norm_v));                   // :928
+    DZO_TRY(bfgs_norm_pair(o, o->g, o->d, &grad_norm, &bfgs_norm_v));   // :921, :928
     double t_g, f_g, t_b, f_b;
     bool dual = false;
     DZO_TRY(bfgs_dual_search(o, o->g, round_to_dtype(dt, step_length / grad_norm), o->d, round_to_dtype(dt, step_length / bfgs_norm_v),
