@@ -829,7 +829,8 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
     } else {
         o->has_terminated = true;                                // :989
     }
-    DZO_HIP(hipStreamSynchronize(o->stream));
+    // (no stream sync here: include/dzo.h -- step functions return once the host-side decisions are
+    // made; the getters and the next step's first read-back synchronise)
     return DZO_OK;
 }
 
