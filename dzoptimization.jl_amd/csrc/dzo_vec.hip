@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void axpby_kernel(int64_t n, T a, const T *
 }
 
 template <typename T, bool VEC>
-__global__ __launch_bounds__(kBlock) void scal_oop_kernel(int64_t n, T *dst, T a, const T *x, int nt = 0) {
+__global__ __launch_bounds__(kBlock) void scal_oop_kernel(int64_t n, T *dst, T a, const T *x) {
     constexpr int N = Vec16<T>::N;
     stream_loop<T, VEC>(
         n,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void scal_oop_kernel(int64_t n, T *dst, T a
             load16(x + i, xv);
 #pragma unroll
             for (int j = 0; j < N; ++j) xv[j] = a * xv[j];
-            if (nt) store16_nt(dst + i, xv); else store16(dst + i, xv);
+            store16(dst + i, xv);
         },
         [&](int64_t i) { dst[i] = a * x[i]; });
 }
@@ -194,8 +194,7 @@ template <typename T> void launch_scal_oop(hipStream_t s, int64_t n, T *dst, T a
     if (n <= 0) return;
     DZO_TIMED("scal", s);
     const bool v = aligned16<T>(x) && aligned16<T>(dst);
-    static const int nt = getenv("DZO_TUNE_SCAL_NT") ? atoi(getenv("DZO_TUNE_SCAL_NT")) : 0;   // experiment
-    DZO_LAUNCH_VEC(scal_oop_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, dst, a, x, nt);
+    DZO_LAUNCH_VEC(scal_oop_kernel, T, v, stream_grid(n, Vec16<T>::N * kUnroll), s, n, dst, a, x);
 }
 template <typename T> void launch_scal(hipStream_t s, int64_t n, T a, T *x) { launch_scal_oop<T>(s, n, x, a, x); }
 template <typename T> void launch_fill(hipStream_t s, int64_t n, T a, T *x) {
