@@ -712,3 +712,24 @@ def test_single_pass_rejected_first_trials_follow_the_reference_loop():
         assert np.allclose(opt.rho_history, ref.rho_history, rtol=1e-9)
     assert opt.single_pass_steps >= 55
     assert opt.single_pass_rejections >= 3 and {1, 2}.issubset(seen)
+
+
+def test_history_longer_than_the_single_pass_limit_switches_paths_cleanly():
+    """m = 24 > 20: the single-pass step serves the first 20 steps of the history fill, then the
+    two-pass kernels take over (the dots handed over by the last single pass included)."""
+    n, m = 1000, 24
+    opt, ref, _ = _gpu_and_oracle(n, m)
+    for it in range(40):
+        opt.step(); ref.step()
+        if it < 12:
+            assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
+            assert opt.last_trials == ref.last_trials
+    assert 15 <= opt.single_pass_steps <= 21 and opt.history_count == m
+    # per-step parity from synced state on both sides of the switch
+    opt2, ref2, _ = _gpu_and_oracle(n, m)
+    for it in range(30):
+        _sync_from_oracle(opt2, ref2)
+        opt2.step(); ref2.step()
+        assert opt2.last_trials == ref2.last_trials, it
+        assert rel(opt2.step_direction.to_host(), ref2.step_direction) <= TOL_DIRECTION, it
+        assert rel(opt2.current_point.to_host(), ref2.current_point) <= 1e-12, it
