@@ -1568,9 +1568,9 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int k = o->k;
     const int64_t nvec = c.n / N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
-    if (!o->halo) {
+    if (!o->halo) DZO_HIP(hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16));
+    if (!o->bak_slab) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
-        DZO_HIP(hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16));
         // one slab, the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator
         // hands out: x, g, d and the backups are written at the same element offset at the same
         // time, and equal offsets into equally aligned buffers hit the same HBM channel
@@ -1642,16 +1642,17 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
         DZO_TRY(rc);
     }
     DZO_HIP(hipEventSynchronize(c.decided));
-    const bool changed = reinterpret_cast<int32_t *>(c.host + 4)[0] != 0;
+    // the host follows the DEVICE's decision (the gated kernels already acted on it): 0 reject, 1 accept, 2 stuck
+    const int32_t status = reinterpret_cast<int32_t *>(c.host + 3)[0];
     c.last_trials = 0;
     o->single_pass_steps += 1;
-    if (!changed) {                                       // :128-131 (x_new == x_old everywhere, so x and g are intact)
+    if (status == 2) {                                    // :128-131 (x_new == x_old everywhere, so x and g are intact)
         c.is_stuck = true;
         return DZO_OK;
     }
     c.last_trials = 1;
     const double f_new = round_to_dtype(c.dtype, c.host[0]);
-    if (f_new < c.f) {                                    // :139-146, and the kernel already did :478-480
+    if (status == 1) {                                    // :139-146 (f_new < f), and the kernel already did :478-480
         c.df = round_to_dtype(c.dtype, f_new - c.f);
         c.f = f_new;
         DZO_TRY(lbfgs_finish_push(o, 0, true, true));     // rho of the new pair was set by the gated gram_finish
