@@ -365,6 +365,7 @@ struct dzo_bfgs_s {
     void *d_alt = nullptr;                      // second buffer the fused update writes d_next to
     void *scratch = nullptr;                    // :748
     void *scratch2 = nullptr, *ref_point2 = nullptr;   // trial point / reference point of the second concurrent search
+    void *spec_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // trial points of the speculative evaluations (two per search)
     void *ref_point = nullptr;                  // LineSearchEvaluator.reference_point (:17)
     int32_t max_increases = 0;                  // QuadraticLineSearch.max_increases (:181-188)
     double sign = -1.0;                         // trial point x + sign*t*dir: -1 BFGS (:945), +1 legacy evaluator (:33)
@@ -379,7 +380,7 @@ struct dzo_bfgs_s {
     double *scalars() const { return ws + dzo::kMaxPartialBlocks + 8; }       // [overlap, delta]
     double *result() const { return ws + dzo::kMaxPartialBlocks + 16; }       // [f]
     int32_t *flags() const { return reinterpret_cast<int32_t *>(ws + dzo::kMaxPartialBlocks + 24); }
-    int32_t *phi_flags() const { return reinterpret_cast<int32_t *>(ws + dzo::kMaxPartialBlocks + 26); }   // [changed, nonzero, differs from ref], kept zero between uses
+    int32_t *phi_flags() const { return reinterpret_cast<int32_t *>(ws + dzo::kMaxPartialBlocks + 32); }   // 18 x int32 {changed, nonzero, differs from ref} per request, kept zero between uses
 };
 
 namespace dzo {
@@ -623,6 +624,8 @@ struct PhiSearch {
     int32_t increases = 0;
     bool want = false, req_ref = false;
     double t_best = 0, f_best = 0;
+    void *cur_point = nullptr;     // buffer holding the trial point of the last consumed evaluation
+    void *spec[2] = {nullptr, nullptr};
 };
 
 static void phi_search_to_quadratic(dzo_bfgs_s *o, PhiSearch &q) {      // bfgs_quadratic_search after :195
@@ -652,7 +655,7 @@ static void phi_search_bracket_done(dzo_bfgs_s *o, PhiSearch &q, double x1, doub
 
 static void phi_search_begin(dzo_bfgs_s *o, PhiSearch &q, const void *dir, double f0, double t0, void *scratch, void *ref_point) {
     q = PhiSearch();
-    q.dir = dir; q.f0 = f0; q.t0 = t0; q.scratch = scratch; q.ref_point = ref_point;
+    q.dir = dir; q.f0 = f0; q.t0 = t0; q.scratch = scratch; q.ref_point = ref_point; q.cur_point = scratch;
     if (!finite_t(f0) || !(t0 > 0) || !finite_t(t0)) {           // :64-66 -> bracket (0, f0, 0, f0)
         phi_search_bracket_done(o, q, 0, f0, 0, f0);
         return;
@@ -675,7 +678,7 @@ static int32_t phi_search_feed(dzo_bfgs_s *o, PhiSearch &q, double f, bool chang
         q.fa = f;                                                // :104
         if (q.fa <= q.f0) {                                      // :130
             q.increases = 0;
-            DZO_HIP(hipMemcpyAsync(q.ref_point, q.scratch, bytes, hipMemcpyDeviceToDevice, o->stream));   // :136
+            DZO_HIP(hipMemcpyAsync(q.ref_point, q.cur_point, bytes, hipMemcpyDeviceToDevice, o->stream));   // :136
             q.state = PhiSearch::DOUBLING;
             q.req_t = round_to_dtype(dt, q.step + q.step); q.increases += 1;
             q.want = true; q.req_ref = true;
@@ -692,7 +695,7 @@ static int32_t phi_search_feed(dzo_bfgs_s *o, PhiSearch &q, double f, bool chang
         if (!stop) stop = equal_ref;                             // :150
         if (stop) { phi_search_bracket_done(o, q, q.step, q.fa, dbl, fb); return DZO_OK; }   // :151
         q.step = dbl; q.fa = fb;
-        DZO_HIP(hipMemcpyAsync(q.ref_point, q.scratch, bytes, hipMemcpyDeviceToDevice, o->stream));       // :155
+        DZO_HIP(hipMemcpyAsync(q.ref_point, q.cur_point, bytes, hipMemcpyDeviceToDevice, o->stream));       // :155
         q.req_t = round_to_dtype(dt, q.step + q.step); q.increases += 1;
         q.want = true; q.req_ref = true;
         return DZO_OK;
@@ -729,19 +732,58 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
     PhiSearch q[2];
     phi_search_begin(o, q[0], dir_a, o->f, t0_a, o->scratch, o->ref_point);
     phi_search_begin(o, q[1], dir_b, o->f, t0_b, o->scratch2, o->ref_point2);
+    for (int r = 0; r < 2; ++r) { q[r].spec[0] = o->spec_buf[2 * r]; q[r].spec[1] = o->spec_buf[2 * r + 1]; }
+    const int32_t dt = o->dtype;
     while (q[0].want || q[1].want) {
-        const void *dir[2] = {q[0].dir, q[1].dir};
-        const double ts[2] = {round_to_dtype(o->dtype, o->sign * q[0].req_t), round_to_dtype(o->dtype, o->sign * q[1].req_t)};
-        void *out[2] = {q[0].scratch, q[1].scratch};
-        const void *ref[2] = {q[0].want && q[0].req_ref ? q[0].ref_point : nullptr, q[1].want && q[1].req_ref ? q[1].ref_point : nullptr};
-        const bool active[2] = {q[0].want, q[1].want};
-        if (!problem_phi2_async(o->problem, o->stream, o->x, dir, ts, out, ref, active, o->phi_flags(), o->host_dev)) return DZO_OK;
+        // Per search: the evaluation it needs now (slot 0) plus the one or two it will most likely
+        // need next (slots 1, 2) -- the first doubling and the first halving after the first point,
+        // the next doubling / halving inside those loops.  All of them ride on the same pass over A;
+        // a speculative value is used only if the state machine then asks for exactly that point.
+        PhiDirHost req[2];
+        double spec_t[2][3];
+        bool spec_ref[2][3];
+        for (int r = 0; r < 2; ++r) {
+            PhiSearch &sm = q[r];
+            req[r].dir = sm.dir;
+            for (int e = 0; e < 3; ++e) { spec_t[r][e] = 0; spec_ref[r][e] = false; }
+            if (!sm.want) { req[r].dir = q[1 - r].dir; continue; }
+            auto post = [&](int slot, double t, void *out, const void *ref, int ref_req, bool is_ref) {
+                req[r].ts[slot] = round_to_dtype(dt, o->sign * t);
+                req[r].point_out[slot] = out; req[r].ref[slot] = ref; req[r].ref_req[slot] = ref_req; req[r].active[slot] = true;
+                spec_t[r][slot] = t; spec_ref[r][slot] = is_ref;
+            };
+            post(0, sm.req_t, sm.scratch, sm.req_ref ? sm.ref_point : nullptr, -1, sm.req_ref);
+            if (sm.state == PhiSearch::FIRST) {
+                post(1, round_to_dtype(dt, sm.req_t + sm.req_t), sm.spec[0], nullptr, 0, true);      // first doubling (:143), :150 against slot 0
+                post(2, round_to_dtype(dt, 0.5 * sm.req_t), sm.spec[1], nullptr, -1, false);         // first halving (:158)
+            } else if (sm.state == PhiSearch::DOUBLING) {
+                post(1, round_to_dtype(dt, sm.req_t + sm.req_t), sm.spec[0], nullptr, 0, true);
+            } else if (sm.state == PhiSearch::SHRINKING) {
+                post(1, round_to_dtype(dt, 0.5 * sm.req_t), sm.spec[0], nullptr, -1, false);
+            }
+        }
+        if (!problem_phi6_async(o->problem, o->stream, o->x, req, o->phi_flags(), o->host_dev)) return DZO_OK;
         DZO_HIP(hipGetLastError());
         DZO_HIP(hipStreamSynchronize(o->stream));
-        const int32_t *hf = reinterpret_cast<const int32_t *>(o->host + 4);
-        for (int r = 0; r < 2; ++r)
-            if (active[r])
-                DZO_TRY(phi_search_feed(o, q[r], round_to_dtype(o->dtype, o->host[r]), hf[3 * r] != 0, hf[3 * r + 1] != 0, hf[3 * r + 2] == 0));
+        const int32_t *hf = reinterpret_cast<const int32_t *>(o->host + 8);
+        for (int r = 0; r < 2; ++r) {
+            PhiSearch &sm = q[r];
+            if (!req[r].active[0]) continue;
+            bool used[3] = {false, false, false};
+            int slot = 0;                                     // the primary request first, then matching speculative ones
+            for (;;) {
+                used[slot] = true;
+                sm.cur_point = req[r].point_out[slot];
+                const int fq = (r * 3 + slot) * 3;
+                DZO_TRY(phi_search_feed(o, sm, round_to_dtype(dt, o->host[r * 3 + slot]), hf[fq] != 0, hf[fq + 1] != 0, hf[fq + 2] == 0));
+                if (!sm.want) break;
+                int next = -1;
+                for (int e = 1; e < 3; ++e)
+                    if (req[r].active[e] && !used[e] && spec_t[r][e] == sm.req_t && spec_ref[r][e] == sm.req_ref) next = e;
+                if (next < 0) break;
+                slot = next;
+            }
+        }
     }
     // the rare tiny-step path (:91-101) is finished with the sequential code
     double tt[2], ff[2];
@@ -838,7 +880,8 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
     const size_t es = dtype_size(o->dtype);
     const size_t vbytes = (size_t)((o->n + 63) / 64 * 64) * es;
     DZO_HIP(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
-    void **vecs[] = {&o->x, &o->g, &o->dx, &o->dg, &o->d, &o->d_alt, &o->scratch, &o->ref_point, &o->scratch2, &o->ref_point2};
+    void **vecs[] = {&o->x, &o->g, &o->dx, &o->dg, &o->d, &o->d_alt, &o->scratch, &o->ref_point, &o->scratch2, &o->ref_point2,
+                     &o->spec_buf[0], &o->spec_buf[1], &o->spec_buf[2], &o->spec_buf[3]};
     for (void **v : vecs) {
         hipError_t e = hipMalloc(v, vbytes);
         if (e != hipSuccess) { set_error("out of device memory allocating BFGS vectors"); return DZO_ERR_NOMEM; }
@@ -852,9 +895,9 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
         }
     }
     DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));
-    DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 32)));
-    DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 32)));
-    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 48)));
+    DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 48)));
+    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 32, hipHostMallocMapped | hipHostMallocCoherent));
     DZO_HIP(hipHostGetDevicePointer((void **)&o->host_dev, o->host, 0));
     DZO_HIP(hipDeviceSynchronize());
     return DZO_OK;
@@ -1044,7 +1087,8 @@ int32_t dzo_gd_step(dzo_bfgs_t o) {
 int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
     if (!o) return DZO_OK;
     if (o->stream) (void)hipStreamSynchronize(o->stream);
-    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->scratch2, o->ref_point2, o->H, o->ws, o->upd_part};
+    void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->scratch2, o->ref_point2, o->spec_buf[0], o->spec_buf[1], o->spec_buf[2],
+                    o->spec_buf[3], o->H, o->ws, o->upd_part};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
     if (o->stream) (void)hipStreamDestroy(o->stream);

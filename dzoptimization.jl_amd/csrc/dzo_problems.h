@@ -35,9 +35,16 @@ bool problem_trial_eval_async(dzo_problem_s *p, hipStream_t s, void *x, void *ba
 // device flags are re-armed.  false when there is no such kernel.
 bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *dir, double ts, void *point_out,
                        int32_t *flags, double *result_dev, const void *ref = nullptr);
-bool problem_phi2_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *const dir[2], const double ts[2],
-                        void *const point_out[2], const void *const ref[2], const bool active[2], int32_t *flags,
-                        double *result_dev);
+// up to three step sizes along one direction, evaluated in the same pass over A
+struct PhiDirHost {
+    const void *dir = nullptr;
+    double ts[3] = {0, 0, 0};
+    void *point_out[3] = {nullptr, nullptr, nullptr};
+    const void *ref[3] = {nullptr, nullptr, nullptr};
+    int ref_req[3] = {-1, -1, -1};
+    bool active[3] = {false, false, false};
+};
+bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev);
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).

@@ -341,79 +341,98 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi_kernel(int64_t n, const 
 // side by side, legacy/DZOptimization.jl:922-932): request r evaluates f(x + ts[r]*dir[r]); each A
 // column is loaded once and used for both.  Per request the arithmetic is that of
 // quadratic_phi_kernel, so every value is bit-identical to a separate evaluation.
-template <typename T> struct PhiRequest {
+// One search direction with up to three step sizes evaluated in the same pass (the request the search
+// needs now plus the one or two it will most likely need next).
+template <typename T> struct PhiDir {
     const T *dir;
-    const T *ref;          // may be null
-    T *point_out;
-    T ts;
-    int active;
+    T ts[3];
+    T *point_out[3];
+    const T *ref[3];       // stagnation test against a stored point (may be null) ...
+    int ref_req[3];        // ... or against request ref_req[q] of the same direction in this launch (-1: none)
+    int active[3];
 };
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void quadratic_phi2_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
-                                                                PhiRequest<T> r0, PhiRequest<T> r1,
+__global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
+                                                                PhiDir<T> a, PhiDir<T> b,
                                                                 double *__restrict__ partials, int32_t *__restrict__ flags) {
     constexpr int N = Vec16<T>::N;
     __shared__ double lds[kWaves];
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
         const T *col = A + j * n;
-        double acc0 = 0, acc1 = 0;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
         const bool vec = ((n % N) == 0);
         if (vec) {
             for (int64_t i = (int64_t)threadIdx.x * N; i < n; i += (int64_t)kBlock * N) {
-                T av[N], xv[N], d0[N], d1[N];
+                T av[N], xv[N], da[N], db[N];
                 load16(col + i, av);
                 load16(x + i, xv);
-                load16(r0.dir + i, d0);
-                load16(r1.dir + i, d1);
+                load16(a.dir + i, da);
+                load16(b.dir + i, db);
 #pragma unroll
                 for (int q = 0; q < N; ++q) {
-                    acc0 = __builtin_fma((double)av[q], (double)dfma(r0.ts, d0[q], xv[q]), acc0);
-                    acc1 = __builtin_fma((double)av[q], (double)dfma(r1.ts, d1[q], xv[q]), acc1);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {      // (wave-uniform skips: later rounds carry one or two requests per direction)
+                        if (a.active[r]) acc[r] = __builtin_fma((double)av[q], (double)dfma(a.ts[r], da[q], xv[q]), acc[r]);
+                        if (b.active[r]) acc[3 + r] = __builtin_fma((double)av[q], (double)dfma(b.ts[r], db[q], xv[q]), acc[3 + r]);
+                    }
                 }
             }
         } else {
             for (int64_t i = threadIdx.x; i < n; i += kBlock) {
-                acc0 = __builtin_fma((double)col[i], (double)dfma(r0.ts, r0.dir[i], x[i]), acc0);
-                acc1 = __builtin_fma((double)col[i], (double)dfma(r1.ts, r1.dir[i], x[i]), acc1);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[r] = __builtin_fma((double)col[i], (double)dfma(a.ts[r], a.dir[i], x[i]), acc[r]);
+                    acc[3 + r] = __builtin_fma((double)col[i], (double)dfma(b.ts[r], b.dir[i], x[i]), acc[3 + r]);
+                }
             }
         }
-        const double c0 = block_sum(acc0, lds);
-        const double c1 = block_sum(acc1, lds);
+        double c[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) c[r] = ((r < 3 ? a.active[r] : b.active[r - 3]) != 0) ? block_sum(acc[r], lds) : 0.0;
         if (threadIdx.x == 0) {
             const T xo = x[j];
-            if (r0.active) {
-                const T dj = r0.dir[j], xt = dfma(r0.ts, dj, xo);
-                partials[j] = c0 * (double)xt;
-                r0.point_out[j] = xt;
-                if (xo != xt) flags[0] = 1;
-                if (dj != (T)0) flags[1] = 1;
-                if (r0.ref && !is_equal(xt, r0.ref[j])) flags[2] = 1;
-            }
-            if (r1.active) {
-                const T dj = r1.dir[j], xt = dfma(r1.ts, dj, xo);
-                partials[n + j] = c1 * (double)xt;
-                r1.point_out[j] = xt;
-                if (xo != xt) flags[3] = 1;
-                if (dj != (T)0) flags[4] = 1;
-                if (r1.ref && !is_equal(xt, r1.ref[j])) flags[5] = 1;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const PhiDir<T> &d = side ? b : a;
+                const T dj = d.dir[j];
+                T xt[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) xt[r] = dfma(d.ts[r], dj, xo);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (!d.active[r]) continue;
+                    const int slot = side * 3 + r;
+                    partials[(int64_t)slot * n + j] = c[slot] * (double)xt[r];
+                    d.point_out[r][j] = xt[r];
+                    if (xo != xt[r]) flags[slot * 3 + 0] = 1;
+                    if (dj != (T)0) flags[slot * 3 + 1] = 1;
+                    if (d.ref[r]) { if (!is_equal(xt[r], d.ref[r][j])) flags[slot * 3 + 2] = 1; }
+                    else if (d.ref_req[r] >= 0) { if (!is_equal(xt[r], xt[d.ref_req[r]])) flags[slot * 3 + 2] = 1; }
+                }
             }
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void finish_phi2_kernel(const double *__restrict__ partials, int64_t count, double scale,
+// values to out[0..5], flags {changed, nonzero, differs from ref} of request q to the int32 view of
+// out[8..] at 3q; flags re-armed
+__global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__restrict__ partials, int64_t count, double scale,
                                                              double *__restrict__ out, int32_t *__restrict__ flags) {
     __shared__ double lds[kWaves];
-    double v0 = 0, v1 = 0;
-    for (int64_t i = threadIdx.x; i < count; i += kBlock) { v0 += partials[i]; v1 += partials[count + i]; }
-    const double s0 = block_sum(v0, lds);
-    const double s1 = block_sum(v1, lds);
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = threadIdx.x; i < count; i += kBlock) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) v[r] += partials[(int64_t)r * count + i];
+    }
+    double sres[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) sres[r] = block_sum(v[r], lds);
     if (threadIdx.x == 0) {
-        out[0] = scale * s0;
-        out[1] = scale * s1;
-        int32_t *ho = reinterpret_cast<int32_t *>(out + 4);
-        for (int q = 0; q < 6; ++q) { ho[q] = flags[q]; flags[q] = 0; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) out[r] = scale * sres[r];
+        int32_t *ho = reinterpret_cast<int32_t *>(out + 8);
+        for (int q = 0; q < 18; ++q) { ho[q] = flags[q]; flags[q] = 0; }
         __threadfence_system();
     }
 }
@@ -721,30 +740,33 @@ bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const voi
     return true;
 }
 
-// Two evaluations f(x + ts_r*dir_r), r = 0, 1, in one pass over A (either may be inactive); values
-// to result_dev[0..1], flags {changed, nonzero, differs from ref} of request r to the int32 view of
-// result_dev[4..6] at 3r.  `flags` are 6 zeroed int32 on the device, re-armed on return.
-bool problem_phi2_async(dzo_problem_s *p, hipStream_t s, const void *x, const void *const dir[2], const double ts[2],
-                        void *const point_out[2], const void *const ref[2], const bool active[2], int32_t *flags,
-                        double *result_dev) {
+// Up to three step sizes along each of two directions in one pass over A.  req[side] describes the
+// requests (inactive ones are skipped); values and flags land in result_dev (>= 17 doubles, may be
+// pinned host memory): values [0..5], int32 flags from [8].  `flags`: 18 zeroed int32 on the device.
+bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev) {
     if (!p || p->kind != DZO_PROBLEM_QUADRATIC || p->l2 != 0.0 || p->cons_on) return false;
     const int64_t n = p->n;
-    if (p->scratch_doubles < 2 * n) return false;
+    if (p->scratch_doubles < 6 * n) return false;
     DZO_TIMED("objective_quadratic_phi", s);
     const int grid = (int)(n < 65535 ? n : 65535);
     auto launch = [&](auto tag) {
         using T = decltype(tag);
-        PhiRequest<T> r[2];
-        for (int q = 0; q < 2; ++q) {
-            const int src = active[q] ? q : (active[0] ? 0 : 1);      // an inactive request re-reads the other one's vectors
-            r[q].dir = (const T *)dir[src]; r[q].ref = (const T *)ref[q]; r[q].point_out = (T *)point_out[q];
-            r[q].ts = (T)ts[src]; r[q].active = active[q] ? 1 : 0;
+        PhiDir<T> d[2];
+        for (int side = 0; side < 2; ++side) {
+            d[side].dir = (const T *)req[side].dir;
+            for (int r = 0; r < 3; ++r) {
+                d[side].ts[r] = (T)req[side].ts[r];
+                d[side].point_out[r] = (T *)req[side].point_out[r];
+                d[side].ref[r] = (const T *)req[side].ref[r];
+                d[side].ref_req[r] = req[side].ref_req[r];
+                d[side].active[r] = req[side].active[r] ? 1 : 0;
+            }
         }
-        hipLaunchKernelGGL(quadratic_phi2_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, r[0], r[1],
+        hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
                            p->scratch, flags);
     };
     if (p->dtype == DZO_F64) launch(double{}); else launch(float{});
-    hipLaunchKernelGGL(finish_phi2_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags);
+    hipLaunchKernelGGL(finish_phi6_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags);
     return true;
 }
 
@@ -819,7 +841,7 @@ int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A
     DZO_REQUIRE(kind != DZO_PROBLEM_LSE || c_dev, DZO_ERR_INVALID, "LSE problem needs c");
     dzo_problem_s *p = new dzo_problem_s();
     p->kind = kind; p->n = n; p->dtype = dtype; p->A = A_dev; p->c = c_dev; p->lambda = lambda;
-    const int64_t scratch = (kind == DZO_PROBLEM_QUADRATIC ? (2 * n > 2 * kMaxPartialBlocks ? 2 * n : 2 * kMaxPartialBlocks)
+    const int64_t scratch = (kind == DZO_PROBLEM_QUADRATIC ? (6 * n > 2 * kMaxPartialBlocks ? 6 * n : 2 * kMaxPartialBlocks)
                                                            : 2 * kMaxPartialBlocks) + 16;
     p->scratch_doubles = scratch - 16;
     hipError_t e = hipMalloc((void **)&p->scratch, sizeof(double) * (size_t)scratch);
