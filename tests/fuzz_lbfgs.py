@@ -1,5 +1,6 @@
-"""Dev tool: GPU fuzz of step!() over ragged n, ring wrap-around and both two-loop modes, with
-per-step resync from the oracle (test infrastructure; uses oracle/)."""
+"""GPU fuzz of step!() over ragged n, ring wrap-around and both two-loop modes, with per-step resync
+from the oracle.  Test infrastructure (lives under tests/ because it uses oracle/); not collected by
+pytest -- run it by hand:  python tests/fuzz_lbfgs.py"""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dzo_loader import dzo
