@@ -462,12 +462,16 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])",
-                   "n": n, "m": m, "history_full": k == m, "two_loop": args.mode,
+                   "n": n, "m": m, "history_full": k == m,
+                   "two_loop": ("single_pass (one sweep over the history per accepted step; gram + combine after a "
+                                "rejected first trial)" if "lbfgs_single_pass" in table else args.mode),
                    "parallelism": "1 optimizer instance per GPU, RCCL all-reduce of the convergence flag only"
                    if world > 1 else "single GPU",
                    "objective_evals_per_step": round(trials / args.steps, 3), "any_stuck": any_stuck,
                    "f_start": f_start, "f_end": opt.current_objective_value, "device": info["name"]},
         "step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 1),
+        "step_algorithmic_note": "SURVEY 8(d) contract bytes per step, (4k+10) n T, over wall time -- NOT bytes moved: the "
+                                 "single-pass step moves (2k+9) n T per accepted step (roofline.achieved uses that figure)",
         "roofline": roofline, "kernels": kernels,
     }
     if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N = 1 only
