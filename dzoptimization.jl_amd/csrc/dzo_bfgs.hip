@@ -366,6 +366,8 @@ struct dzo_bfgs_s {
     void *scratch = nullptr;                    // :748
     void *scratch2 = nullptr, *ref_point2 = nullptr;   // trial point / reference point of the second concurrent search
     void *spec_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // trial points of the speculative evaluations (two per search)
+    void *grad_pool = nullptr;                  // 24 vectors: gradients at the evaluated trial points of the last 4 rounds
+    const void *best_grad[2] = {nullptr, nullptr};   // gradient at the best point of the last dual search, per direction (or null)
     void *ref_point = nullptr;                  // LineSearchEvaluator.reference_point (:17)
     int32_t max_increases = 0;                  // QuadraticLineSearch.max_increases (:181-188)
     double sign = -1.0;                         // trial point x + sign*t*dir: -1 BFGS (:945), +1 legacy evaluator (:33)
@@ -626,13 +628,17 @@ struct PhiSearch {
     double t_best = 0, f_best = 0;
     void *cur_point = nullptr;     // buffer holding the trial point of the last consumed evaluation
     void *spec[2] = {nullptr, nullptr};
+    // gradient (A*x_t, a by-product of the evaluation) and round of: the last consumed evaluation, the
+    // point `step`, the bracket ends, the best point so far
+    const void *cur_grad = nullptr, *step_grad = nullptr, *g1 = nullptr, *g2 = nullptr, *best_grad = nullptr;
+    int cur_round = 0, step_round = 0, r1 = 0, r2 = 0, best_round = 0;
 };
 
 static void phi_search_to_quadratic(dzo_bfgs_s *o, PhiSearch &q) {      // bfgs_quadratic_search after :195
     const int32_t dt = o->dtype;
-    q.xb = 0; q.fb = q.f0;                                       // :196
-    if (q.f1 < q.fb) { q.xb = q.x1; q.fb = q.f1; }               // :197-199
-    if (q.f2 < q.fb) { q.xb = q.x2; q.fb = q.f2; }               // :200-202
+    q.xb = 0; q.fb = q.f0; q.best_grad = nullptr;                // :196
+    if (q.f1 < q.fb) { q.xb = q.x1; q.fb = q.f1; q.best_grad = q.g1; q.best_round = q.r1; }   // :197-199
+    if (q.f2 < q.fb) { q.xb = q.x2; q.fb = q.f2; q.best_grad = q.g2; q.best_round = q.r2; }   // :200-202
     const double d1 = round_to_dtype(dt, q.f0 - q.f1), d2 = round_to_dtype(dt, q.f2 - q.f1);
     const double sum = round_to_dtype(dt, d1 + d2);              // :203-205
     if (d1 >= 0 && d2 >= 0 && sum > 0) {                         // :206
@@ -648,8 +654,9 @@ static void phi_search_to_quadratic(dzo_bfgs_s *o, PhiSearch &q) {      // bfgs_
     }
 }
 
-static void phi_search_bracket_done(dzo_bfgs_s *o, PhiSearch &q, double x1, double f1, double x2, double f2) {
-    q.x1 = x1; q.f1 = f1; q.x2 = x2; q.f2 = f2;
+static void phi_search_bracket_done(dzo_bfgs_s *o, PhiSearch &q, double x1, double f1, double x2, double f2,
+                                    const void *g1 = nullptr, int r1 = 0, const void *g2 = nullptr, int r2 = 0) {
+    q.x1 = x1; q.f1 = f1; q.x2 = x2; q.f2 = f2; q.g1 = g1; q.r1 = r1; q.g2 = g2; q.r2 = r2;
     phi_search_to_quadratic(o, q);
 }
 
@@ -676,6 +683,7 @@ static int32_t phi_search_feed(dzo_bfgs_s *o, PhiSearch &q, double f, bool chang
         if (!changed) { q.state = PhiSearch::SEQUENTIAL; return DZO_OK; }                  // :91-101 tiny-step path: rare, done sequentially
         o->evals += 1;
         q.fa = f;                                                // :104
+        q.step_grad = q.cur_grad; q.step_round = q.cur_round;
         if (q.fa <= q.f0) {                                      // :130
             q.increases = 0;
             DZO_HIP(hipMemcpyAsync(q.ref_point, q.cur_point, bytes, hipMemcpyDeviceToDevice, o->stream));   // :136
@@ -693,8 +701,8 @@ static int32_t phi_search_feed(dzo_bfgs_s *o, PhiSearch &q, double f, bool chang
         const double dbl = q.req_t, fb = f;
         bool stop = (o->max_increases > 0 && q.increases >= o->max_increases) || !finite_t(fb) || fb > q.fa;
         if (!stop) stop = equal_ref;                             // :150
-        if (stop) { phi_search_bracket_done(o, q, q.step, q.fa, dbl, fb); return DZO_OK; }   // :151
-        q.step = dbl; q.fa = fb;
+        if (stop) { phi_search_bracket_done(o, q, q.step, q.fa, dbl, fb, q.step_grad, q.step_round, q.cur_grad, q.cur_round); return DZO_OK; }   // :151
+        q.step = dbl; q.fa = fb; q.step_grad = q.cur_grad; q.step_round = q.cur_round;
         DZO_HIP(hipMemcpyAsync(q.ref_point, q.cur_point, bytes, hipMemcpyDeviceToDevice, o->stream));       // :155
         q.req_t = round_to_dtype(dt, q.step + q.step); q.increases += 1;
         q.want = true; q.req_ref = true;
@@ -703,16 +711,16 @@ static int32_t phi_search_feed(dzo_bfgs_s *o, PhiSearch &q, double f, bool chang
     case PhiSearch::SHRINKING: {                                 // :157-171
         o->evals += 1;
         const double hs = q.req_t, fb = f;
-        if (fb <= q.f0) { phi_search_bracket_done(o, q, hs, fb, q.step, q.fa); return DZO_OK; }   // :166
+        if (fb <= q.f0) { phi_search_bracket_done(o, q, hs, fb, q.step, q.fa, q.cur_grad, q.cur_round, q.step_grad, q.step_round); return DZO_OK; }   // :166
         if (hs == 0.0) { phi_search_bracket_done(o, q, 0, q.f0, 0, q.f0); return DZO_OK; }
-        q.step = hs; q.fa = fb;
+        q.step = hs; q.fa = fb; q.step_grad = q.cur_grad; q.step_round = q.cur_round;
         q.req_t = round_to_dtype(dt, 0.5 * q.step);
         q.want = true; q.req_ref = false;
         return DZO_OK;
     }
     case PhiSearch::QUADRATIC:                                   // :210-213
         o->evals += 1;
-        if (f < q.fb) { q.xb = q.req_t; q.fb = f; }
+        if (f < q.fb) { q.xb = q.req_t; q.fb = f; q.best_grad = q.cur_grad; q.best_round = q.cur_round; }
         q.t_best = q.xb; q.f_best = q.fb;
         q.state = PhiSearch::DONE;
         return DZO_OK;
@@ -734,7 +742,11 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
     phi_search_begin(o, q[1], dir_b, o->f, t0_b, o->scratch2, o->ref_point2);
     for (int r = 0; r < 2; ++r) { q[r].spec[0] = o->spec_buf[2 * r]; q[r].spec[1] = o->spec_buf[2 * r + 1]; }
     const int32_t dt = o->dtype;
+    const size_t vbytes = (size_t)((o->n + 63) / 64 * 64) * dtype_size(dt);
+    int round = 0;
+    o->best_grad[0] = o->best_grad[1] = nullptr;
     while (q[0].want || q[1].want) {
+        round += 1;
         // Per search: the evaluation it needs now (slot 0) plus the one or two it will most likely
         // need next (slots 1, 2) -- the first doubling and the first halving after the first point,
         // the next doubling / halving inside those loops.  All of them ride on the same pass over A;
@@ -750,6 +762,7 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
             auto post = [&](int slot, double t, void *out, const void *ref, int ref_req, bool is_ref) {
                 req[r].ts[slot] = round_to_dtype(dt, o->sign * t);
                 req[r].point_out[slot] = out; req[r].ref[slot] = ref; req[r].ref_req[slot] = ref_req; req[r].active[slot] = true;
+                req[r].grad_out[slot] = (char *)o->grad_pool + (size_t)((round % 4) * 6 + r * 3 + slot) * vbytes;
                 spec_t[r][slot] = t; spec_ref[r][slot] = is_ref;
             };
             post(0, sm.req_t, sm.scratch, sm.req_ref ? sm.ref_point : nullptr, -1, sm.req_ref);
@@ -774,6 +787,7 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
             for (;;) {
                 used[slot] = true;
                 sm.cur_point = req[r].point_out[slot];
+                sm.cur_grad = req[r].grad_out[slot]; sm.cur_round = round;
                 const int fq = (r * 3 + slot) * 3;
                 DZO_TRY(phi_search_feed(o, sm, round_to_dtype(dt, o->host[r * 3 + slot]), hf[fq] != 0, hf[fq + 1] != 0, hf[fq + 2] == 0));
                 if (!sm.want) break;
@@ -791,6 +805,9 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
         if (q[r].state == PhiSearch::SEQUENTIAL) DZO_TRY(bfgs_quadratic_search(o, q[r].dir, o->f, q[r].t0, &tt[r], &ff[r]));
         else { tt[r] = q[r].t_best; ff[r] = q[r].f_best; }
     }
+    for (int r = 0; r < 2; ++r)        // gradient at the best point, if its pool entry has not been recycled since
+        if (q[r].state == PhiSearch::DONE && q[r].t_best != 0.0 && q[r].best_grad && round - q[r].best_round < 4)
+            o->best_grad[r] = q[r].best_grad;
     *t_a = tt[0]; *f_a = ff[0]; *t_b = tt[1]; *f_b = ff[1];
     *done = true;
     return DZO_OK;
@@ -805,7 +822,7 @@ static int32_t bfgs_identity(dzo_bfgs_s *o) {
 }
 
 // :943-950 / :971-978
-static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir) {
+static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir, const void *grad_at_new_point = nullptr) {
     hipStream_t s = o->stream;
     {
         DZO_TIMED("bfgs_move", s);
@@ -821,7 +838,10 @@ static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir) {
         DZO_REQUIRE(o->constraint(o->cb_ctx, o->x) != 0, DZO_ERR_ASSERT,
                     "@assert constraint_success (legacy/DZOptimization.jl:947)");
     }
-    DZO_TRY(bfgs_grad(o));                                       // :948
+    if (grad_at_new_point && !o->gradient && !o->constraint && !(o->problem && o->problem->cons_on))
+        DZO_HIP(hipMemcpyAsync(o->g, grad_at_new_point, (size_t)o->n * dtype_size(o->dtype), hipMemcpyDeviceToDevice, s));   // :948, already computed by the line search
+    else
+        DZO_TRY(bfgs_grad(o));                                   // :948
     // :949-950  (-x_old) + x_new == x_new - x_old exactly
     DZO_DISPATCH(o->dtype, launch_axpby<T>(s, o->n, (T)1, (const T *)o->x, (T)-1, (T *)o->dx));
     DZO_DISPATCH(o->dtype, launch_axpby<T>(s, o->n, (T)1, (const T *)o->g, (T)-1, (T *)o->dg));
@@ -841,6 +861,7 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
     DZO_TRY(bfgs_dual_search(o, o->g, round_to_dtype(dt, step_length / grad_norm), o->d, round_to_dtype(dt, step_length / bfgs_norm_v),
                              &t_g, &f_g, &t_b, &f_b, &dual));    // :922-925 and :929-932 side by side
     if (!dual) {
+        o->best_grad[0] = o->best_grad[1] = nullptr;
         DZO_TRY(bfgs_quadratic_search(o, o->g, o->f, round_to_dtype(dt, step_length / grad_norm), &t_g, &f_g));   // :922-925
         DZO_TRY(bfgs_quadratic_search(o, o->d, o->f, round_to_dtype(dt, step_length / bfgs_norm_v), &t_b, &f_b)); // :929-932
     }
@@ -849,7 +870,7 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
         o->last_step_length = round_to_dtype(dt, t_b * bfgs_norm_v);   // :938
         o->last_step_type = DZO_STEP_BFGS;                       // :939
         o->iteration_count += 1;                                 // :940
-        DZO_TRY(bfgs_move(o, t_b, o->d));                        // :943-950
+        DZO_TRY(bfgs_move(o, t_b, o->d, o->best_grad[1]));       // :943-950
         // :953-960 update_inverse_hessian!(H, -t_b, d, dg, scratch) fused with d = H*g
         if (o->n >= 65535LL * kColsPerBlock) {
             DZO_DISPATCH(dt, launch_bfgs_update<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (T *)o->d, (const T *)o->dg,
@@ -865,7 +886,7 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
         o->last_step_length = round_to_dtype(dt, t_g * grad_norm);   // :966
         o->last_step_type = DZO_STEP_GRADIENT_DESCENT;           // :967
         o->iteration_count += 1;                                 // :968
-        DZO_TRY(bfgs_move(o, t_g, o->g));                        // :971-978
+        DZO_TRY(bfgs_move(o, t_g, o->g, o->best_grad[0]));       // :971-978
         DZO_TRY(bfgs_identity(o));                               // :981
         DZO_HIP(hipMemcpyAsync(o->d, o->g, bytes, hipMemcpyDeviceToDevice, o->stream));   // :984-986
     } else {
@@ -894,6 +915,7 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
             return DZO_ERR_NOMEM;
         }
     }
+    DZO_HIP(hipMalloc(&o->grad_pool, 24 * vbytes));
     DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));
     DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 48)));
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 48)));
@@ -1088,7 +1110,7 @@ int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
     if (!o) return DZO_OK;
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->scratch2, o->ref_point2, o->spec_buf[0], o->spec_buf[1], o->spec_buf[2],
-                    o->spec_buf[3], o->H, o->ws, o->upd_part};
+                    o->spec_buf[3], o->grad_pool, o->H, o->ws, o->upd_part};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
     if (o->stream) (void)hipStreamDestroy(o->stream);

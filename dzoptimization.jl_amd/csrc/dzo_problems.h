@@ -42,6 +42,7 @@ struct PhiDirHost {
     void *point_out[3] = {nullptr, nullptr, nullptr};
     const void *ref[3] = {nullptr, nullptr, nullptr};
     int ref_req[3] = {-1, -1, -1};
+    void *grad_out[3] = {nullptr, nullptr, nullptr};
     bool active[3] = {false, false, false};
 };
 bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev);

@@ -349,6 +349,7 @@ template <typename T> struct PhiDir {
     T *point_out[3];
     const T *ref[3];       // stagnation test against a stored point (may be null) ...
     int ref_req[3];        // ... or against request ref_req[q] of the same direction in this launch (-1: none)
+    T *grad_out[3];        // may be null: A*x_t, the gradient at the trial point, is a by-product (c_j = A[:,j].x_t)
     int active[3];
 };
 
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
                     const int slot = side * 3 + r;
                     partials[(int64_t)slot * n + j] = c[slot] * (double)xt[r];
                     d.point_out[r][j] = xt[r];
+                    if (d.grad_out[r]) d.grad_out[r][j] = (T)c[slot];      // exactly what quadratic_kernel<WRITE_G> stores
                     if (xo != xt[r]) flags[slot * 3 + 0] = 1;
                     if (dj != (T)0) flags[slot * 3 + 1] = 1;
                     if (d.ref[r]) { if (!is_equal(xt[r], d.ref[r][j])) flags[slot * 3 + 2] = 1; }
@@ -759,6 +761,7 @@ bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const Ph
                 d[side].point_out[r] = (T *)req[side].point_out[r];
                 d[side].ref[r] = (const T *)req[side].ref[r];
                 d[side].ref_req[r] = req[side].ref_req[r];
+                d[side].grad_out[r] = (T *)req[side].grad_out[r];
                 d[side].active[r] = req[side].active[r] ? 1 : 0;
             }
         }
