@@ -1,0 +1,12 @@
+import sys, time; sys.path.insert(0,'/root/repo')
+import bench
+from dzo_loader import dzo
+dzo.init(0)
+n=10_000_000
+x0=bench.rosenbrock_chain_x0(n, seed=5)
+opt=dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0)
+for _ in range(10): opt.step()
+dzo.synchronize(); t0=time.perf_counter()
+for _ in range(100): opt.step()
+dzo.synchronize(); dt=time.perf_counter()-t0
+print('AdGD n=1e7: %.1f step!()/s, %.3f ms/step, f=%.6e' % (100/dt, dt*10, opt.current_objective_value))
