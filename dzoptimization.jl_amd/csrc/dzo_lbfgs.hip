@@ -1347,7 +1347,7 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
     dzo_lbfgs_s *o = static_cast<dzo_lbfgs_s *>(self);
     OptCore &c = o->core;
     int grid = 0;
-    DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, gate));
+    DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, gate, c.xold_src, c.gold_src));
     o->tail_grid = grid;
     if (o->mode == DZO_TWOLOOP_GRAM) return DZO_OK;      // rho rides on the next gram_reduce launch
     return lbfgs_rho_finish(o, grid, gate);
@@ -1515,6 +1515,12 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     }
     const bool fused = o->fused_post && !c.objective && !c.gradient && !c.constraint &&
                        problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
+    if (c.xold_src && !fused) {                           // (cannot happen with the single pass's own conditions; keep the plain path whole)
+        const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
+        DZO_HIP(hipMemcpyAsync(c.dx, c.xold_src, bytes, hipMemcpyDeviceToDevice, c.stream));
+        DZO_HIP(hipMemcpyAsync(c.g, c.gold_src, bytes, hipMemcpyDeviceToDevice, c.stream));
+        c.xold_src = nullptr; c.gold_src = nullptr;
+    }
     c.defer_delta = fused;
     c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
     c.speculative_self = o;
@@ -1530,7 +1536,7 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     } else if (fused) {
         // :145 + :478-480 + partials of :505 in one pass
         int grid = 0;
-        DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid));
+        DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, nullptr, c.xold_src, c.gold_src));
         done = lbfgs_finish_push(o, grid, false);
     } else {
         DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
@@ -1663,12 +1669,19 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
         o->halo_valid = true;
         return DZO_OK;
     }
-    // rejected: put x_old and g_old back, then continue the reference loop at its first halving
+    // rejected: continue the reference loop at its first halving.  x_old and g_old are read from the
+    // backups the pass wrote (the trial kernel rebuilds x from x_old, the accepted-step tail overwrites
+    // g and the deltas); only a search that ends stuck needs them copied back.
     o->single_pass_rejections += 1;
     const size_t bytes = (size_t)c.n * sizeof(T);
-    DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
-    DZO_HIP(hipMemcpyAsync(c.dx, o->xbak, bytes, hipMemcpyDeviceToDevice, s));   // the :118 backup where the trial kernels expect it
-    return lbfgs_search_and_post(o, true);
+    c.xold_src = o->xbak; c.gold_src = o->gbak;
+    const int32_t rc = lbfgs_search_and_post(o, true);
+    c.xold_src = nullptr; c.gold_src = nullptr;
+    DZO_TRY(rc);
+    if (c.is_stuck) {                                     // (:151 restored x already -- from the backup; g still holds the rejected trial's gradient)
+        DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    return DZO_OK;
 }
 
 static int32_t lbfgs_step(dzo_lbfgs_s *o) {

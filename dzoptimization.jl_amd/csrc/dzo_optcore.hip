@@ -163,7 +163,8 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     const bool trial_fused = speculate && fuse_trial && !c.box_on &&
                              problem_trial_eval_async(c.problem, s, c.x, c.dx, dir, t, first, c.flag(), &partials, &count, &scale);
     if (!trial_fused) {
-        DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)c.dx, (const T *)dir, (T)t, first, c.flag()));
+        DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)(c.xold_src && !first ? const_cast<void *>(c.xold_src) : c.dx),
+                                              (const T *)dir, (T)t, first, c.flag()));
         DZO_HIP(hipGetLastError());
     }
     // built-in box constraint: projection is always feasible, so it can ride in the stream (:134-135)
@@ -201,7 +202,8 @@ int32_t core_accept(OptCore &c, double f_new) {
 }
 
 int32_t core_reject(OptCore &c) {
-    DZO_HIP(hipMemcpyAsync(c.x, c.dx, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :151
+    const void *src = c.xold_src ? c.xold_src : c.dx;            // where this search keeps x_old
+    DZO_HIP(hipMemcpyAsync(c.x, src, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :151
     return DZO_OK;
 }
 

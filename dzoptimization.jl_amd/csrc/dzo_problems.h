@@ -51,7 +51,8 @@ int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void 
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).
 bool problem_has_fused_post(const dzo_problem_s *p, const void *x, const void *dx, const void *g, const void *dg);
 int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x, void *dx, void *g, void *dg,
-                                 double *partials, int *grid_out, const int32_t *gate = nullptr);
+                                 double *partials, int *grid_out, const int32_t *gate = nullptr, const void *xold_src = nullptr,
+                                 const void *gold_src = nullptr);
 // x[i] = clamp(x[i], lo, hi) on stream s (UniformBoxConstraint, legacy :264-272)
 int32_t box_clamp_async(hipStream_t s, int64_t n, int32_t dtype, void *x, double lo, double hi);
 }  // namespace dzo

@@ -89,10 +89,13 @@ __global__ __launch_bounds__(kBlock) void rosen_chain_grad_kernel(int64_t n, T *
 // values for the gradient stencil come from wave shuffles; only lanes 0 / 63 touch memory again.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void rosen_accept_grad_delta_kernel(int64_t n, const T *__restrict__ x,
-                                                                         T *__restrict__ dx, T *__restrict__ g,
+                                                                         T *dx, T *g,
                                                                          T *__restrict__ dg,
                                                                          double *__restrict__ partials,
-                                                                         const int32_t *__restrict__ gate) {
+                                                                         const int32_t *__restrict__ gate,
+                                                                         const T *xold, const T *gold) {
+    // xold / gold: where x_old and g_old are read from -- dx and g themselves on the ordinary path
+    // (in place), the single pass's backups after its first trial was rejected (no restore copies)
     constexpr int N = Vec16<T>::N;
     constexpr int U = 2;
     __shared__ double lds[kWaves];
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void rosen_accept_grad_delta_kernel(int64_t
         for (int u = 0; u < U; ++u) {
             const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
             ok[u] = v < nvec;
-            if (ok[u]) { load16(x + v * N, xv[u]); load16(dx + v * N, xo[u]); load16(g + v * N, go[u]); }
+            if (ok[u]) { load16(x + v * N, xv[u]); load16(xold + v * N, xo[u]); load16(gold + v * N, go[u]); }
             else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) { xv[u][j] = 0; xo[u][j] = 0; go[u][j] = 0; }
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void rosen_accept_grad_delta_kernel(int64_t
     const int64_t t = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t < n) {
         const T gn = rosen_grad_elem<T>(t, n, t > 0 ? x[t - 1] : (T)0, x[t], t + 1 < n ? x[t + 1] : (T)0);
-        const T dxn = x[t] - dx[t];
-        const T dgn = gn - g[t];
+        const T dxn = x[t] - xold[t];
+        const T dgn = gn - gold[t];
         acc = __builtin_fma((double)dxn, (double)dgn, acc);
         dx[t] = dxn; g[t] = gn; dg[t] = dgn;
     }
@@ -680,17 +683,18 @@ bool problem_has_fused_post(const dzo_problem_s *p, const void *x, const void *d
 }
 
 int32_t problem_fused_post_async(dzo_problem_s *p, hipStream_t s, const void *x, void *dx, void *g, void *dg,
-                                 double *partials, int *grid_out, const int32_t *gate) {
-    DZO_TIMED("lbfgs_fused_accept_grad_delta", s);
+                                 double *partials, int *grid_out, const int32_t *gate, const void *xold_src, const void *gold_src) {
     const int64_t n = p->n;
+    DZO_TIMED("lbfgs_fused_accept_grad_delta", s);
     const int vecn = p->dtype == DZO_F64 ? 2 : 4;
     const int grid = stream_grid(n, vecn * 2);
+    const void *xo = xold_src ? xold_src : dx, *go = gold_src ? gold_src : g;
     if (p->dtype == DZO_F64)
         hipLaunchKernelGGL(rosen_accept_grad_delta_kernel<double>, dim3(grid), dim3(kBlock), 0, s, n, (const double *)x,
-                           (double *)dx, (double *)g, (double *)dg, partials, gate);
+                           (double *)dx, (double *)g, (double *)dg, partials, gate, (const double *)xo, (const double *)go);
     else
         hipLaunchKernelGGL(rosen_accept_grad_delta_kernel<float>, dim3(grid), dim3(kBlock), 0, s, n, (const float *)x,
-                           (float *)dx, (float *)g, (float *)dg, partials, gate);
+                           (float *)dx, (float *)g, (float *)dg, partials, gate, (const float *)xo, (const float *)go);
     *grid_out = grid;
     DZO_HIP(hipGetLastError());
     return DZO_OK;
