@@ -271,6 +271,23 @@ __global__ __launch_bounds__(kBlock) void bfgs_move_kernel(int64_t n, T *__restr
     }
 }
 
+// move + deltas in one launch when the gradient at the new point is already known (it is a
+// by-product of the line search, bfgs_dual_search): x = fma(-t, dir, x) (:945), delta_point =
+// x_new - x_old (:949), g = g_new (:948), delta_gradient = g_new - g_old (:950)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bfgs_move_with_gradient_kernel(int64_t n, T *x, const T *dir, T *g, const T *__restrict__ gnew,
+                                                                         T t, T *__restrict__ dx, T *__restrict__ dg) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads) {
+        const T xo = x[i], go = g[i], di = dir[i], gn = gnew[i];      // (dir may alias g: both read before any store)
+        const T xn = dfma(-t, di, xo);
+        x[i] = xn;
+        dx[i] = xn - xo;
+        g[i] = gn;
+        dg[i] = gn - go;
+    }
+}
+
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // run `body` with the constexpr column-group width CC selected by DZO_TUNE_BFGS_COLS
@@ -824,6 +841,14 @@ static int32_t bfgs_identity(dzo_bfgs_s *o) {
 // :943-950 / :971-978
 static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir, const void *grad_at_new_point = nullptr) {
     hipStream_t s = o->stream;
+    if (grad_at_new_point && !o->gradient && !o->constraint && !(o->problem && o->problem->cons_on)) {
+        DZO_TIMED("bfgs_move", s);
+        const int grid = stream_grid(o->n, 1);
+        DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(bfgs_move_with_gradient_kernel<T>, dim3(grid), dim3(kBlock), 0, s, o->n, (T *)o->x,
+                                                  (const T *)dir, (T *)o->g, (const T *)grad_at_new_point, (T)t, (T *)o->dx, (T *)o->dg));
+        DZO_HIP(hipGetLastError());
+        return DZO_OK;
+    }
     {
         DZO_TIMED("bfgs_move", s);
         const int grid = stream_grid(o->n, 1);
