@@ -9,8 +9,8 @@ rng = np.random.default_rng(12345)
 def rel(a,b): return np.linalg.norm(a-b)/max(np.linalg.norm(b),1e-300)
 worst = 0
 for ex in range(120):
-    n = int(rng.choice([1,2,3,5,63,64,65,127,129,255,257,1000,4097,65537,200003]))
-    m = int(rng.integers(1, 13)); warm = int(rng.integers(0, 45)); mode = int(rng.integers(0, 2))
+    n = int(rng.choice([1,2,3,5,8,63,64,65,122,124,126,127,129,248,255,257,372,1000,4097,7936,7938,65537,100000,200002,200003]))
+    m = int(rng.integers(1, 23)); warm = int(rng.integers(0, 45)); mode = int(rng.integers(0, 2))
     dtype = np.float64
     x0 = (orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5) * 2.0
     ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 0.5, m)
