@@ -272,9 +272,13 @@ function _lb_p(o::LBFGSOptimizer{T}, w, idx=0) where {T}
     check(ccall((:dzo_lbfgs_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}), getfield(o, :handle), w, idx, p))
     return HipVector{T}(p[], length(getfield(o, :current_point)))
 end
-function _lb_hist(o::LBFGSOptimizer{T}, sym) where {T}
+function _lb_hist(o::LBFGSOptimizer{T}, rho::Bool) where {T}   # (ccall needs a literal symbol name)
     buf = Vector{Cdouble}(undef, 64); cnt = Ref{Cint}(0)
-    check(ccall((sym, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), getfield(o, :handle), buf, 64, cnt))
+    if rho
+        check(ccall((:dzo_lbfgs_get_rho, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), getfield(o, :handle), buf, 64, cnt))
+    else
+        check(ccall((:dzo_lbfgs_get_alpha, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ref{Cint}), getfield(o, :handle), buf, 64, cnt))
+    end
     return T.(buf[1:cnt[]])
 end
 
@@ -291,8 +295,8 @@ function Base.getproperty(o::LBFGSOptimizer{T}, s::Symbol) where {T}
     s === :step_direction && return _lb_p(o, 4)
     s === :delta_point_history && return [_lb_p(o, 5, i - 1) for i in 1:_lb_i(o, 4)]
     s === :delta_gradient_history && return [_lb_p(o, 6, i - 1) for i in 1:_lb_i(o, 4)]
-    s === :rho_history && return _lb_hist(o, :dzo_lbfgs_get_rho)
-    s === :alpha_history && return _lb_hist(o, :dzo_lbfgs_get_alpha)
+    s === :rho_history && return _lb_hist(o, true)
+    s === :alpha_history && return _lb_hist(o, false)
     s === :last_step_length && return fill(T(_lb_s(o, 2)))
     s === :history_resets && return Int(_lb_i(o, 8))
     s === :descent_resets && return Int(_lb_i(o, 9))
