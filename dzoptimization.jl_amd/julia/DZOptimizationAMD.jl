@@ -22,7 +22,9 @@ import LinearAlgebra: axpy!, axpby!, dot, norm, rmul!
 export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentOptimizer, QuadraticLineSearch,
        UniformBoxConstraint, with_l2!, with_box_gradient!, with_box_constraint!, step!,
        set_safeguards!, set_line_search!, BACKTRACKING, STRONG_WOLFE,
-       RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem
+       RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem,
+       BatchedBFGSOptimizer, count_active, LineSearchEvaluator, compute_lbfgs_step_direction!,
+       update_inverse_hessian!, synchronize
 
 const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
 
@@ -48,6 +50,8 @@ function init(device::Integer=0)
     _initialised[] = true
 end
 ensure_init() = _initialised[] || init(parse(Int, get(ENV, "DZO_DEVICE", "0")))
+"""Wait for every stream of the library (step functions return before their last kernels finish)."""
+synchronize() = check(ccall((:dzo_synchronize, libdzo), Cint, ()))
 
 ################################################################################ HipVector
 
@@ -128,10 +132,14 @@ end
 
 ################################################################################ built-in objectives
 
-struct BuiltinProblem{T}
+mutable struct BuiltinProblem{T}
     handle::Ptr{Cvoid}
     n::Int
     keep::Any
+    function BuiltinProblem{T}(h::Ptr{Cvoid}, n::Integer, keep) where {T}
+        # optimizers built from a problem hold it in a field, so it outlives their handles
+        return finalizer(q -> ccall((:dzo_problem_destroy, libdzo), Cint, (Ptr{Cvoid},), q.handle), new{T}(h, n, keep))
+    end
 end
 function _problem(kind, n, ::Type{T}; A=nothing, c=nothing, lambda=0.0) where {T}
     ensure_init()
@@ -203,7 +211,7 @@ function step! end
 """`LBFGSOptimizer(constraint!, objective, gradient!, x0, step, m)` (src/DZOptimization.jl:400-407)
 or the full form with `f0, g0` (:347-356).  `objective` may be a `BuiltinProblem`, in which case
 the whole step runs on the device.  Aliases `x0` as `current_point` (:393)."""
-struct LBFGSOptimizer{T,A,C,F,G} <: AbstractOptimizer{T,A}
+mutable struct LBFGSOptimizer{T,A,C,F,G} <: AbstractOptimizer{T,A}
     handle::Ptr{Cvoid}
     constraint_function!::C
     objective_function::F
@@ -211,6 +219,10 @@ struct LBFGSOptimizer{T,A,C,F,G} <: AbstractOptimizer{T,A}
     current_point::A
     history_length::Int
     keep::Any
+    function LBFGSOptimizer{T,A,C,F,G}(h, c, f, g, x, m, keep) where {T,A,C,F,G}
+        return finalizer(o -> ccall((:dzo_lbfgs_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)),
+                         new{T,A,C,F,G}(h, c, f, g, x, m, keep))
+    end
 end
 
 function LBFGSOptimizer(constraint!::C, objective::F, gradient!::G, x0::HipVector{T},
@@ -248,6 +260,11 @@ end
 
 """`step!(opt)` (src/DZOptimization.jl:454-509)."""
 step!(opt::LBFGSOptimizer) = (check(ccall((:dzo_lbfgs_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
+
+"""`compute_lbfgs_step_direction!(opt)` (src/DZOptimization.jl:430-451): the two-loop recursion alone,
+`opt.step_direction = -H_k * opt.current_gradient`."""
+compute_lbfgs_step_direction!(opt::LBFGSOptimizer) =
+    (check(ccall((:dzo_lbfgs_direction, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
 
 const BACKTRACKING, STRONG_WOLFE = Cint(0), Cint(1)
 
@@ -307,13 +324,17 @@ end
 
 """`BFGSOptimizer(objective, gradient!, [constraint!,] x0, initial_step_length)` (README.md:33-36,
 legacy/DZOptimization.jl:753-766).  Copies `x0` (:769)."""
-struct BFGSOptimizer{T,F,G,C}
+mutable struct BFGSOptimizer{T,F,G,C}
     handle::Ptr{Cvoid}
     objective_function::F
     gradient_function!::G
     constraint_function!::C
     n::Int
     keep::Any
+    function BFGSOptimizer{T,F,G,C}(h, f, g, c, n, keep) where {T,F,G,C}
+        return finalizer(o -> ccall((:dzo_bfgs_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)),
+                         new{T,F,G,C}(h, f, g, c, n, keep))
+    end
 end
 BFGSOptimizer(objective, gradient!, x0::HipVector, step::Real) = BFGSOptimizer(objective, gradient!, nothing, x0, step)
 function BFGSOptimizer(objective::F, gradient!::G, constraint!::C, x0::HipVector{T}, step::Real) where {T,F,G,C}
@@ -331,6 +352,26 @@ function BFGSOptimizer(objective::F, gradient!::G, constraint!::C, x0::HipVector
                 @cfunction(_c_gradient, Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), cf,
                 pointer_from_objref(cb), length(x0), dtype_code(T), x0.ptr, step, h))
     return BFGSOptimizer{T,F,G,C}(h[], objective, gradient!, constraint!, length(x0), cb)
+end
+
+"""`BFGSOptimizer(T, opt, objective_in_T)` (legacy/DZOptimization.jl:812-862): the same optimizer state in
+another precision (fp32 warm start, fp64 finish); objective value, gradient and `H*g` are recomputed
+in `T` (:825-836).  `objective_in_T` is the built-in problem of the target precision."""
+function BFGSOptimizer(::Type{T}, opt::BFGSOptimizer, objective::BuiltinProblem{T}) where {T}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_bfgs_convert_problem, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                getfield(opt, :handle), objective.handle, h))
+    return BFGSOptimizer{T,typeof(objective),Nothing,Nothing}(h[], objective, nothing, nothing, getfield(opt, :n), nothing)
+end
+
+"""`update_inverse_hessian!(H, step_length, d, delta_gradient, scratch)` (legacy/DZOptimization.jl:864-889) on
+raw device arrays (`H` column-major n*n); rescales `d` in place (:874)."""
+function update_inverse_hessian!(H::HipVector{T}, step_length::Real, d::HipVector{T}, delta_gradient::HipVector{T},
+                                 scratch::HipVector{T}) where {T}
+    check(ccall((:dzo_bfgs_update, libdzo), Cint,
+                (Int64, Cint, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                length(d), dtype_code(T), H.ptr, step_length, d.ptr, delta_gradient.ptr, scratch.ptr, C_NULL, C_NULL))
+    return H
 end
 
 """`step!(opt)` (legacy/DZOptimization.jl:891-994)."""
@@ -372,7 +413,13 @@ function GradientDescentOptimizer(objective::BuiltinProblem{T}, ::Any, ls::Quadr
     check(ccall((:dzo_bfgs_set_max_increases, libdzo), Cint, (Ptr{Cvoid}, Cint), h[], ls.max_increases))
     return GDHandle{T}(h[], length(x0), objective)
 end
-struct GDHandle{T}; handle::Ptr{Cvoid}; n::Int; keep::Any; end
+mutable struct GDHandle{T}
+    handle::Ptr{Cvoid}
+    n::Int
+    keep::Any
+    GDHandle{T}(h, n, keep) where {T} =
+        finalizer(o -> ccall((:dzo_bfgs_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)), new{T}(h, n, keep))
+end
 step!(opt::GDHandle) = (check(ccall((:dzo_gd_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
 function Base.getproperty(o::GDHandle{T}, s::Symbol) where {T}      # the BFGS-family getters (include/dzo.h)
     s in (:has_terminated, :has_converged, :is_stuck) && return fill(_bf_i(o, 0) != 0)
@@ -392,10 +439,12 @@ end
 
 """`AdGDOptimizer(constraint!, objective, gradient!, x0, initial_step_length)`
 (src/DZOptimization.jl:245-251); built-in objectives only in this thin binding."""
-struct AdGDOptimizer{T}
+mutable struct AdGDOptimizer{T}
     handle::Ptr{Cvoid}
     current_point::HipVector{T}
     keep::Any
+    AdGDOptimizer{T}(h, x, keep) where {T} =
+        finalizer(o -> ccall((:dzo_adgd_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)), new{T}(h, x, keep))
 end
 function AdGDOptimizer(::Nothing, objective::BuiltinProblem{T}, ::Any, x0::HipVector{T}, step::Real) where {T}
     ensure_init()
@@ -415,6 +464,74 @@ function Base.getproperty(o::AdGDOptimizer{T}, s::Symbol) where {T}
     s === :current_step_size && return fill(T(_ad_s(o, 2)))
     s === :previous_step_size && return fill(T(_ad_s(o, 3)))
     return getfield(o, s)
+end
+
+################################################################################ batched dense BFGS
+
+"""`BatchedBFGSOptimizer(kind, x0, n, initial_step_length)`: `length(x0) / n` independent `BFGSOptimizer`s
+(legacy/DZOptimization.jl:733-994 each) on one device, `x0` instance-major; `kind` = 1 for the chained
+Rosenbrock objective.  `step!(b, k)` runs k synchronous steps of every live instance;
+`count_active(b) == 0` is the shard's "everyone has_terminated".  One shard per process / GPU."""
+mutable struct BatchedBFGSOptimizer{T}
+    handle::Ptr{Cvoid}
+    batch::Int
+    n::Int
+    function BatchedBFGSOptimizer(kind::Integer, x0::HipVector{T}, n::Integer, step::Real) where {T}
+        ensure_init()
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        batch = div(length(x0), n)
+        check(ccall((:dzo_bfgs_batch_create, libdzo), Cint, (Cint, Int64, Int64, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                    kind, batch, n, dtype_code(T), x0.ptr, step, h))
+        return finalizer(o -> ccall((:dzo_bfgs_batch_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)),
+                         new{T}(h[], batch, n))
+    end
+end
+step!(b::BatchedBFGSOptimizer, steps::Integer=1) =
+    (check(ccall((:dzo_bfgs_batch_step, libdzo), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}), b.handle, steps, C_NULL)); b)
+function count_active(b::BatchedBFGSOptimizer)
+    v = Ref{Int64}(0)
+    check(ccall((:dzo_bfgs_batch_count_active, libdzo), Cint, (Ptr{Cvoid}, Ref{Int64}), b.handle, v))
+    return Int(v[])
+end
+"""`current_point(b)`: the batch x n points (instance-major) as one device vector."""
+function current_point(b::BatchedBFGSOptimizer{T}) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_bfgs_batch_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), b.handle, 0, p))
+    return HipVector{T}(p[], b.batch * b.n)
+end
+
+################################################################################ LineSearchEvaluator
+
+"""`LineSearchEvaluator(constraint!, objective, gradient!, x, f, d, overlap)` and its call
+`ev(t, compute_gradient)` -> `(trial_objective_value, improvement_ratio, slope_ratio)`
+(src/DZOptimization.jl:12-62, :65-92).  `trial_point` / `trial_gradient` are the evaluator's own."""
+struct LineSearchEvaluator{T,CB}
+    callbacks::CB
+    current_point::HipVector{T}
+    current_objective_value::T
+    step_direction::HipVector{T}
+    overlap::T
+    trial_point::HipVector{T}
+    trial_gradient::HipVector{T}
+end
+function LineSearchEvaluator(constraint!::C, objective::F, gradient!::G, x::HipVector{T}, f::Real, d::HipVector{T},
+                             overlap::Real) where {T,C,F,G}
+    cb = Ref(Callbacks{C,F,G,T}(constraint!, objective, gradient!, length(x)))
+    return LineSearchEvaluator{T,typeof(cb)}(cb, x, T(f), d, T(overlap), similar(x), similar(x))
+end
+function (ev::LineSearchEvaluator{T})(step_size::Real, compute_gradient::Bool) where {T}
+    cb = ev.callbacks
+    cf = cb[].constraint! === nothing ? C_NULL : @cfunction(_c_constraint, Cint, (Ptr{Cvoid}, Ptr{Cvoid}))
+    f, imp, slope = Ref{Cdouble}(0), Ref{Cdouble}(0), Ref{Cdouble}(0)
+    GC.@preserve cb check(ccall((:dzo_line_search_eval, libdzo), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}, Cdouble, Cdouble,
+                 Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}, Ref{Cdouble}),
+                cf, @cfunction(_c_objective, Cdouble, (Ptr{Cvoid}, Ptr{Cvoid})),
+                @cfunction(_c_gradient, Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), pointer_from_objref(cb),
+                length(ev.current_point), dtype_code(T), ev.current_point.ptr, ev.current_objective_value,
+                ev.step_direction.ptr, ev.overlap, step_size, compute_gradient, ev.trial_point.ptr,
+                ev.trial_gradient.ptr, f, imp, slope))
+    return T(f[]), T(imp[]), T(slope[])
 end
 
 end # module
