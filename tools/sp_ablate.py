@@ -11,15 +11,16 @@ import bench  # noqa: E402
 from dzo_loader import dzo  # noqa: E402
 
 n, k = int(os.environ.get("AB_N", 10_000_000)), int(os.environ.get("AB_K", 20))
+dt = np.dtype(os.environ.get("AB_DTYPE", "float64"))
 dzo.init(0)
-S = np.empty((k, n)); Y = np.empty((k, n))
+S = np.empty((k, n), dt); Y = np.empty((k, n), dt)
 for i in range(k):
     S[i] = (bench.pcg32_uniform(n, 100 + i) - 0.5) * 1e-3
     Y[i] = (bench.pcg32_uniform(n, 200 + i) - 0.5) * 1e-3 + S[i]
 Sd, Yd = dzo.DeviceArray.from_host(S), dzo.DeviceArray.from_host(Y)
 del S, Y
-prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
-x = dzo.DeviceArray.from_host(bench.rosenbrock_chain_x0(n, seed=5))
+prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dt)
+x = dzo.DeviceArray.from_host(bench.rosenbrock_chain_x0(n, seed=5).astype(dt))
 opt = dzo.LBFGSOptimizer(None, prob, None, x, 1.0, k)
 times = []
 for it in range(int(os.environ.get("AB_ROUNDS", 6))):
@@ -34,4 +35,5 @@ for it in range(int(os.environ.get("AB_ROUNDS", 6))):
     tab = dzo.profile_table()
     if "lbfgs_single_pass" in tab:
         times.append(tab["lbfgs_single_pass"][1] / tab["lbfgs_single_pass"][0] * 1e3)
-print("DZO_TUNE_SP_DEBUG =", os.environ.get("DZO_TUNE_SP_DEBUG", "0"), " single pass us:", [round(t, 1) for t in times])
+print("DZO_TUNE_SP_DEBUG =", os.environ.get("DZO_TUNE_SP_DEBUG", "0"), str(dt), "k", k, " single pass us:", [round(t, 1) for t in times],
+      {kk: round(v[1] / v[0] * 1e3, 1) for kk, v in tab.items()})
