@@ -122,3 +122,39 @@ def test_julia_module_binds_declared_symbols_with_the_right_arity():
             j += 1
         values = _split_top(src[i:j - 1].lstrip(", \n"))
         assert len(values) == len(types), (name, values, types)
+
+
+def test_streaming_kernels_keep_their_registers():
+    """The single-pass step holds two sets of 2k history vectors in registers (502 of 512 VGPRs at
+    k = 20, fp64).  A single spilled register costs far more than its own traffic: scratch loads
+    share vmcnt with the global loads and retire in order, so waiting for one drains the next row's
+    prefetch.  Guard the fp64 instantiations (and the two-pass streaming kernels) against a
+    compiler or source change that tips them over."""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no ROCm llvm tools")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(dzo.build(), os.path.join(tmp, "lib.so"))
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        meta = {}
+        for f in os.listdir(tmp):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=tmp, check=True,
+                                   capture_output=True, text=True).stdout
+            name = None
+            for line in notes.splitlines():
+                m = re.match(r"\s+\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.match(r"\s+\.(vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", line)
+                if m and name:
+                    meta.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    guarded = [n for n in meta if re.search(r"lbfgs_single_pass_kernelId|gram_pass_lanes_kernelId|combine_kernelId", n)]
+    assert len(guarded) >= 5, sorted(meta)[:20]
+    for n in guarded:
+        assert meta[n].get("vgpr_spill_count", 0) == 0 and meta[n].get("private_segment_fixed_size", 0) == 0, (n, meta[n])
