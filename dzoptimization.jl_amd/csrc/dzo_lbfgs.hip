@@ -945,19 +945,24 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     };
     T sA[K][N], yA[K][N], xA[N], gA[N];
     T sB[K][N], yB[K][N], xB[N], gB[N];
+    // The prefetch of the next row is UNCONDITIONAL (past the end it re-reads the last row): a branch
+    // around the loads makes a control-flow join at which the compiler's s_waitcnt insertion must
+    // assume the loads were skipped, so every wait on the current set would also wait for the set
+    // just requested (vmcnt retires in order) and the two register sets would buy nothing.
     int64_t row = (int64_t)blockIdx.x * kWaves + wave;
-    uint32_t boff = row < rows ? byte_offset(row) : 0u;
-    if (row < rows) issue(row, boff, sA, yA, xA, gA);
+    auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };
+    uint32_t boff = byte_offset(in_range(row));
+    issue(in_range(row), boff, sA, yA, xA, gA);
     while (row < rows) {
         int64_t nrow = row + stride;
-        uint32_t nboff = nrow < rows ? byte_offset(nrow) : 0u;
-        if (nrow < rows) issue(nrow, nboff, sB, yB, xB, gB);
+        uint32_t nboff = byte_offset(in_range(nrow));
+        issue(in_range(nrow), nboff, sB, yB, xB, gB);
         compute(row, boff, sA, yA, xA, gA);
         row = nrow; boff = nboff;
         if (row >= rows) break;
         nrow = row + stride;
-        nboff = nrow < rows ? byte_offset(nrow) : 0u;
-        if (nrow < rows) issue(nrow, nboff, sA, yA, xA, gA);
+        nboff = byte_offset(in_range(nrow));
+        issue(in_range(nrow), nboff, sA, yA, xA, gA);
         compute(row, boff, sB, yB, xB, gB);
         row = nrow; boff = nboff;
     }
