@@ -446,11 +446,25 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
                 fetch(0, sA, yA);
             }
         }
-        for (int i = 0; i < k; i += 2) {
-            if (i + 1 < k) fetch(i + 1, sB, yB);
+        // The steady-state loop has NO condition around its fetches: a branch there is a control-flow
+        // join at which the compiler's s_waitcnt insertion must assume the fetch was skipped, and every
+        // consume would then also wait for the pair just requested (vmcnt retires in order).  (At this
+        // kernel's 16 waves per CU the occupancy hides it either way: 478 vs 477 us at config 3.)
+        int i = 0;
+        for (; i + 2 < k; i += 2) {
+            fetch(i + 1, sB, yB);
+            __builtin_amdgcn_sched_barrier(0);              // (keeps the consumer's fmas, and with them its
+            consume(i, sA, yA);                             //  waits, below the requests)
+            fetch(i + 2, sA, yA);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(i + 1, sB, yB);
+        }
+        if (i + 1 < k) {                                    // two pairs left
+            fetch(i + 1, sB, yB);
             consume(i, sA, yA);
-            if (i + 2 < k) fetch(i + 2, sA, yA);
-            if (i + 1 < k) consume(i + 1, sB, yB);
+            consume(i + 1, sB, yB);
+        } else if (i < k) {                                 // one pair left
+            consume(i, sA, yA);
         }
     };
     const int64_t tile_v = (int64_t)kBlock * U;
