@@ -5,7 +5,7 @@ import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dzo_loader import dzo
 from oracle import oracle as orc
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 12345)))
 def rel(a,b): return np.linalg.norm(a-b)/max(np.linalg.norm(b),1e-300)
 worst = 0
 for ex in range(120):
