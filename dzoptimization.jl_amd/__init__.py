@@ -669,6 +669,8 @@ class AdGDOptimizer(_OptBase):
     delta_objective_value = property(lambda s: s._s(1))
     current_step_size = property(lambda s: s._s(2))
     previous_step_size = property(lambda s: s._s(3))
+    fused_steps = property(lambda s: s._i(3))
+    fused_rejections = property(lambda s: s._i(4))
 
 
 class BFGSOptimizer(_OptBase):

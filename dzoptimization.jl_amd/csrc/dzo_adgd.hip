@@ -2,14 +2,248 @@
 // Reuses the backtracking kernels of dzo_optcore.hip; adds only two nrm2 reductions.
 #include "dzo_optcore.h"
 
+#include "dzo_problems.h"
+#include "dzo_rosen.h"
+
 struct dzo_adgd_s {
     dzo::OptCore core;
     double current_step_size = 0;    // :195
     double previous_step_size = 0;   // :196
     void *dx_buf = nullptr, *dg_buf = nullptr;
+    // fused step (built-in chained Rosenbrock): one pass does :301 (first trial), :306-308 and the
+    // two sums of squares that :292 / :294 of the NEXT step need
+    bool fused = true;               // DZO_TUNE_ADGD_FUSED=0 forces the generic kernel sequence
+    void *halo = nullptr;            // [2][rows][2 sides][x, g]: boundary vectors of the wave-rows
+    int halo_cur = 0;
+    bool halo_valid = false;         // the last fused pass left the boundary vectors of x_new / g_new
+    void *bak = nullptr, *xbak = nullptr, *gbak = nullptr;   // x_old / g_old for a rejected first trial
+    bool norms_ready = false;        // |delta_point|^2, |delta_gradient|^2 of the last step are in norm2[]
+    double norm2[2] = {0, 0};
+    int64_t fused_steps = 0, fused_rejections = 0;
 };
 
 namespace dzo {
+
+// ---------------------------------------------------------------------------------------------
+// Fused AdGD step for the built-in chained Rosenbrock objective.  Wave-rows of 62 owned 16-B vectors
+// plus one halo vector on each side (the 3-point stencil of the gradient needs x_new of both
+// neighbours); halo lanes take x_old / g_old from a boundary buffer, because x and g are updated in
+// place and the neighbouring row may already have moved on.  Per element:
+//   x_new = fma(-step, g_old, x_old)                 take_backtracking_step! :124 (first trial)
+//   objective terms of x_new, changed flag            :128, :138
+//   g_new = grad f(x_new)                             :307
+//   delta_point = x_new - x_old                       :145
+//   delta_gradient = g_new - g_old                    :306, :308
+//   partial sums of |delta_point|^2, |delta_gradient|^2   (:292, :294 of the next step)
+// 2 reads + 6 writes per element instead of the 16 element passes of the separate kernels.
+constexpr int kAdgdOwn = 62;
+
+template <typename T> struct AdgdFusedParams {
+    int64_t n;
+    T t;                                       // -step size
+    T *x, *g;
+    const T *halo;
+    T *halo_next;
+    T *xbak, *gbak, *dx, *dg;
+    double *partials;                          // [3][gridDim.x]: objective, |dx|^2, |dg|^2
+    int32_t *changed;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void adgd_halo_snapshot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ g,
+                                                                    T *__restrict__ halo) {
+    constexpr int N = Vec16<T>::N;
+    const int64_t nvec = n / N;
+    const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
+    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (id >= rows * 2) return;
+    const int64_t row = id >> 1;
+    const int64_t v = (id & 1) ? row * kAdgdOwn + kAdgdOwn : row * kAdgdOwn - 1;
+    if (v < 0 || v >= nvec) return;
+    T xv[N], gv[N];
+    load16(x + v * N, xv);
+    load16(g + v * N, gv);
+    store16(halo + id * 2 * N, xv);
+    store16(halo + id * 2 * N + N, gv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParams<T> p) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[kWaves];
+    __shared__ int lds_flag;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t nvec = p.n / N;
+    const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
+    const bool halo_lane = lane == 0 || lane == 63;
+    double fobj = 0, sdx = 0, sdg = 0;
+    bool diff = false;
+    for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < rows; row += (int64_t)gridDim.x * kWaves) {
+        const int64_t v = row * kAdgdOwn - 1 + lane;
+        const bool valid = v >= 0 && v < nvec;
+        const bool owner = valid && !halo_lane;
+        const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);          // clamped: the value is never used
+        const int64_t e0 = v * N;
+        T xo[N], go[N];
+        const T *h = p.halo + ((row * 2 + (lane == 63 ? 1 : 0)) * 2) * N;
+        load16(halo_lane ? h : p.x + vc * N, xo);
+        load16(halo_lane ? h + N : p.g + vc * N, go);
+        T xn[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            xn[j] = dfma(p.t, go[j], xo[j]);                               // :124
+            diff |= owner && !is_equal(xn[j], xo[j]);                      // :128
+        }
+        const T xprev = __shfl_up(xn[N - 1], 1, 64);
+        const T xnext = __shfl_down(xn[0], 1, 64);
+        T gn[N], sn[N], yn[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T xp = j > 0 ? xn[(j + N - 1) % N] : xprev;
+            const T xq = j + 1 < N ? xn[(j + 1) % N] : xnext;
+            gn[j] = rosen_grad_elem<T>(e0 + j, p.n, xp, xn[j], xq);        // :307
+            sn[j] = xn[j] - xo[j];                                         // :145
+            yn[j] = gn[j] - go[j];                                         // :308
+            if (owner) {
+                if (e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);    // :138
+                sdx = __builtin_fma((double)sn[j], (double)sn[j], sdx);
+                sdg = __builtin_fma((double)yn[j], (double)yn[j], sdg);
+            }
+        }
+        if (owner) {
+            store16_nt(p.x + v * N, xn);
+            store16_nt(p.xbak + v * N, xo);
+            store16_nt(p.g + v * N, gn);
+            store16_nt(p.gbak + v * N, go);
+            store16_nt(p.dx + v * N, sn);
+            store16_nt(p.dg + v * N, yn);
+            // the first / last owned vector of a row is the right / left halo of its neighbour in the NEXT pass
+            if (lane == 1 && row > 0) {
+                T *hn = p.halo_next + (((row - 1) * 2 + 1) * 2) * N;
+                store16(hn, xn); store16(hn + N, gn);
+            }
+            if (lane == kAdgdOwn && row + 1 < rows) {
+                T *hn = p.halo_next + (((row + 1) * 2 + 0) * 2) * N;
+                store16(hn, xn); store16(hn + N, gn);
+            }
+        }
+    }
+    block_raise_flag(diff, p.changed, &lds_flag);
+    const double f = block_sum(fobj, lds);
+    const double a = block_sum(sdx, lds);
+    const double b = block_sum(sdg, lds);
+    if (threadIdx.x == 0) {
+        p.partials[blockIdx.x] = f;
+        p.partials[(int64_t)gridDim.x + blockIdx.x] = a;
+        p.partials[2 * (int64_t)gridDim.x + blockIdx.x] = b;
+    }
+}
+
+// fixed-order sums of the three partial arrays, the :128 / :139 decision, everything the host needs
+// straight into its pinned mirror: {f_new, -, -, status, changed, |dx|^2, |dg|^2}
+__global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__restrict__ partials, int grid,
+                                                             int32_t *__restrict__ changed, double f_cur, int to_f32,
+                                                             double *__restrict__ host_out) {
+    __shared__ double lds[kWaves];
+    double v[3];
+    for (int c = 0; c < 3; ++c) {
+        double a = 0;
+        for (int i = threadIdx.x; i < grid; i += kBlock) a += partials[(int64_t)c * grid + i];
+        v[c] = block_sum(a, lds);
+    }
+    if (threadIdx.x == 0) {
+        double f_new = v[0];
+        if (to_f32) f_new = (double)(float)f_new;
+        const int32_t ch = *changed;
+        int32_t st = 0;
+        if (ch == 0) st = 2;
+        else if (f_new < f_cur) st = 1;
+        *changed = 0;
+        host_out[0] = v[0];
+        host_out[5] = v[1];
+        host_out[6] = v[2];
+        reinterpret_cast<int32_t *>(host_out + 3)[0] = st;
+        reinterpret_cast<int32_t *>(host_out + 4)[0] = ch;
+        __threadfence_system();
+    }
+}
+
+static bool adgd_fused_ok(dzo_adgd_s *o) {
+    OptCore &c = o->core;
+    if (!o->fused || c.objective || c.gradient || c.constraint || c.box_on || !c.problem) return false;
+    const int vecn = 16 / (int)dtype_size(c.dtype);
+    if (c.n % vecn != 0 || c.n < 4 * vecn) return false;
+    return problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
+}
+
+// One fused pass at the first trial step size.  *accepted = false: nothing has changed (x and g are
+// restored) and the caller runs the generic sequence.
+template <typename T> static int32_t adgd_fused_try(dzo_adgd_s *o, double step, bool *accepted) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    constexpr int N = Vec16<T>::N;
+    *accepted = false;
+    const int64_t nvec = c.n / N;
+    const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
+    const size_t halo_elems = (size_t)rows * 2 * 2 * N;
+    if (!o->halo) DZO_HIP(hipMalloc(&o->halo, 2 * halo_elems * sizeof(T)));
+    if (!o->bak) {
+        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
+        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;             // an odd number of KiB apart
+        DZO_HIP(hipMalloc(&o->bak, 2 * slot + 16 * 1024));
+        o->xbak = (char *)o->bak + 5 * 1024;
+        o->gbak = (char *)o->xbak + slot;
+    }
+    AdgdFusedParams<T> fp;
+    fp.n = c.n; fp.t = (T)(-step);
+    fp.x = (T *)c.x; fp.g = (T *)c.g; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
+    fp.dx = (T *)c.dx; fp.dg = (T *)c.dg;
+    fp.halo = (const T *)o->halo + (size_t)o->halo_cur * halo_elems;
+    fp.halo_next = (T *)o->halo + (size_t)(o->halo_cur ^ 1) * halo_elems;
+    fp.partials = c.partials();
+    fp.changed = c.flag();
+    int64_t blocks = (rows + kWaves - 1) / kWaves;
+    if (blocks > 1024) blocks = 1024;                                        // 3 x 1024 partials fit the workspace
+    const int grid = (int)(blocks < 1 ? 1 : blocks);
+    if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
+    c.flag_armed = false;
+    if (!o->halo_valid) {
+        DZO_TIMED("adgd_halo_snapshot", s);
+        const int hgrid = (int)((rows * 2 + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(adgd_halo_snapshot_kernel<T>, dim3(hgrid), dim3(kBlock), 0, s, c.n, (const T *)c.x, (const T *)c.g,
+                           (T *)o->halo + (size_t)o->halo_cur * halo_elems);
+    }
+    o->halo_valid = false;
+    {
+        DZO_TIMED("adgd_fused_step", s);
+        hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
+    }
+    hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), c.f,
+                       c.dtype == DZO_F32 ? 1 : 0, c.host_dev);
+    c.flag_armed = true;
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(s));
+    const int32_t st = reinterpret_cast<const int32_t *>(c.host + 3)[0];
+    if (st == 1) {
+        const double f_new = round_to_dtype(c.dtype, c.host[0]);
+        c.df = round_to_dtype(c.dtype, f_new - c.f);                         // :142-143
+        c.f = f_new;                                                         // :144
+        c.last_trials = 1;
+        o->norm2[0] = c.host[5]; o->norm2[1] = c.host[6];
+        o->norms_ready = true;
+        o->halo_cur ^= 1; o->halo_valid = true;
+        o->fused_steps += 1;
+        *accepted = true;
+        return DZO_OK;
+    }
+    // first trial rejected (or no change): put x_old / g_old back and let the generic loop run
+    const size_t bytes = (size_t)c.n * sizeof(T);
+    DZO_HIP(hipMemcpyAsync(c.x, o->xbak, bytes, hipMemcpyDeviceToDevice, s));
+    DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
+    o->fused_rejections += 1;
+    return DZO_OK;
+}
 
 static int32_t norm_blocking(OptCore &c, const void *v, double *out) {
     double ss = 0;
@@ -36,10 +270,12 @@ static int32_t adgd_step(dzo_adgd_s *o) {
         const double root = dt == DZO_F32 ? (double)sqrtf((float)(1.0 + theta)) : sqrt(1.0 + theta);
         next = round_to_dtype(dt, next * root);                      // :291
         double dgn = 0;
-        DZO_TRY(norm_blocking(c, c.dg, &dgn));                       // :292
+        if (o->norms_ready) dgn = dt == DZO_F32 ? (double)sqrtf((float)o->norm2[1]) : sqrt(o->norm2[1]);
+        else DZO_TRY(norm_blocking(c, c.dg, &dgn));                  // :292
         if (dgn != 0.0) {                                            // :293
             double dxn = 0;
-            DZO_TRY(norm_blocking(c, c.dx, &dxn));
+            if (o->norms_ready) dxn = dt == DZO_F32 ? (double)sqrtf((float)o->norm2[0]) : sqrt(o->norm2[0]);
+            else DZO_TRY(norm_blocking(c, c.dx, &dxn));
             const double inv_L = round_to_dtype(dt, dxn / dgn);      // :294
             const double cap = round_to_dtype(dt, inv_sqrt_two * inv_L);
             next = next < cap ? next : cap;                          // :295
@@ -47,6 +283,16 @@ static int32_t adgd_step(dzo_adgd_s *o) {
     }
     o->previous_step_size = current;                                 // :298
     o->current_step_size = next;                                     // :299
+    o->norms_ready = false;
+    if (adgd_fused_ok(o)) {
+        bool accepted = false;
+        DZO_DISPATCH(dt, DZO_TRY(adgd_fused_try<T>(o, next, &accepted)));
+        if (accepted) {
+            c.iteration_count += 1;                                  // :310
+            return DZO_OK;
+        }
+    }
+    o->halo_valid = false;
     DZO_TRY(core_backtracking_step(c, -next, c.g));                  // :301
     if (c.is_stuck) return DZO_OK;                                   // :302-304
     DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(dt), hipMemcpyDeviceToDevice, c.stream));  // :306
@@ -90,6 +336,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     c.is_stuck = (gnorm == 0.0);                                   // :231
     const double s0 = c.is_stuck ? 0.0 : round_to_dtype(dtype, initial_step_length / gnorm);  // :232-233
     o->current_step_size = s0; o->previous_step_size = s0;         // :241
+    o->fused = getenv("DZO_TUNE_ADGD_FUSED") ? atoi(getenv("DZO_TUNE_ADGD_FUSED")) != 0 : true;
     *out = o;
     return DZO_OK;
 }
@@ -117,6 +364,8 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->dx_buf) (void)hipFree(o->dx_buf);
     if (o->dg_buf) (void)hipFree(o->dg_buf);
+    if (o->halo) (void)hipFree(o->halo);
+    if (o->bak) (void)hipFree(o->bak);
     core_free(o->core);
     delete o;
     return DZO_OK;
@@ -127,6 +376,7 @@ int32_t dzo_adgd_set_callbacks(dzo_adgd_t o, dzo_constraint_fn constraint, dzo_o
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     o->core.constraint = constraint; o->core.objective = objective; o->core.gradient = gradient;
     o->core.cb_ctx = cb_ctx;
+    o->halo_valid = false;
     return DZO_OK;
 }
 
@@ -141,6 +391,8 @@ int32_t dzo_adgd_get_i(dzo_adgd_t o, int32_t what, int64_t *value) {
     case 0: *value = o->core.is_stuck ? 1 : 0; break;
     case 1: *value = o->core.iteration_count; break;
     case 2: *value = o->core.n; break;
+    case 3: *value = o->fused_steps; break;
+    case 4: *value = o->fused_rejections; break;
     default: set_error("dzo_adgd_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;
@@ -161,6 +413,9 @@ int32_t dzo_adgd_get_s(dzo_adgd_t o, int32_t what, double *value) {
 int32_t dzo_adgd_get_ptr(dzo_adgd_t o, int32_t what, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
     DZO_HIP(hipStreamSynchronize(o->core.stream));
+    // the caller may write through the pointer: do not trust what the fused step cached about it
+    if (what == 0 || what == 2) o->halo_valid = false;
+    if (what == 1 || what == 3) o->norms_ready = false;
     switch (what) {
     case 0: *ptr_dev = o->core.x; break;
     case 1: *ptr_dev = o->core.dx; break;

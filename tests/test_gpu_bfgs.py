@@ -347,3 +347,48 @@ def test_side_by_side_line_searches_equal_the_sequential_ones(n, monkeypatch):
         assert len(other) == len(runs[0])
         for a, b in zip(runs[0], other):
             assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [8, 124, 126, 248, 4100, 100_000])
+def test_adgd_fused_step_equals_separate_kernels(n, dtype, monkeypatch):
+    """The one-pass AdGD step (built-in chained Rosenbrock) against the generic kernel sequence
+    (DZO_TUNE_ADGD_FUSED=0): same x, g, deltas bit for bit per step from the same state; objective
+    and the two norms are summed in another order, so step sizes agree to rounding."""
+    x0 = orc.rosenbrock_chain_x0(n).astype(dtype)
+    monkeypatch.setenv("DZO_TUNE_ADGD_FUSED", "1")
+    a = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), 0.1)
+    monkeypatch.setenv("DZO_TUNE_ADGD_FUSED", "0")
+    b = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), 0.1)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    for it in range(25):
+        a.step(); b.step()
+        assert a.is_stuck == b.is_stuck and a.iteration_count == b.iteration_count
+        if a.is_stuck:
+            break
+        assert a.current_step_size == pytest.approx(b.current_step_size, rel=tol)
+        assert a.current_objective_value == pytest.approx(b.current_objective_value, rel=tol)
+        xa, xb = a.current_point.to_host(), b.current_point.to_host()
+        assert rel(xa, xb) <= tol
+        assert rel(a.current_gradient.to_host(), b.current_gradient.to_host()) <= 10 * tol
+        assert rel(a.delta_point.to_host(), b.delta_point.to_host()) <= 1e3 * tol
+    vecn = 16 // np.dtype(dtype).itemsize
+    assert b.fused_steps == 0 and (a.fused_steps > 0) == (n % vecn == 0 and n >= 4 * vecn)
+
+
+def test_adgd_fused_step_rejected_first_trial_falls_back():
+    """A first step that is far too long: the fused pass is rejected, the point restored and the
+    halving loop of take_backtracking_step! (:121-152) runs on the separate kernels; the oracle
+    takes the same steps."""
+    n = 1240
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 200.0)
+    opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 200.0)
+    for it in range(60):
+        opt.step(); ref.step()
+        assert opt.is_stuck == ref.is_stuck and opt.iteration_count == ref.iteration_count
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-10
+        assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-10)
+        assert rel(opt.delta_point.to_host(), ref.delta_point) <= 1e-9
+        assert rel(opt.delta_gradient.to_host(), ref.delta_gradient) <= 1e-9
+    assert opt.fused_rejections >= 1 and opt.fused_steps >= 1
