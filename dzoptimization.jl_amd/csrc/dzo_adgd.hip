@@ -44,7 +44,7 @@ template <typename T> struct AdgdFusedParams {
     T *x, *g;
     const T *halo;
     T *halo_next;
-    T *xbak, *gbak, *dx, *dg;
+    T *xbak, *gbak, *dx, *dg;                  // RETRY: xbak / gbak are the SOURCE (x_old, g_old), x / g only written
     double *partials;                          // [3][gridDim.x]: objective, |dx|^2, |dg|^2
     int32_t *changed;
 };
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(kBlock) void adgd_halo_snapshot_kernel(int64_t n, c
     store16(halo + id * 2 * N + N, gv);
 }
 
-template <typename T>
+// RETRY = a later trial of the same step (:151-152): x_old / g_old come from the backups the first pass
+// wrote, so nothing is read from the arrays being written and the halo lanes read their neighbours directly.
+template <typename T, bool RETRY>
 __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
     __shared__ double lds[kWaves];
@@ -86,9 +88,14 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
         const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);          // clamped: the value is never used
         const int64_t e0 = v * N;
         T xo[N], go[N];
-        const T *h = p.halo + ((row * 2 + (lane == 63 ? 1 : 0)) * 2) * N;
-        load16(halo_lane ? h : p.x + vc * N, xo);
-        load16(halo_lane ? h + N : p.g + vc * N, go);
+        if constexpr (RETRY) {
+            load16(p.xbak + vc * N, xo);
+            load16(p.gbak + vc * N, go);
+        } else {
+            const T *h = p.halo + ((row * 2 + (lane == 63 ? 1 : 0)) * 2) * N;
+            load16(halo_lane ? h : p.x + vc * N, xo);
+            load16(halo_lane ? h + N : p.g + vc * N, go);
+        }
         T xn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -113,9 +120,11 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
         }
         if (owner) {
             store16_nt(p.x + v * N, xn);
-            store16_nt(p.xbak + v * N, xo);
             store16_nt(p.g + v * N, gn);
-            store16_nt(p.gbak + v * N, go);
+            if constexpr (!RETRY) {
+                store16_nt(p.xbak + v * N, xo);
+                store16_nt(p.gbak + v * N, go);
+            }
             store16_nt(p.dx + v * N, sn);
             store16_nt(p.dg + v * N, yn);
             // the first / last owned vector of a row is the right / left halo of its neighbour in the NEXT pass
@@ -177,13 +186,14 @@ static bool adgd_fused_ok(dzo_adgd_s *o) {
     return problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
 }
 
-// One fused pass at the first trial step size.  *accepted = false: nothing has changed (x and g are
-// restored) and the caller runs the generic sequence.
-template <typename T> static int32_t adgd_fused_try(dzo_adgd_s *o, double step, bool *accepted) {
+// The whole step on fused passes: first trial in place; after a rejection the halving loop of
+// take_backtracking_step! (:121-152) re-runs the pass from the backups.  *done = false: not eligible
+// or nothing touched, the caller runs the generic sequence.
+template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step, bool *done) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     constexpr int N = Vec16<T>::N;
-    *accepted = false;
+    *done = false;
     const int64_t nvec = c.n / N;
     const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
     const size_t halo_elems = (size_t)rows * 2 * 2 * N;
@@ -196,7 +206,7 @@ template <typename T> static int32_t adgd_fused_try(dzo_adgd_s *o, double step, 
         o->gbak = (char *)o->xbak + slot;
     }
     AdgdFusedParams<T> fp;
-    fp.n = c.n; fp.t = (T)(-step);
+    fp.n = c.n;
     fp.x = (T *)c.x; fp.g = (T *)c.g; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
     fp.dx = (T *)c.dx; fp.dg = (T *)c.dg;
     fp.halo = (const T *)o->halo + (size_t)o->halo_cur * halo_elems;
@@ -215,34 +225,53 @@ template <typename T> static int32_t adgd_fused_try(dzo_adgd_s *o, double step, 
                            (T *)o->halo + (size_t)o->halo_cur * halo_elems);
     }
     o->halo_valid = false;
-    {
-        DZO_TIMED("adgd_fused_step", s);
-        hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
-    }
-    hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), c.f,
-                       c.dtype == DZO_F32 ? 1 : 0, c.host_dev);
-    c.flag_armed = true;
-    DZO_HIP(hipGetLastError());
-    DZO_HIP(hipStreamSynchronize(s));
-    const int32_t st = reinterpret_cast<const int32_t *>(c.host + 3)[0];
-    if (st == 1) {
-        const double f_new = round_to_dtype(c.dtype, c.host[0]);
-        c.df = round_to_dtype(c.dtype, f_new - c.f);                         // :142-143
-        c.f = f_new;                                                         // :144
-        c.last_trials = 1;
-        o->norm2[0] = c.host[5]; o->norm2[1] = c.host[6];
-        o->norms_ready = true;
-        o->halo_cur ^= 1; o->halo_valid = true;
-        o->fused_steps += 1;
-        *accepted = true;
+    auto restore = [&]() -> int32_t {                                        // :151 (and g, which the pass also replaced)
+        const size_t bytes = (size_t)c.n * sizeof(T);
+        DZO_HIP(hipMemcpyAsync(c.x, o->xbak, bytes, hipMemcpyDeviceToDevice, s));
+        DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
         return DZO_OK;
+    };
+    *done = true;
+    c.last_trials = 0;
+    int64_t halvings = 0;
+    double t = step;
+    for (bool first = true;; first = false) {                                // :121
+        fp.t = (T)(-t);
+        {
+            DZO_TIMED(first ? "adgd_fused_step" : "adgd_fused_retry", s);
+            if (first) hipLaunchKernelGGL((adgd_fused_rosen_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, fp);
+            else hipLaunchKernelGGL((adgd_fused_rosen_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, fp);
+        }
+        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), c.f,
+                           c.dtype == DZO_F32 ? 1 : 0, c.host_dev);
+        c.flag_armed = true;
+        DZO_HIP(hipGetLastError());
+        DZO_HIP(hipStreamSynchronize(s));
+        const int32_t st = reinterpret_cast<const int32_t *>(c.host + 3)[0];
+        if (st == 2) {                                                       // :128-130 (x_new == x_old bit for bit)
+            DZO_TRY(restore());
+            c.is_stuck = true;
+            return DZO_OK;
+        }
+        c.last_trials += 1;
+        if (st == 1) {                                                       // :139
+            const double f_new = round_to_dtype(c.dtype, c.host[0]);
+            c.df = round_to_dtype(c.dtype, f_new - c.f);                     // :142-143
+            c.f = f_new;                                                     // :144
+            o->norm2[0] = c.host[5]; o->norm2[1] = c.host[6];
+            o->norms_ready = true;
+            o->halo_cur ^= 1; o->halo_valid = true;
+            o->fused_steps += 1;
+            if (!first) o->fused_rejections += 1;
+            return DZO_OK;
+        }
+        t = round_to_dtype(c.dtype, t * 0.5);                                // :152
+        if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
+            DZO_TRY(restore());
+            c.is_stuck = true;
+            return DZO_OK;
+        }
     }
-    // first trial rejected (or no change): put x_old / g_old back and let the generic loop run
-    const size_t bytes = (size_t)c.n * sizeof(T);
-    DZO_HIP(hipMemcpyAsync(c.x, o->xbak, bytes, hipMemcpyDeviceToDevice, s));
-    DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
-    o->fused_rejections += 1;
-    return DZO_OK;
 }
 
 static int32_t norm_blocking(OptCore &c, const void *v, double *out) {
@@ -285,10 +314,10 @@ static int32_t adgd_step(dzo_adgd_s *o) {
     o->current_step_size = next;                                     // :299
     o->norms_ready = false;
     if (adgd_fused_ok(o)) {
-        bool accepted = false;
-        DZO_DISPATCH(dt, DZO_TRY(adgd_fused_try<T>(o, next, &accepted)));
-        if (accepted) {
-            c.iteration_count += 1;                                  // :310
+        bool done = false;
+        DZO_DISPATCH(dt, DZO_TRY(adgd_fused_step<T>(o, next, &done)));
+        if (done) {
+            if (!c.is_stuck) c.iteration_count += 1;                 // :302-304, :310
             return DZO_OK;
         }
     }

@@ -274,9 +274,9 @@ int32_t dzo_adgd_set_callbacks(dzo_adgd_t opt, dzo_constraint_fn constraint,
                                dzo_objective_fn objective, dzo_gradient_fn gradient, void *ctx);
 int32_t dzo_adgd_step(dzo_adgd_t opt);
 /* With the built-in chained Rosenbrock objective step! is ONE pass over x and g (first trial, objective,
- * gradient, both deltas and the two norms the next step's :292-294 need); a rejected first trial
- * restores the point and continues on the separate kernels.
- * get_i: 0 is_stuck 1 iteration_count 2 n 3 fused steps 4 fused first trials rejected;
+ * gradient, both deltas and the two norms the next step's :292-294 need); after a rejected trial the
+ * pass is repeated at half the step from the backups it wrote (:151-152).
+ * get_i: 0 is_stuck 1 iteration_count 2 n 3 fused steps 4 of them after a rejected first trial;
  * get_s: 0 f 1 delta_f 2 current_step_size 3 previous_step_size;
  * get_ptr: 0 x 1 delta_point 2 g 3 delta_gradient (the optimizer then assumes the caller may have
  * written through the pointer and re-reads what it had cached about that array) */

@@ -392,3 +392,25 @@ def test_adgd_fused_step_rejected_first_trial_falls_back():
         assert rel(opt.delta_point.to_host(), ref.delta_point) <= 1e-9
         assert rel(opt.delta_gradient.to_host(), ref.delta_gradient) <= 1e-9
     assert opt.fused_rejections >= 1 and opt.fused_steps >= 1
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_adgd_fused_run_to_stuck_leaves_a_consistent_state(dtype):
+    """Run the one-pass AdGD step until is_stuck (:128-130): the point, gradient and objective it
+    leaves must belong together (the pass had overwritten them and restores from its backups), and
+    further step! calls are no-ops (:276-278)."""
+    n = 64
+    x0 = orc.rosenbrock_chain_x0(n).astype(dtype)
+    p = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype)
+    opt = dzo.AdGDOptimizer(None, p, None, dzo.DeviceArray.from_host(x0), 0.1)
+    for it in range(200_000):
+        opt.step()
+        if opt.is_stuck:
+            break
+    assert opt.is_stuck and opt.fused_steps > 0
+    x, g, f, its = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value, opt.iteration_count
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype=dtype)
+    assert np.array_equal(ref_p.grad(x), g)
+    assert f == pytest.approx(ref_p.eval(x), rel=1e-5 if dtype == np.float32 else 1e-12, abs=1e-30)
+    opt.step()
+    assert opt.iteration_count == its and np.array_equal(opt.current_point.to_host(), x)
