@@ -279,6 +279,39 @@ def secondary_workload(args):
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
                                  "traffic": None, "note": "3 n^2 T per accepted BFGS instance-step; line searches included in the time"},
                     "kernels": kern})
+    elif args.workload == "adgd":
+        # AdGDOptimizer (src/DZOptimization.jl:179-312) on the headline objective
+        n = args.n
+        x0 = rosenbrock_chain_x0(n, seed=5 + rank)
+        opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0)
+        for _ in range(10 + args.warmup):
+            opt.step()
+        f_start = opt.current_objective_value
+        fused0, rej0 = opt.fused_steps, opt.fused_rejections
+        dzo.profile_reset(); dzo.profile_enable(2)
+        _barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt.step()
+        dzo.synchronize(); _barrier(world)
+        el = sharding.max_over_ranks(time.perf_counter() - t0)
+        dzo.profile_enable(False)
+        tab = dzo.profile_table()
+        kern = {kk: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for kk, v in tab.items()}
+        us = 1e3 * tab["adgd_fused_step"][1] / tab["adgd_fused_step"][0] if "adgd_fused_step" in tab else None
+        ach = None if us is None else 8 * n * 8 / (us * 1e-6) / 1e9
+        out.update({"metric": "step!() calls/sec, AdGD n=10^7 fp64 (SURVEY 8(f) rank 1)",
+                    "value": round(world * args.steps / el, 2), "unit": "step!() calls/s",
+                    "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
+                    "config": {"workload": f"AdGD on N-D chained Rosenbrock, n={n}, fp64", "f_start": f_start,
+                               "f_end": opt.current_objective_value, "stuck": opt.is_stuck,
+                               "fused_steps": opt.fused_steps - fused0, "steps_after_a_rejected_trial": opt.fused_rejections - rej0,
+                               "device": info["name"]},
+                    "roofline": {"bound": "hbm", "kernel": "adgd_fused_step", "achieved": None if ach is None else round(ach, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "avg_launch_us": None if us is None else round(us, 2),
+                                 "note": "8 n T per pass: reads x, g; writes x, g, delta_point, delta_gradient and the two backups"},
+                    "kernels": kern})
     else:  # lbfgs_lse_f32 (config 4)
         n = 1_000_000 if args.n == 10_000_000 else args.n
         m = 10 if args.m == 20 else args.m
@@ -355,7 +388,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--kernel-events", type=int, default=1, choices=[1, 2],
                     help="HIP events in the timed region: 1 = the two-loop (roofline) kernels only, 2 = every kernel")
-    ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32"],
+    ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32", "adgd"],
                     help="lbfgs = BASELINE configs[2] (the headline; default). The others are the remaining "
                          "BASELINE configs, reported as secondary lines.")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
