@@ -183,7 +183,7 @@ ABI = {
     "dzo_bfgs_update": [_i64, _i32, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "dzo_symv": [_i64, _i32, _vp, _vp, _vp],
     "dzo_bfgs_update_mfma": [_i64, _i32, _vp, _dbl, _vp, _vp, _vp],
-    "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32],
+    "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32], "dzo_bfgs_reset": [_vp],
     "dzo_bfgs_get_i": [_vp, _i32, _P(_i64)], "dzo_bfgs_get_s": [_vp, _i32, _P(_dbl)],
     "dzo_bfgs_get_ptr": [_vp, _i32, _P(_vp)],
     "dzo_gd_create_callbacks": [CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp, _i64, _i32, _vp, _dbl, _P(_vp)],
@@ -750,6 +750,11 @@ class BFGSOptimizer(_OptBase):
 
     def set_max_increases(self, v):
         _check(lib().dzo_bfgs_set_max_increases(self.h, v))
+
+    def reset_inverse_hessian(self):
+        """H <- I, next_step_direction <- gradient (the reset of legacy/DZOptimization.jl:981-986)."""
+        _check(lib().dzo_bfgs_reset(self.h))
+        return self
 
 
 class GradientDescentOptimizer(BFGSOptimizer):

@@ -1257,6 +1257,14 @@ int32_t dzo_bfgs_line_search(dzo_bfgs_t o, int32_t use_gradient_direction, doubl
     return bfgs_quadratic_search(o, use_gradient_direction ? o->g : o->d, o->f, t0, t_best, f_best);
 }
 
+int32_t dzo_bfgs_reset(dzo_bfgs_t o) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(o->H, DZO_ERR_STATE, "this handle has no inverse Hessian (gradient-descent optimizer)");
+    DZO_TRY(bfgs_identity(o));                                                               // :981 (identity_matrix! :712-720)
+    DZO_HIP(hipMemcpyAsync(o->d, o->g, (size_t)o->n * dtype_size(o->dtype), hipMemcpyDeviceToDevice, o->stream));   // :984-986
+    return DZO_OK;
+}
+
 int32_t dzo_bfgs_set_max_increases(dzo_bfgs_t o, int32_t max_increases) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     o->max_increases = max_increases;

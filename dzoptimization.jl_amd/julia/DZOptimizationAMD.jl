@@ -24,7 +24,7 @@ export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentO
        set_safeguards!, set_line_search!, BACKTRACKING, STRONG_WOLFE,
        RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem,
        BatchedBFGSOptimizer, count_active, LineSearchEvaluator, compute_lbfgs_step_direction!,
-       update_inverse_hessian!, synchronize
+       update_inverse_hessian!, reset_inverse_hessian!, synchronize
 
 const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
 
@@ -373,6 +373,10 @@ function update_inverse_hessian!(H::HipVector{T}, step_length::Real, d::HipVecto
                 length(d), dtype_code(T), H.ptr, step_length, d.ptr, delta_gradient.ptr, scratch.ptr, C_NULL, C_NULL))
     return H
 end
+
+"""`reset_inverse_hessian!(opt)`: `approximate_inverse_hessian = I`, `next_step_direction = gradient`
+(the reset of legacy/DZOptimization.jl:981-986, `identity_matrix!` :712-720)."""
+reset_inverse_hessian!(opt::BFGSOptimizer) = (check(ccall((:dzo_bfgs_reset, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
 
 """`step!(opt)` (legacy/DZOptimization.jl:891-994)."""
 step!(opt::BFGSOptimizer) = (check(ccall((:dzo_bfgs_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)

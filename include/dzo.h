@@ -328,6 +328,9 @@ int32_t dzo_symv(int64_t n, int32_t dtype, const void *H_dev, const void *v_dev,
 int32_t dzo_bfgs_line_search(dzo_bfgs_t opt, int32_t use_gradient_direction, double t0,
                              double *t_best, double *f_best);
 int32_t dzo_bfgs_set_max_increases(dzo_bfgs_t opt, int32_t max_increases);
+/* approximate_inverse_hessian <- I (identity_matrix!, :712-720) and next_step_direction <- gradient:
+ * the reset step! performs itself after a gradient-descent step (:981-986), for hosts that restart. */
+int32_t dzo_bfgs_reset(dzo_bfgs_t opt);
 /* get_i: 0 has_terminated (== has_converged, README.md:38) 1 iteration_count 2 n
  *        3 last_step_type 4 objective evaluations so far
  * get_s: 0 current_objective_value 1 last_step_length

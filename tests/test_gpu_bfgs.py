@@ -414,3 +414,22 @@ def test_adgd_fused_run_to_stuck_leaves_a_consistent_state(dtype):
     assert f == pytest.approx(ref_p.eval(x), rel=1e-5 if dtype == np.float32 else 1e-12, abs=1e-30)
     opt.step()
     assert opt.iteration_count == its and np.array_equal(opt.current_point.to_host(), x)
+
+
+def test_bfgs_reset_restores_identity_and_gradient_direction():
+    """dzo_bfgs_reset = the reset step! performs after a gradient-descent step (legacy :981-986)."""
+    n = 48
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    opt = dzo.BFGSOptimizer(dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0)
+    for _ in range(40):
+        opt.step()
+        if opt.last_step_type == 2:                               # a BFGS step: H has been updated
+            break
+    H = opt.approximate_inverse_hessian.to_host().reshape(n, n)
+    assert opt.last_step_type == 2 and not np.array_equal(H, np.eye(n))
+    opt.reset_inverse_hessian()
+    assert np.array_equal(opt.approximate_inverse_hessian.to_host().reshape(n, n), np.eye(n))
+    assert np.array_equal(opt.next_step_direction.to_host(), opt.current_gradient.to_host())
+    f = opt.current_objective_value
+    opt.step()
+    assert opt.current_objective_value < f
