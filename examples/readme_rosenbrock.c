@@ -6,7 +6,8 @@
  *
  * The objective and the gradient are the CALLER's functions (host callbacks that read and write
  * device memory through dzo_memcpy_*), exactly as a Julia host would supply them; a second run
- * uses the library's built-in device objective and an L-BFGS optimizer on the chained problem.
+ * uses the library's built-in device objective and an L-BFGS optimizer on the chained problem, a
+ * third the AdGD optimizer.
  *
  *   gcc -O2 -Iinclude examples/readme_rosenbrock.c -Ldzoptimization.jl_amd -ldzo_hip \
  *       -Wl,-rpath,$PWD/dzoptimization.jl_amd -o readme_rosenbrock && ./readme_rosenbrock
@@ -98,10 +99,33 @@ int main(void) {
            (long long)n, (long long)iters, f, worst);
     const int ok2 = stuck && f < 1e-18 && worst < 1e-8;
     CHECK(dzo_lbfgs_destroy(lb));
+
+    /* ---- AdGDOptimizer(nothing, f, g!, x0, 0.1) (src/DZOptimization.jl:245-251), same objective ---- */
+    for (int64_t i = 0; i < n; ++i) h[i] = (i % 2 == 0) ? -1.2 : 1.0;
+    CHECK(dzo_memcpy_h2d(xd, h, n * (int64_t)sizeof(double)));
+    dzo_adgd_t ad = NULL;
+    CHECK(dzo_adgd_create_problem(prob, xd, 0.1, &ad));
+    double f_start = 0, f_prev = 0;
+    CHECK(dzo_adgd_get_s(ad, 0, &f_start));
+    f_prev = f_start;
+    int monotone = 1;
+    stuck = 0;
+    for (iters = 0; iters < 2000 && !stuck; ++iters) {
+        CHECK(dzo_adgd_step(ad));                          /* step!(opt) (:270-312) */
+        CHECK(dzo_adgd_get_i(ad, 0, &stuck));
+        CHECK(dzo_adgd_get_s(ad, 0, &f));
+        if (!stuck && !(f < f_prev)) monotone = 0;         /* :139: accepted steps strictly decrease f */
+        f_prev = f;
+    }
+    printf("AdGD   chained Rosenbrock n=%lld (device objective): %lld steps, f = %.6e -> %.6e\n",
+           (long long)n, (long long)iters, f_start, f);
+    const int ok3 = monotone && f < 0.5 * f_start;
+    CHECK(dzo_adgd_destroy(ad));
     CHECK(dzo_problem_destroy(prob));
     CHECK(dzo_free(xd));
     free(h);
     CHECK(dzo_shutdown());
+    if (!ok3) { fprintf(stderr, "FAILED: AdGD did not decrease the objective monotonically\n"); return 3; }
     if (!ok1 || !ok2) { fprintf(stderr, "FAILED: did not converge to (1, ..., 1)\n"); return 2; }
     printf("OK\n");
     return 0;
