@@ -147,6 +147,8 @@ ABI = {
     "dzo_fill": [_i64, _i32, _dbl, _vp], "dzo_dot": [_i64, _i32, _vp, _vp, _P(_dbl)],
     "dzo_nrm2": [_i64, _i32, _vp, _P(_dbl)], "dzo_isequal": [_i64, _i32, _vp, _vp, _P(_i32)],
     "dzo_trial_point": [_i64, _i32, _vp, _dbl, _vp, _vp],
+    "dzo_norm2": [_i64, _i32, _vp, _P(_dbl)], "dzo_inv_norm": [_i64, _i32, _vp, _P(_dbl)],
+    "dzo_negate": [_i64, _i32, _vp], "dzo_scal_oop": [_i64, _i32, _vp, _dbl, _vp],
     "dzo_problem_create": [_i32, _i64, _i32, _vp, _vp, _dbl, _P(_vp)], "dzo_problem_destroy": [_vp],
     "dzo_problem_eval": [_vp, _vp, _P(_dbl)], "dzo_problem_grad": [_vp, _vp, _vp],
     "dzo_problem_set_l2": [_vp, _dbl], "dzo_problem_set_box_gradient": [_vp, _i32, _dbl, _dbl],
@@ -186,11 +188,18 @@ ABI = {
     "dzo_bfgs_line_search": [_vp, _i32, _dbl, _P(_dbl), _P(_dbl)], "dzo_bfgs_set_max_increases": [_vp, _i32], "dzo_bfgs_reset": [_vp],
     "dzo_bfgs_get_i": [_vp, _i32, _P(_i64)], "dzo_bfgs_get_s": [_vp, _i32, _P(_dbl)],
     "dzo_bfgs_get_ptr": [_vp, _i32, _P(_vp)],
+    "dzo_bfgs_set_s": [_vp, _i32, _dbl], "dzo_bfgs_set_i": [_vp, _i32, _i64],
     "dzo_gd_create_callbacks": [CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp, _i64, _i32, _vp, _dbl, _P(_vp)],
     "dzo_gd_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_gd_step": [_vp],
     "dzo_bfgs_batch_create": [_i32, _i64, _i64, _i32, _vp, _dbl, _P(_vp)], "dzo_bfgs_batch_destroy": [_vp],
     "dzo_bfgs_batch_step": [_vp, _i32, _P(_i32)], "dzo_bfgs_batch_get_ptr": [_vp, _i32, _P(_vp)],
     "dzo_bfgs_batch_count_active": [_vp, _P(_i64)],
+    "dzo_bfgs_batch_create_on": [_i32, _i32, _i64, _i64, _i32, _vp, _dbl, _P(_vp)], "dzo_bfgs_batch_device": [_vp, _P(_i32)],
+    "dzo_comm_unique_id": [_vp], "dzo_comm_init_rank": [_vp, _i32, _i32, _P(_vp)],
+    "dzo_comm_init_all": [_P(_i32), _i32, _P(_vp)], "dzo_comm_destroy": [_vp],
+    "dzo_comm_info": [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i64)],
+    "dzo_flag_allreduce_min": [_vp, _P(_i32), _P(_i32)],
+    "dzo_bfgs_batch_all_done": [_vp, _P(_vp), _i32, _P(_i32)],
 }
 
 
@@ -324,6 +333,32 @@ def norm(x):
 def isequal(a, b):
     r = C.c_int32()
     _check(lib().dzo_isequal(a.size, _dt(a.dtype), a.ptr, b.ptr, C.byref(r))); return bool(r.value)
+
+
+# legacy/Kernels.jl primitives without a LinearAlgebra twin
+def norm2(x):
+    """``norm2(x)``: the sum of squares, not its root (legacy/Kernels.jl:49-55,139)."""
+    r = C.c_double()
+    _check(lib().dzo_norm2(x.size, _dt(x.dtype), x.ptr, C.byref(r))); return r.value
+
+
+def inv_norm(x):
+    """``inv_norm(x) = rsqrt(norm2(x))`` (legacy/Kernels.jl:141)."""
+    r = C.c_double()
+    _check(lib().dzo_inv_norm(x.size, _dt(x.dtype), x.ptr, C.byref(r))); return r.value
+
+
+def negate_(x):
+    """``negate!(x)`` (legacy/Kernels.jl:76-83)."""
+    _check(lib().dzo_negate(x.size, _dt(x.dtype), x.ptr)); return x
+
+
+def scale_(dst, alpha, x=None):
+    """``scale!(x, alpha)`` in place (legacy/Kernels.jl:87-94) or ``scale!(dst, alpha, x)`` out of
+    place (:96-104)."""
+    if x is None:
+        return rmul_(dst, alpha)
+    _check(lib().dzo_scal_oop(x.size, _dt(x.dtype), dst.ptr, alpha, x.ptr)); return dst
 
 
 def box_clamp_(x, lower_bound, upper_bound):
@@ -756,6 +791,28 @@ class BFGSOptimizer(_OptBase):
         _check(lib().dzo_bfgs_reset(self.h))
         return self
 
+    def install_state(self, x, g, H, d, f, last_step_length, iteration_count=0, last_step_type=STEP_NULL,
+                      dx=None, dg=None):
+        """Overwrite the whole optimizer state (every field of the reference's struct is public,
+        legacy/DZOptimization.jl:733-751; README.md:11 "save/load data in the middle of optimization").
+        ``H``: (n, n) symmetric or column-major host array."""
+        dt = self.dtype
+        self.current_point.upload(np.asarray(x, dt))
+        self.current_gradient.upload(np.asarray(g, dt))
+        self.approximate_inverse_hessian.upload(np.ascontiguousarray(np.asarray(H, dt).T))   # column-major on the device
+        self.next_step_direction.upload(np.asarray(d, dt))
+        if dx is not None:
+            self.delta_point.upload(np.asarray(dx, dt))
+        if dg is not None:
+            self.delta_gradient.upload(np.asarray(dg, dt))
+        L = lib()
+        _check(L.dzo_bfgs_set_s(self.h, 0, float(f)))
+        _check(L.dzo_bfgs_set_s(self.h, 1, float(last_step_length)))
+        _check(L.dzo_bfgs_set_i(self.h, 0, 0))
+        _check(L.dzo_bfgs_set_i(self.h, 1, int(iteration_count)))
+        _check(L.dzo_bfgs_set_i(self.h, 3, int(last_step_type)))
+        return self
+
 
 class GradientDescentOptimizer(BFGSOptimizer):
     """``GradientDescentOptimizer([constraint_function!,] objective_function, gradient_function!,
@@ -818,16 +875,31 @@ def symv_(out, H, v):
 class BatchedBFGS:
     """B independent ``BFGSOptimizer`` instances on one device (config 5)."""
 
-    def __init__(self, problem_kind, x0, initial_step_length):
+    def __init__(self, problem_kind, x0, initial_step_length, device=None):
+        """``device``: the GPU this shard lives on (default: the device selected with ``init``); a host that
+        drives several shards from one process passes each shard's device and a :class:`Comm` built with
+        ``Comm.init_all``."""
         _need_init()
+        if device is not None:
+            init(int(device))                           # x0 is uploaded to that device
         x0 = _as_dev(x0)
         self.batch, self.n = x0.shape
         self.dtype = x0.dtype
         self._x0 = x0
         h = C.c_void_p()
-        _check(lib().dzo_bfgs_batch_create(problem_kind, self.batch, self.n, _dt(self.dtype), x0.ptr,
-                                           initial_step_length, C.byref(h)))
+        if device is None:
+            _check(lib().dzo_bfgs_batch_create(problem_kind, self.batch, self.n, _dt(self.dtype), x0.ptr,
+                                               initial_step_length, C.byref(h)))
+        else:
+            _check(lib().dzo_bfgs_batch_create_on(int(device), problem_kind, self.batch, self.n, _dt(self.dtype), x0.ptr,
+                                                  initial_step_length, C.byref(h)))
         self.h = h
+
+    @property
+    def device(self):
+        v = C.c_int32()
+        _check(lib().dzo_bfgs_batch_device(self.h, C.byref(v)))
+        return v.value
 
     def step(self, steps=1, poll=True):
         """Runs ``steps`` step! calls on every live instance; returns all_done if ``poll``."""
@@ -857,6 +929,26 @@ class BatchedBFGS:
         _check(lib().dzo_bfgs_batch_count_active(self.h, C.byref(v)))
         return v.value
 
+    def install_state(self, x, g, H, d, f, last_step_length, iteration_count=None, last_step_type=None,
+                      has_terminated=None, dx=None, dg=None):
+        """Overwrite the state of every instance: the arrays behind ``dzo_bfgs_batch_get_ptr`` ARE the
+        state (include/dzo.h).  ``H``: (B, n, n), each symmetric or column-major."""
+        B, n, dt = self.batch, self.n, self.dtype
+        self.current_point.upload(np.asarray(x, dt).reshape(B, n))
+        self.current_gradient.upload(np.asarray(g, dt).reshape(B, n))
+        self.approximate_inverse_hessian.upload(np.ascontiguousarray(np.transpose(np.asarray(H, dt).reshape(B, n, n), (0, 2, 1))))
+        self.next_step_direction.upload(np.asarray(d, dt).reshape(B, n))
+        self.current_objective_value.upload(np.asarray(f, np.float64).reshape(B))
+        self.last_step_length.upload(np.asarray(last_step_length, np.float64).reshape(B))
+        self.iteration_count.upload(np.zeros(B, np.int64) if iteration_count is None else np.asarray(iteration_count, np.int64))
+        self.last_step_type.upload(np.zeros(B, np.int32) if last_step_type is None else np.asarray(last_step_type, np.int32))
+        self.has_terminated.upload(np.zeros(B, np.int32) if has_terminated is None else np.asarray(has_terminated, np.int32))
+        if dx is not None:
+            self.delta_point.upload(np.asarray(dx, dt).reshape(B, n))
+        if dg is not None:
+            self.delta_gradient.upload(np.asarray(dg, dt).reshape(B, n))
+        return self
+
     def close(self):
         if getattr(self, "h", None) and _lib is not None:
             lib().dzo_bfgs_batch_destroy(self.h)
@@ -869,14 +961,124 @@ class BatchedBFGS:
             pass
 
 
+def _preload_rccl():
+    """Same reasoning as _preload_hip_runtime: libdzo_hip.so dlopen()s librccl.so.1 at first use; when
+    PyTorch is installed its bundled copy (same SONAME) must be the one in the process."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+class Comm:
+    """The one collective of the design (include/dzo.h): all-reduce(MIN) of the convergence flag of
+    sharded independent optimizers over RCCL / xGMI, behind the C ABI.
+
+    ``Comm.init_all(devices)``: one process, several GPUs (ncclCommInitAll).
+    ``Comm.init_rank(uid, nranks, rank)``: one process per GPU; ``Comm.unique_id()`` on rank 0, carried to
+    the other ranks by the launcher (``Comm.from_torch_distributed()`` does that over an initialised
+    ``torch.distributed`` group)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        _need_init()
+        _preload_rccl()
+        buf = C.create_string_buffer(128)
+        _check(lib().dzo_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid: bytes, nranks: int, rank: int):
+        _need_init()
+        _preload_rccl()
+        assert len(uid) == 128
+        h = C.c_void_p()
+        _check(lib().dzo_comm_init_rank(C.create_string_buffer(uid, 128), nranks, rank, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, devices):
+        lib()
+        _preload_rccl()
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _check(lib().dzo_comm_init_all(arr, len(devices), C.byref(h)))
+        global _inited
+        _inited = True
+        return cls(h)
+
+    @classmethod
+    def from_torch_distributed(cls):
+        """One rank per process of an initialised ``torch.distributed`` group: rank 0's unique id is
+        broadcast through the group (any backend), then every rank joins."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.init_rank(box[0], world, rank)
+
+    def _info(self):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        _check(lib().dzo_comm_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    nranks = property(lambda s: s._info()[0])
+    nlocal = property(lambda s: s._info()[1])
+    first_rank = property(lambda s: s._info()[2])
+    collectives = property(lambda s: s._info()[3])
+
+    def allreduce_min(self, local_flags) -> int:
+        flags = [int(local_flags)] if np.isscalar(local_flags) or isinstance(local_flags, bool) else [int(f) for f in local_flags]
+        arr = (C.c_int32 * len(flags))(*flags)
+        out = C.c_int32()
+        _check(lib().dzo_flag_allreduce_min(self.h, arr, C.byref(out)))
+        return out.value
+
+    def all_done(self, batches) -> bool:
+        """``dzo_bfgs_batch_all_done``: every instance of every shard (local and remote) has terminated."""
+        hs = (C.c_void_p * len(batches))(*[b.h for b in batches])
+        out = C.c_int32()
+        _check(lib().dzo_bfgs_batch_all_done(self.h, hs, len(batches), C.byref(out)))
+        return bool(out.value)
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            lib().dzo_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def batches_all_done(batches, comm=None) -> bool:
+    """``dzo_bfgs_batch_all_done`` with or without a communicator."""
+    hs = (C.c_void_p * len(batches))(*[b.h for b in batches])
+    out = C.c_int32()
+    _check(lib().dzo_bfgs_batch_all_done(comm.h if comm is not None else None, hs, len(batches), C.byref(out)))
+    return bool(out.value)
+
+
 def step_(opt):
     """``step!(opt)``: the reference's generic function (src/DZOptimization.jl:104)."""
     return opt.step()
 
 
 __all__ = [
-    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
+    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "Comm", "batches_all_done", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
     "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
+    "norm2", "inv_norm", "negate_", "scale_",
     "update_inverse_hessian_", "update_inverse_hessian_mfma_", "symv_", "init", "build", "lib", "device_info", "synchronize",
     "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",
 ]

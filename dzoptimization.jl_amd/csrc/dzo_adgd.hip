@@ -9,7 +9,7 @@ struct dzo_adgd_s {
     dzo::OptCore core;
     double current_step_size = 0;    // :195
     double previous_step_size = 0;   // :196
-    void *dx_buf = nullptr, *dg_buf = nullptr;
+    void *dx_buf = nullptr, *dg_buf = nullptr, *dg_alt = nullptr;
     // fused step (built-in chained Rosenbrock): one pass does :301 (first trial), :306-308 and the
     // two sums of squares that :292 / :294 of the NEXT step need
     bool fused = true;               // DZO_TUNE_ADGD_FUSED=0 forces the generic kernel sequence
@@ -178,12 +178,32 @@ __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__res
     }
 }
 
+// Eligibility of the one-pass step, INCLUDING its optional buffers (boundary vectors, x / g backups):
+// they are allocated here, before step! changes anything, and a failed allocation only switches the
+// optimizer to the generic kernel sequence (which needs no extra memory) instead of failing the step.
 static bool adgd_fused_ok(dzo_adgd_s *o) {
     OptCore &c = o->core;
     if (!o->fused || c.objective || c.gradient || c.constraint || c.box_on || !c.problem) return false;
     const int vecn = 16 / (int)dtype_size(c.dtype);
     if (c.n % vecn != 0 || c.n < 4 * vecn) return false;
-    return problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
+    if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg)) return false;
+    const size_t es = dtype_size(c.dtype);
+    if (!o->halo) {
+        const int64_t rows = (c.n / vecn + kAdgdOwn - 1) / kAdgdOwn;
+        if (hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16) != hipSuccess) { (void)hipGetLastError(); o->halo = nullptr; o->fused = false; return false; }
+    }
+    if (!o->bak) {
+        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * es;
+        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;             // an odd number of KiB apart
+        if (hipMalloc(&o->bak, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->bak = nullptr; o->fused = false; return false; }
+        o->xbak = (char *)o->bak + 5 * 1024;
+        o->gbak = (char *)o->xbak + slot;
+    }
+    if (!o->dg_alt) {
+        const size_t bytes = (size_t)((c.n + 63) / 64 * 64) * es;
+        if (hipMalloc(&o->dg_alt, bytes) != hipSuccess) { (void)hipGetLastError(); o->dg_alt = nullptr; o->fused = false; return false; }
+    }
+    return true;
 }
 
 // The whole step on fused passes: first trial in place; after a rejection the halving loop of
@@ -197,18 +217,14 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     const int64_t nvec = c.n / N;
     const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
     const size_t halo_elems = (size_t)rows * 2 * 2 * N;
-    if (!o->halo) DZO_HIP(hipMalloc(&o->halo, 2 * halo_elems * sizeof(T)));
-    if (!o->bak) {
-        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
-        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;             // an odd number of KiB apart
-        DZO_HIP(hipMalloc(&o->bak, 2 * slot + 16 * 1024));
-        o->xbak = (char *)o->bak + 5 * 1024;
-        o->gbak = (char *)o->xbak + slot;
-    }
     AdgdFusedParams<T> fp;
     fp.n = c.n;
     fp.x = (T *)c.x; fp.g = (T *)c.g; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
-    fp.dx = (T *)c.dx; fp.dg = (T *)c.dg;
+    // delta_gradient is written into the OTHER of two buffers and the pointers swap when the step is
+    // accepted: a step that ends stuck leaves the previous step's delta_gradient untouched, as
+    // take_backtracking_step! does (:128-130 returns before anything but delta_point was written)
+    void *dg_new = (c.dg == o->dg_buf) ? o->dg_alt : o->dg_buf;
+    fp.dx = (T *)c.dx; fp.dg = (T *)dg_new;
     fp.halo = (const T *)o->halo + (size_t)o->halo_cur * halo_elems;
     fp.halo_next = (T *)o->halo + (size_t)(o->halo_cur ^ 1) * halo_elems;
     fp.partials = c.partials();
@@ -229,6 +245,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
         const size_t bytes = (size_t)c.n * sizeof(T);
         DZO_HIP(hipMemcpyAsync(c.x, o->xbak, bytes, hipMemcpyDeviceToDevice, s));
         DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
+        DZO_HIP(hipMemcpyAsync(c.dx, o->xbak, bytes, hipMemcpyDeviceToDevice, s));   // :118 delta_point holds x_old when the search gives up
         return DZO_OK;
     };
     *done = true;
@@ -260,6 +277,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
             c.f = f_new;                                                     // :144
             o->norm2[0] = c.host[5]; o->norm2[1] = c.host[6];
             o->norms_ready = true;
+            c.dg = dg_new;                                                   // (the previous delta_gradient buffer is the next step's target)
             o->halo_cur ^= 1; o->halo_valid = true;
             o->fused_steps += 1;
             if (!first) o->fused_rejections += 1;
@@ -286,7 +304,12 @@ static int32_t adgd_step(dzo_adgd_s *o) {
     if (c.is_stuck) return DZO_OK;                                   // :276-278
     DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
                 "step! needs objective and gradient (callbacks or a built-in problem)");
+    if (c.problem && c.problem->parent) {
+        problem_view_sync(c.problem);
+        c.box_on = c.problem->cons_on; c.box_lo = c.problem->cons_lo; c.box_hi = c.problem->cons_hi;
+    }
     const int32_t dt = c.dtype;
+    const bool fused_ok = adgd_fused_ok(o);                          // (may allocate; before any state changes)
     const double half = 0.5;
     const double inv_sqrt_two = dt == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);   // :283
     const double previous = o->previous_step_size;                   // :285
@@ -313,7 +336,7 @@ static int32_t adgd_step(dzo_adgd_s *o) {
     o->previous_step_size = current;                                 // :298
     o->current_step_size = next;                                     // :299
     o->norms_ready = false;
-    if (adgd_fused_ok(o)) {
+    if (fused_ok) {
         bool done = false;
         DZO_DISPATCH(dt, DZO_TRY(adgd_fused_step<T>(o, next, &done)));
         if (done) {
@@ -383,7 +406,8 @@ int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initi
     if (rc == DZO_OK) rc = dzo_adgd_create(problem->n, problem->dtype, x_dev, g, f0, initial_step_length, out);
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
-    (*out)->core.problem = problem;
+    rc = problem_view_create(problem, &(*out)->core.problem);    // private partial-sum workspace per optimizer
+    if (rc != DZO_OK) { dzo_adgd_destroy(*out); *out = nullptr; return rc; }
     (*out)->core.box_on = problem->cons_on; (*out)->core.box_lo = problem->cons_lo; (*out)->core.box_hi = problem->cons_hi;
     return DZO_OK;
 }
@@ -393,6 +417,7 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->dx_buf) (void)hipFree(o->dx_buf);
     if (o->dg_buf) (void)hipFree(o->dg_buf);
+    if (o->dg_alt) (void)hipFree(o->dg_alt);
     if (o->halo) (void)hipFree(o->halo);
     if (o->bak) (void)hipFree(o->bak);
     core_free(o->core);

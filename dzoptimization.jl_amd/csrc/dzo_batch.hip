@@ -395,6 +395,7 @@ __global__ __launch_bounds__(kBlock) void batch_count_active_kernel(const int32_
 
 struct dzo_bfgs_batch_s {
     dzo::BatchState st;
+    int device = 0;                     // the shard's GPU; every entry point enters it (DeviceScope)
     int32_t dtype = DZO_F64;
     hipStream_t stream = nullptr;
     unsigned long long *count_dev = nullptr;
@@ -405,10 +406,33 @@ struct dzo_bfgs_batch_s {
 
 using namespace dzo;
 
+namespace dzo {
+int batch_device(const dzo_bfgs_batch_s *b) { return b->device; }
+
+// count of live instances, split so that several shards can count concurrently
+int32_t batch_count_active_enqueue(dzo_bfgs_batch_s *b) {
+    DeviceScope scope(b->device);
+    DZO_HIP(hipMemsetAsync(b->count_dev, 0, sizeof(unsigned long long), b->stream));
+    int grid = (int)((b->st.batch + kBlock - 1) / kBlock);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(batch_count_active_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->st.has_terminated, b->st.batch, b->count_dev);
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipMemcpyAsync(b->count_host, b->count_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    return DZO_OK;
+}
+int32_t batch_count_active_finish(dzo_bfgs_batch_s *b, int64_t *active) {
+    DeviceScope scope(b->device);
+    DZO_HIP(hipStreamSynchronize(b->stream));
+    *active = (int64_t)*b->count_host;
+    return DZO_OK;
+}
+}  // namespace dzo
+
 extern "C" {
 
 int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b) {
     if (!b) return DZO_OK;
+    DeviceScope scope(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->st.x, b->st.g, b->st.dx, b->st.dg, b->st.d, b->st.H, b->st.f, b->st.last_step_length,
                     b->st.last_step_type, b->st.has_terminated, b->st.iteration_count, b->count_dev};
@@ -431,6 +455,7 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
                 "batched mode needs an even n in 2..1024 (got %lld)", (long long)n);
     dzo_bfgs_batch_s *b = new dzo_bfgs_batch_s();
     b->dtype = dtype;
+    b->device = ctx().device;
     b->st.batch = batch; b->st.n = n;
     b->rp = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
     const size_t es = dtype_size(dtype);
@@ -472,20 +497,32 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
 
 int32_t dzo_bfgs_batch_count_active(dzo_bfgs_batch_t b, int64_t *active) {
     DZO_REQUIRE(b && active, DZO_ERR_INVALID, "null argument");
-    DZO_HIP(hipMemsetAsync(b->count_dev, 0, sizeof(unsigned long long), b->stream));
-    int grid = (int)((b->st.batch + kBlock - 1) / kBlock);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(batch_count_active_kernel, dim3(grid), dim3(kBlock), 0, b->stream, b->st.has_terminated, b->st.batch, b->count_dev);
-    DZO_HIP(hipGetLastError());
-    DZO_HIP(hipMemcpyAsync(b->count_host, b->count_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
-    DZO_HIP(hipStreamSynchronize(b->stream));
-    *active = (int64_t)*b->count_host;
-    return DZO_OK;
+    DZO_TRY(batch_count_active_enqueue(b));
+    return batch_count_active_finish(b, active);
+}
+
+// The same constructor on an explicit device: a host that shards instances over the GPUs of a node
+// from ONE process (dzo_comm_init_all) creates one shard per device.  x0_dev must live on `device`.
+int32_t dzo_bfgs_batch_create_on(int32_t device, int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype,
+                                 const void *x0_dev, double initial_step_length, dzo_bfgs_batch_t *out) {
+    int count = 0;
+    DZO_HIP(hipGetDeviceCount(&count));
+    DZO_REQUIRE(device >= 0 && device < count && device < kMaxDevices, DZO_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+    const int prev = ctx().ready ? ctx().device : -1;
+    DZO_TRY(dzo_init(device));                          // makes sure the device has a library context
+    int32_t rc;
+    {
+        DeviceScope scope(device);
+        rc = dzo_bfgs_batch_create(problem_kind, batch, n, dtype, x0_dev, initial_step_length, out);
+    }
+    if (prev >= 0 && prev != device) (void)dzo_init(prev);   // the calling thread stays on the device it had selected
+    return rc;
 }
 
 int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done) {
     DZO_REQUIRE(b, DZO_ERR_INVALID, "null batch");
     DZO_REQUIRE(steps >= 0, DZO_ERR_INVALID, "negative step count");
+    DeviceScope scope(b->device);
     if (steps > 0) {
         DZO_TIMED("bfgs_batch_step", b->stream);
         const dim3 grid((unsigned)b->st.batch), block(kBlock);
@@ -505,6 +542,7 @@ int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done
 
 int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev) {
     DZO_REQUIRE(b && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(b->device);
     DZO_HIP(hipStreamSynchronize(b->stream));
     switch (what) {
     case 0: *ptr_dev = b->st.x; break;
@@ -520,6 +558,12 @@ int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev)
     case 10: *ptr_dev = b->st.last_step_type; break;
     default: set_error("dzo_bfgs_batch_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
     }
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_batch_device(dzo_bfgs_batch_t b, int32_t *device) {
+    DZO_REQUIRE(b && device, DZO_ERR_INVALID, "null argument");
+    *device = b->device;
     return DZO_OK;
 }
 

@@ -876,6 +876,7 @@ static int32_t bfgs_move(dzo_bfgs_s *o, double t, const void *dir, const void *g
 
 static int32_t bfgs_step(dzo_bfgs_s *o) {
     if (o->has_terminated) return DZO_OK;                        // :893
+    problem_view_sync(o->problem);
     const int32_t dt = o->dtype;
     const size_t bytes = (size_t)o->n * dtype_size(dt);
     const double step_length = o->last_step_length;              // :918
@@ -1059,6 +1060,7 @@ static int32_t gd_create_common(dzo_bfgs_s *o, const void *x0_dev, double initia
 
 static int32_t gd_step(dzo_bfgs_s *o) {
     if (o->has_terminated) return DZO_OK;                        // :402
+    problem_view_sync(o->problem);
     const int32_t dt = o->dtype;
     const size_t bytes = (size_t)o->n * dtype_size(dt);
     hipStream_t s = o->stream;
@@ -1104,8 +1106,9 @@ int32_t dzo_gd_create_problem(dzo_problem_t problem, const void *x0_dev, double 
     DZO_TRY(require_init());
     DZO_REQUIRE(problem && x0_dev && out, DZO_ERR_INVALID, "null argument");
     dzo_bfgs_s *o = new dzo_bfgs_s();
-    o->n = problem->n; o->dtype = problem->dtype; o->problem = problem;
-    int32_t rc = gd_create_common(o, x0_dev, initial_step_length);
+    o->n = problem->n; o->dtype = problem->dtype;
+    int32_t rc = problem_view_create(problem, &o->problem);
+    if (rc == DZO_OK) rc = gd_create_common(o, x0_dev, initial_step_length);
     if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
     *out = o;
     return DZO_OK;
@@ -1138,6 +1141,7 @@ int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
                     o->spec_buf[3], o->grad_pool, o->H, o->ws, o->upd_part};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
+    problem_view_destroy(o->problem);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     delete o;
     return DZO_OK;
@@ -1162,8 +1166,9 @@ int32_t dzo_bfgs_create_problem(dzo_problem_t problem, const void *x0_dev, doubl
     DZO_TRY(require_init());
     DZO_REQUIRE(problem && x0_dev && out, DZO_ERR_INVALID, "null argument");
     dzo_bfgs_s *o = new dzo_bfgs_s();
-    o->n = problem->n; o->dtype = problem->dtype; o->problem = problem;
-    int32_t rc = bfgs_create_common(o, x0_dev, initial_step_length);
+    o->n = problem->n; o->dtype = problem->dtype;
+    int32_t rc = problem_view_create(problem, &o->problem);        // private partial-sum workspace per optimizer
+    if (rc == DZO_OK) rc = bfgs_create_common(o, x0_dev, initial_step_length);
     if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
     *out = o;
     return DZO_OK;
@@ -1174,8 +1179,9 @@ int32_t dzo_bfgs_convert_problem(dzo_bfgs_t src, dzo_problem_t problem, dzo_bfgs
     DZO_REQUIRE(src && problem && out, DZO_ERR_INVALID, "null argument");
     DZO_REQUIRE(problem->n == src->n, DZO_ERR_INVALID, "problem size does not match the optimizer");
     dzo_bfgs_s *o = new dzo_bfgs_s();
-    o->n = src->n; o->dtype = problem->dtype; o->problem = problem;
-    int32_t rc = bfgs_convert(src, o);
+    o->n = src->n; o->dtype = problem->dtype;
+    int32_t rc = problem_view_create(problem, &o->problem);
+    if (rc == DZO_OK) rc = bfgs_convert(src, o);
     if (rc != DZO_OK) { dzo_bfgs_destroy(o); return rc; }
     *out = o;
     return DZO_OK;
@@ -1254,6 +1260,7 @@ int32_t dzo_symv(int64_t n, int32_t dtype, const void *H_dev, const void *v_dev,
 
 int32_t dzo_bfgs_line_search(dzo_bfgs_t o, int32_t use_gradient_direction, double t0, double *t_best, double *f_best) {
     DZO_REQUIRE(o && t_best && f_best, DZO_ERR_INVALID, "null argument");
+    problem_view_sync(o->problem);
     return bfgs_quadratic_search(o, use_gradient_direction ? o->g : o->d, o->f, t0, t_best, f_best);
 }
 
@@ -1288,6 +1295,39 @@ int32_t dzo_bfgs_get_s(dzo_bfgs_t o, int32_t what, double *value) {
     DZO_REQUIRE(o && value, DZO_ERR_INVALID, "null argument");
     DZO_REQUIRE(what >= 0 && what <= 2, DZO_ERR_INVALID, "unknown field %d", what);
     *value = what == 0 ? o->f : (what == 1 ? o->last_step_length : o->df);
+    return DZO_OK;
+}
+
+// Install host-side state (checkpoint / resume, and per-step parity tests that upload the CPU
+// reference's state before every step).  The device arrays are written through dzo_bfgs_get_ptr.
+int32_t dzo_bfgs_set_s(dzo_bfgs_t o, int32_t what, double value) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_REQUIRE(what >= 0 && what <= 2, DZO_ERR_INVALID, "unknown field %d", what);
+    const double v = round_to_dtype(o->dtype, value);
+    if (what == 0) {
+        DZO_REQUIRE(!(v != v), DZO_ERR_ASSERT, "@assert !isnan(objective value) (legacy/DZOptimization.jl:773)");
+        o->f = v;
+    } else if (what == 1) {
+        o->last_step_length = v;
+    } else {
+        o->df = v;
+    }
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_set_i(dzo_bfgs_t o, int32_t what, int64_t value) {
+    DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    switch (what) {
+    case 0: o->has_terminated = value != 0; break;
+    case 1: DZO_REQUIRE(value >= 0, DZO_ERR_INVALID, "negative iteration_count"); o->iteration_count = value; break;
+    case 3:
+        DZO_REQUIRE(value == DZO_STEP_NULL || value == DZO_STEP_GRADIENT_DESCENT || value == DZO_STEP_BFGS, DZO_ERR_INVALID,
+                    "unknown step type %lld", (long long)value);
+        o->last_step_type = (int32_t)value;
+        break;
+    case 4: DZO_REQUIRE(value >= 0, DZO_ERR_INVALID, "negative evaluation count"); o->evals = value; break;
+    default: set_error("dzo_bfgs_set_i: field %d is not settable", what); return DZO_ERR_INVALID;
+    }
     return DZO_OK;
 }
 

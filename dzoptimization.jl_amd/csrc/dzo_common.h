@@ -62,8 +62,24 @@ struct Context {
     double *scratch = nullptr;          // device: partial sums for handle-less reductions
     double *host_scalar = nullptr;      // pinned host: results of blocking reductions
 };
+// One context per HIP device; ctx() is the context of the device the CALLING THREAD last selected
+// with dzo_init (or entered through a DeviceScope), the first initialised device otherwise.
 Context &ctx();
 int32_t require_init();
+constexpr int kMaxDevices = 32;
+
+// Enter `device` for the lifetime of the scope (HIP's current device of this thread and the
+// library context), then return to where the thread was.  Entry points of handles that record
+// their device (the batched optimizer, the communicator) use it so that one host thread can drive
+// shards on several GPUs.
+struct DeviceScope {
+    int prev_hip = -1, prev_ctx = -1;
+    bool active = false;
+    explicit DeviceScope(int device);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 
 // streaming-kernel grid: enough blocks to fill 256 CUs x 8, grid-stride the rest
 inline int stream_grid(int64_t n, int elems_per_thread) {

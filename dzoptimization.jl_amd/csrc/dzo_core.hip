@@ -20,9 +20,29 @@ int32_t hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return DZO_ERR_HIP;
 }
 
+static Context g_ctx[kMaxDevices];
+static int g_default_device = -1;              // first device initialised in this process
+static thread_local int tl_device = -1;        // device selected by this thread (dzo_init / DeviceScope)
+
 Context &ctx() {
-    static Context c;
-    return c;
+    const int d = tl_device >= 0 ? tl_device : g_default_device;
+    return g_ctx[d >= 0 ? d : 0];
+}
+
+DeviceScope::DeviceScope(int device) {
+    if (device < 0 || device >= kMaxDevices) return;
+    prev_ctx = tl_device;
+    if (hipGetDevice(&prev_hip) != hipSuccess) prev_hip = -1;
+    if (prev_hip != device) (void)hipSetDevice(device);
+    tl_device = device;
+    active = true;
+}
+
+DeviceScope::~DeviceScope() {
+    if (!active) return;
+    tl_device = prev_ctx;
+    int cur = -1;
+    if (prev_hip >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev_hip) (void)hipSetDevice(prev_hip);
 }
 
 int32_t require_init() {
@@ -119,7 +139,6 @@ int32_t dzo_version(void) { return DZO_VERSION; }
 const char *dzo_last_error(void) { return g_error; }
 
 int32_t dzo_init(int32_t device) {
-    Context &c = ctx();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -127,10 +146,15 @@ int32_t dzo_init(int32_t device) {
                   hipGetErrorString(e));
         return DZO_ERR_HIP;
     }
-    DZO_REQUIRE(device >= 0 && device < count, DZO_ERR_INVALID, "device %d out of range [0,%d)",
-                device, count);
+    DZO_REQUIRE(device >= 0 && device < count && device < kMaxDevices, DZO_ERR_INVALID, "device %d out of range [0,%d)",
+                device, count < kMaxDevices ? count : kMaxDevices);
     DZO_HIP(hipSetDevice(device));
-    if (c.ready && c.device == device) return DZO_OK;
+    tl_device = device;                        // this thread now works on `device`
+    static std::mutex init_mu;
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (g_default_device < 0) g_default_device = device;
+    Context &c = g_ctx[device];
+    if (c.ready) return DZO_OK;
     hipDeviceProp_t prop;
     DZO_HIP(hipGetDeviceProperties(&prop, device));
     c.device = device;
@@ -145,13 +169,18 @@ int32_t dzo_init(int32_t device) {
 }
 
 int32_t dzo_shutdown(void) {
-    Context &c = ctx();
-    if (!c.ready) return DZO_OK;
-    (void)hipStreamSynchronize(c.stream);
-    (void)hipFree(c.scratch);
-    (void)hipHostFree(c.host_scalar);
-    (void)hipStreamDestroy(c.stream);
-    c = Context();
+    for (int d = 0; d < kMaxDevices; ++d) {
+        Context &c = g_ctx[d];
+        if (!c.ready) continue;
+        DeviceScope scope(d);
+        (void)hipStreamSynchronize(c.stream);
+        (void)hipFree(c.scratch);
+        (void)hipHostFree(c.host_scalar);
+        (void)hipStreamDestroy(c.stream);
+        c = Context();
+    }
+    g_default_device = -1;
+    tl_device = -1;
     return DZO_OK;
 }
 
@@ -207,6 +236,14 @@ int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launch
     return DZO_OK;
 }
 
+// device that owns a device pointer (-1: unknown / host memory -> stay on the current device)
+static int device_of(const void *p) {
+    hipPointerAttribute_t a;
+    if (p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice) return a.device;
+    (void)hipGetLastError();
+    return -1;
+}
+
 int32_t dzo_malloc(void **ptr_dev, int64_t bytes) {
     DZO_TRY(require_init());
     DZO_REQUIRE(ptr_dev && bytes >= 0, DZO_ERR_INVALID, "dzo_malloc: bad arguments");
@@ -221,12 +258,14 @@ int32_t dzo_malloc(void **ptr_dev, int64_t bytes) {
 
 int32_t dzo_free(void *ptr_dev) {
     DZO_TRY(require_init());
+    DeviceScope scope(device_of(ptr_dev));
     if (ptr_dev) DZO_HIP(hipFree(ptr_dev));
     return DZO_OK;
 }
 
 int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes) {
     DZO_TRY(require_init());
+    DeviceScope scope(device_of(dst_dev));
     DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
     DZO_HIP(hipDeviceSynchronize());
@@ -235,6 +274,7 @@ int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes) {
 
 int32_t dzo_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes) {
     DZO_TRY(require_init());
+    DeviceScope scope(device_of(src_dev));
     // every library stream is non-blocking w.r.t. the null stream: drain the device first
     DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
@@ -243,6 +283,7 @@ int32_t dzo_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes) {
 
 int32_t dzo_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes) {
     DZO_TRY(require_init());
+    DeviceScope scope(device_of(dst_dev));
     DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice));
     DZO_HIP(hipDeviceSynchronize());

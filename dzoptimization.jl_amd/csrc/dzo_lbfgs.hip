@@ -1548,7 +1548,13 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     c.defer_delta = false;
     c.speculative_tail = nullptr;
     DZO_TRY(rc);
-    if (c.is_stuck) return DZO_OK;                        // :474-476
+    if (c.is_stuck) {                                     // :474-476
+        // delta_point holds x_old (:118, the first trial's backup); delta_gradient is still the
+        // previous step's, which lives in the newest pair of the ring
+        if (c.xold_src) DZO_HIP(hipMemcpyAsync(c.dx, c.xold_src, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
+        if (o->k > 0) c.dg = o->y_slot_v(o->newest);
+        return DZO_OK;
+    }
     int32_t done = -1;
     if (fused && speculated) {
         done = lbfgs_finish_push(o, 0, true);             // the gated tail already ran
@@ -1583,6 +1589,22 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
     if (c.n % vecn != 0 || c.n < 4 * vecn || (uint64_t)c.n * dtype_size(c.dtype) >= (1ull << 32)) return false;   // 32-bit byte offsets
     o->refresh_delta_ptrs();
     if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg) || !al16v(o->d)) return false;
+    // optional buffers of the pass (row-boundary vectors, x / g backups): allocated here, before the step
+    // touches anything; a failed allocation only switches this optimizer to the two-pass kernels
+    if (!o->halo) {
+        const int64_t rows = (c.n / vecn + kRowOwn - 1) / kRowOwn;
+        if (hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16) != hipSuccess) { (void)hipGetLastError(); o->halo = nullptr; o->single_pass = false; return false; }
+    }
+    if (!o->bak_slab) {
+        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * dtype_size(c.dtype);
+        // one slab, the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator
+        // hands out: x, g, d and the backups are written at the same element offset at the same
+        // time, and equal offsets into equally aligned buffers hit the same HBM channel
+        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;
+        if (hipMalloc(&o->bak_slab, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->bak_slab = nullptr; o->single_pass = false; return false; }
+        o->xbak = (char *)o->bak_slab + 5 * 1024;
+        o->gbak = (char *)o->xbak + slot;
+    }
     return true;
 }
 
@@ -1593,17 +1615,6 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int k = o->k;
     const int64_t nvec = c.n / N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
-    if (!o->halo) DZO_HIP(hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16));
-    if (!o->bak_slab) {
-        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * sizeof(T);
-        // one slab, the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator
-        // hands out: x, g, d and the backups are written at the same element offset at the same
-        // time, and equal offsets into equally aligned buffers hit the same HBM channel
-        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;
-        DZO_HIP(hipMalloc(&o->bak_slab, 2 * slot + 16 * 1024));
-        o->xbak = (char *)o->bak_slab + 5 * 1024;
-        o->gbak = (char *)o->xbak + slot;
-    }
     DZO_TRY(gram_scalars<T>(o));                          // alpha / coef / scale of THIS step (:438-448 on scalars)
     o->scalars_ready = false;
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
@@ -1673,6 +1684,10 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     o->single_pass_steps += 1;
     if (status == 2) {                                    // :128-131 (x_new == x_old everywhere, so x and g are intact)
         c.is_stuck = true;
+        // the fields as take_backtracking_step! leaves them: delta_point = x_old (:118), delta_gradient
+        // still the previous step's (= the newest pair of the ring; the pass wrote only spare slots)
+        DZO_HIP(hipMemcpyAsync(c.dx, o->xbak, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));
+        if (o->k > 0) c.dg = o->y_slot_v(o->newest);
         return DZO_OK;
     }
     c.last_trials = 1;
@@ -1708,6 +1723,10 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     if (c.is_stuck) return DZO_OK;                        // :456-458
     DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
                 "step! needs objective and gradient (callbacks or a built-in problem)");
+    if (c.problem && c.problem->parent) {                 // decorators may have been changed on the user's handle
+        problem_view_sync(c.problem);
+        c.box_on = c.problem->cons_on; c.box_lo = c.problem->cons_lo; c.box_hi = c.problem->cons_hi;
+    }
     bool quasi = false;
     o->last_step_kind = 0;
     if (single_pass_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_single_pass<T>(o)); }
@@ -1902,7 +1921,8 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
     if (rc == DZO_OK) rc = dzo_lbfgs_create(problem->n, history_length, problem->dtype, x_dev, g, f0, initial_step_length, out);
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
-    (*out)->core.problem = problem;
+    rc = problem_view_create(problem, &(*out)->core.problem);    // private partial-sum workspace per optimizer
+    if (rc != DZO_OK) { dzo_lbfgs_destroy(*out); *out = nullptr; return rc; }
     (*out)->core.box_on = problem->cons_on; (*out)->core.box_lo = problem->cons_lo; (*out)->core.box_hi = problem->cons_hi;
     return DZO_OK;
 }
@@ -1919,7 +1939,10 @@ int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t o, dzo_problem_t problem) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(!problem || (problem->n == o->core.n && problem->dtype == o->core.dtype), DZO_ERR_INVALID,
                 "problem size/dtype does not match the optimizer");
-    o->core.problem = problem;
+    (void)hipStreamSynchronize(o->core.stream);
+    problem_view_destroy(o->core.problem);
+    o->core.problem = nullptr;
+    if (problem) DZO_TRY(problem_view_create(problem, &o->core.problem));
     o->core.box_on = problem && problem->cons_on;
     if (problem) { o->core.box_lo = problem->cons_lo; o->core.box_hi = problem->cons_hi; }
     return DZO_OK;

@@ -132,6 +132,8 @@ void core_free(OptCore &c) {
     if (c.host) (void)hipHostFree(c.host);
     if (c.decided) (void)hipEventDestroy(c.decided);
     if (c.owns_g && c.g) (void)hipFree(c.g);
+    problem_view_destroy(c.problem);                         // (no-op unless the optimizer owns a view)
+    c.problem = nullptr;
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c.ws = nullptr; c.host = nullptr; c.stream = nullptr;
 }

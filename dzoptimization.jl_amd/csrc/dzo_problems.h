@@ -13,6 +13,11 @@ struct dzo_problem_s {
     double l2 = 0;                         // L2 wrappers' lambda; 0 = off
     bool bg_on = false; double bg_lo = 0, bg_hi = 0;       // UniformBoxGradientWrapper
     bool cons_on = false; double cons_lo = 0, cons_hi = 0; // UniformBoxConstraint as constraint_function!
+    // Workspace.  A problem handle that an optimizer was created from is never used directly by that
+    // optimizer: each optimizer works on its own VIEW (same definition, private scratch / result /
+    // host scalars; `parent` points at the user's handle), so several optimizers built on one
+    // dzo_problem_t can run on their own streams / host threads without sharing partial sums.
+    dzo_problem_s *parent = nullptr;
     double *scratch = nullptr; // device partials
     int64_t scratch_doubles = 0;   // usable partials in scratch
     double *result = nullptr;  // device: [f, ...] inside scratch
@@ -20,6 +25,11 @@ struct dzo_problem_s {
 };
 
 namespace dzo {
+// per-optimizer view of a user's problem handle (see dzo_problem_s::parent); sync re-reads the
+// definition and the decorators from the parent (they may be changed between steps)
+int32_t problem_view_create(dzo_problem_s *parent, dzo_problem_s **out);
+void problem_view_sync(dzo_problem_s *view);
+void problem_view_destroy(dzo_problem_s *view);
 // Enqueue f(x) on `s`; result_dev[0] receives the value (fp64, rounded to T by the caller).
 int32_t problem_eval_async(dzo_problem_s *p, hipStream_t s, const void *x, double *result_dev);
 // Objective partials only (no final sum); false if this objective needs its own finish kernel.

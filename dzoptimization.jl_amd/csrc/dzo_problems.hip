@@ -830,6 +830,44 @@ int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void 
     return DZO_OK;
 }
 
+static int32_t problem_alloc_workspace(dzo_problem_s *p) {
+    const int64_t n = p->n;
+    const int64_t scratch = (p->kind == DZO_PROBLEM_QUADRATIC ? (6 * n > 2 * kMaxPartialBlocks ? 6 * n : 2 * kMaxPartialBlocks)
+                                                              : 2 * kMaxPartialBlocks) + 16;
+    p->scratch_doubles = scratch - 16;
+    hipError_t e = hipMalloc((void **)&p->scratch, sizeof(double) * (size_t)scratch);
+    if (e != hipSuccess) { p->scratch = nullptr; return hip_fail(e, "hipMalloc(problem scratch)", __FILE__, __LINE__); }
+    e = hipHostMalloc((void **)&p->host, sizeof(double) * 4, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipFree(p->scratch); p->scratch = nullptr; p->host = nullptr; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+    p->result = p->scratch + scratch - 8;
+    return DZO_OK;
+}
+
+int32_t problem_view_create(dzo_problem_s *parent, dzo_problem_s **out) {
+    dzo_problem_s *root = parent->parent ? parent->parent : parent;
+    dzo_problem_s *v = new dzo_problem_s(*root);
+    v->parent = root; v->scratch = nullptr; v->result = nullptr; v->host = nullptr;
+    const int32_t rc = problem_alloc_workspace(v);
+    if (rc != DZO_OK) { delete v; return rc; }
+    *out = v;
+    return DZO_OK;
+}
+
+void problem_view_sync(dzo_problem_s *v) {
+    if (!v || !v->parent) return;
+    const dzo_problem_s *r = v->parent;
+    v->kind = r->kind; v->n = r->n; v->dtype = r->dtype; v->A = r->A; v->c = r->c; v->lambda = r->lambda;
+    v->l2 = r->l2; v->bg_on = r->bg_on; v->bg_lo = r->bg_lo; v->bg_hi = r->bg_hi;
+    v->cons_on = r->cons_on; v->cons_lo = r->cons_lo; v->cons_hi = r->cons_hi;
+}
+
+void problem_view_destroy(dzo_problem_s *v) {
+    if (!v || !v->parent) return;                            // only views are owned by optimizers
+    if (v->scratch) (void)hipFree(v->scratch);
+    if (v->host) (void)hipHostFree(v->host);
+    delete v;
+}
+
 }  // namespace dzo
 
 using namespace dzo;
@@ -848,14 +886,8 @@ int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A
     DZO_REQUIRE(kind != DZO_PROBLEM_LSE || c_dev, DZO_ERR_INVALID, "LSE problem needs c");
     dzo_problem_s *p = new dzo_problem_s();
     p->kind = kind; p->n = n; p->dtype = dtype; p->A = A_dev; p->c = c_dev; p->lambda = lambda;
-    const int64_t scratch = (kind == DZO_PROBLEM_QUADRATIC ? (6 * n > 2 * kMaxPartialBlocks ? 6 * n : 2 * kMaxPartialBlocks)
-                                                           : 2 * kMaxPartialBlocks) + 16;
-    p->scratch_doubles = scratch - 16;
-    hipError_t e = hipMalloc((void **)&p->scratch, sizeof(double) * (size_t)scratch);
-    if (e != hipSuccess) { delete p; return hip_fail(e, "hipMalloc(problem scratch)", __FILE__, __LINE__); }
-    e = hipHostMalloc((void **)&p->host, sizeof(double) * 4, hipHostMallocDefault);
-    if (e != hipSuccess) { (void)hipFree(p->scratch); delete p; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
-    p->result = p->scratch + scratch - 8;
+    const int32_t rc = problem_alloc_workspace(p);
+    if (rc != DZO_OK) { delete p; return rc; }
     *out = p;
     return DZO_OK;
 }

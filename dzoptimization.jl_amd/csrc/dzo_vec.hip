@@ -3,6 +3,7 @@
 // Each kernel is one HBM pass: 16-byte-per-lane coalesced loads (1 KiB per wave
 // instruction), 4 independent vectors in flight per thread, grid capped at 8 blocks per CU
 // with a grid-stride loop.  Reductions are two-stage and deterministic.
+#include <cmath>
 #include <cstdlib>
 #include "dzo_common.h"
 
@@ -333,6 +334,41 @@ int32_t dzo_isequal(int64_t n, int32_t dtype, const void *a_dev, const void *b_d
     DZO_HIP(hipMemcpyAsync(host, flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx().stream));
     DZO_HIP(hipStreamSynchronize(ctx().stream));
     *result = (*host == 0) ? 1 : 0;
+    return DZO_OK;
+}
+
+// ---- legacy/Kernels.jl primitives that have no LinearAlgebra twin above
+// norm2(x): the SUM OF SQUARES, not its square root (Kernels.jl:49-55,139); rounded to T like the loop's accumulator
+int32_t dzo_norm2(int64_t n, int32_t dtype, const void *x_dev, double *result) {
+    double ss = 0;
+    DZO_TRY(dzo_dot(n, dtype, x_dev, x_dev, &ss));
+    *result = dtype == DZO_F32 ? (double)(float)ss : ss;
+    return DZO_OK;
+}
+
+// inv_norm(x) = rsqrt(norm2(x)) (Kernels.jl:141), evaluated in T
+int32_t dzo_inv_norm(int64_t n, int32_t dtype, const void *x_dev, double *result) {
+    double ss = 0;
+    DZO_TRY(dzo_dot(n, dtype, x_dev, x_dev, &ss));
+    *result = dtype == DZO_F32 ? (double)(1.0f / sqrtf((float)ss)) : 1.0 / sqrt(ss);
+    return DZO_OK;
+}
+
+// negate!(x): x[i] = -x[i] (Kernels.jl:76-83)
+int32_t dzo_negate(int64_t n, int32_t dtype, void *x_dev) {
+    DZO_CHECK_VEC(n, x_dev);
+    DZO_DISPATCH(dtype, launch_scal<T>(ctx().stream, n, (T)-1, (T *)x_dev));   // (-1)*x == -x bit for bit for every non-NaN x (signed zeros and infinities included); NaN stays NaN
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+// scale!(dst, alpha, x): dst[i] = alpha * x[i] (out of place, Kernels.jl:96-104); dst may alias x
+int32_t dzo_scal_oop(int64_t n, int32_t dtype, void *dst_dev, double alpha, const void *x_dev) {
+    DZO_CHECK_VEC(n, dst_dev, x_dev);
+    DZO_DISPATCH(dtype, launch_scal_oop<T>(ctx().stream, n, (T *)dst_dev, (T)alpha, (const T *)x_dev));
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
     return DZO_OK;
 }
 

@@ -24,7 +24,8 @@ export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentO
        set_safeguards!, set_line_search!, BACKTRACKING, STRONG_WOLFE,
        RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem,
        BatchedBFGSOptimizer, count_active, LineSearchEvaluator, compute_lbfgs_step_direction!,
-       update_inverse_hessian!, reset_inverse_hessian!, synchronize
+       update_inverse_hessian!, reset_inverse_hessian!, synchronize,
+       norm2, inv_norm, negate!, scale!, HipBackend, install_state!, ShardComm, all_done
 
 const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
 
@@ -128,6 +129,51 @@ function norm(x::HipVector{T}) where {T}
     r = Ref{Cdouble}(0)
     check(ccall((:dzo_nrm2, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ref{Cdouble}), x.len, dtype_code(T), x.ptr, r))
     return T(r[])
+end
+
+# legacy/Kernels.jl primitives without a LinearAlgebra twin (SURVEY.md a14)
+"""`norm2(x)`: the sum of squares, NOT its root (legacy/Kernels.jl:49-55,139)."""
+function norm2(x::HipVector{T}) where {T}
+    r = Ref{Cdouble}(0)
+    check(ccall((:dzo_norm2, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ref{Cdouble}), x.len, dtype_code(T), x.ptr, r))
+    return T(r[])
+end
+"""`inv_norm(x) = rsqrt(norm2(x))` (legacy/Kernels.jl:141)."""
+function inv_norm(x::HipVector{T}) where {T}
+    r = Ref{Cdouble}(0)
+    check(ccall((:dzo_inv_norm, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ref{Cdouble}), x.len, dtype_code(T), x.ptr, r))
+    return T(r[])
+end
+"""`negate!(x)` (legacy/Kernels.jl:76-83,143)."""
+function negate!(x::HipVector{T}) where {T}
+    check(ccall((:dzo_negate, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}), x.len, dtype_code(T), x.ptr))
+    return x
+end
+"""`scale!(x, alpha)` in place (legacy/Kernels.jl:87-94,145-146), `scale!(dst, alpha, x)` out of place (:96-104)."""
+scale!(x::HipVector, alpha::Number) = rmul!(x, alpha)
+function scale!(dst::HipVector{T}, alpha::Number, x::HipVector{T}) where {T}
+    check(ccall((:dzo_scal_oop, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}), x.len, dtype_code(T), dst.ptr, Float64(alpha), x.ptr))
+    return x                                                   # (the reference returns x, :103)
+end
+
+# KernelAbstractions.get_backend(::HipVector): the reference's constructors call it on every array and
+# @assert the backends equal (src/DZOptimization.jl:3,44-54,216-226,363-378,410,420).  KernelAbstractions
+# is a dependency of the REFERENCE, not of this module: when it is loadable (it is whenever the
+# reference itself is), HipVector gets a singleton backend, so the reference's own generic
+# constructors and `step!` run unmodified on HipVector (INTEGRATION.md route A).
+const _KA = try
+    Base.require(Base.PkgId(Base.UUID("63c18a36-062a-441e-b654-da1e3ab1ce7c"), "KernelAbstractions"))
+catch
+    nothing
+end
+if _KA !== nothing
+    @eval begin
+        """Singleton backend of `HipVector` (device memory behind libdzo_hip.so)."""
+        struct HipBackend <: $(_KA).GPU end
+        $(_KA).get_backend(::HipVector) = HipBackend()
+    end
+else
+    struct HipBackend end                                       # KernelAbstractions absent: route B only
 end
 
 ################################################################################ built-in objectives
@@ -337,6 +383,11 @@ mutable struct BFGSOptimizer{T,F,G,C}
     end
 end
 BFGSOptimizer(objective, gradient!, x0::HipVector, step::Real) = BFGSOptimizer(objective, gradient!, nothing, x0, step)
+# README.md:33-36 passes a host array (`rand(2)`): upload it (the optimizer copies x0 anyway, :769)
+BFGSOptimizer(objective, gradient!, x0::Array{T}, step::Real) where {T<:Union{Float32,Float64}} =
+    BFGSOptimizer(objective, gradient!, nothing, HipVector(x0), step)
+BFGSOptimizer(objective, gradient!, constraint!, x0::Array{T}, step::Real) where {T<:Union{Float32,Float64}} =
+    BFGSOptimizer(objective, gradient!, constraint!, HipVector(x0), step)
 function BFGSOptimizer(objective::F, gradient!::G, constraint!::C, x0::HipVector{T}, step::Real) where {T,F,G,C}
     ensure_init()
     h = Ref{Ptr{Cvoid}}(C_NULL)
@@ -403,6 +454,27 @@ function Base.getproperty(o::BFGSOptimizer{T}, s::Symbol) where {T}
     return getfield(o, s)
 end
 
+"""`install_state!(opt; x, g, H, d, f, last_step_length, iteration_count, last_step_type, delta_point, delta_gradient)`:
+overwrite the optimizer's state from host arrays ("save/load data in the middle of optimization",
+README.md:11); `H` column-major n*n.  The device arrays are the state itself (`opt.current_point` etc. are
+views of them); the host-side fields go through `dzo_bfgs_set_s / set_i`."""
+function install_state!(opt::BFGSOptimizer{T}; x=nothing, g=nothing, H=nothing, d=nothing, f=nothing, last_step_length=nothing,
+                        iteration_count=nothing, last_step_type=nothing, delta_point=nothing, delta_gradient=nothing) where {T}
+    up(dst::HipVector, src) = (h = Array{T}(vec(src));
+                               check(ccall((:dzo_memcpy_h2d, libdzo), Cint, (Ptr{Cvoid}, Ptr{T}, Int64), dst.ptr, h, sizeof(h))))
+    x === nothing || up(opt.current_point, x)
+    g === nothing || up(opt.current_gradient, g)
+    H === nothing || up(opt.approximate_inverse_hessian, H)
+    d === nothing || up(opt.next_step_direction, d)
+    delta_point === nothing || up(opt.delta_point, delta_point)
+    delta_gradient === nothing || up(opt.delta_gradient, delta_gradient)
+    f === nothing || check(ccall((:dzo_bfgs_set_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Cdouble), getfield(opt, :handle), 0, f))
+    last_step_length === nothing || check(ccall((:dzo_bfgs_set_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Cdouble), getfield(opt, :handle), 1, last_step_length))
+    iteration_count === nothing || check(ccall((:dzo_bfgs_set_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Int64), getfield(opt, :handle), 1, iteration_count))
+    last_step_type === nothing || check(ccall((:dzo_bfgs_set_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Int64), getfield(opt, :handle), 3, last_step_type))
+    return opt
+end
+
 ################################################################################ legacy gradient descent
 
 """`GradientDescentOptimizer(objective, gradient!, QuadraticLineSearch(), x0, step)`
@@ -467,6 +539,14 @@ function Base.getproperty(o::AdGDOptimizer{T}, s::Symbol) where {T}
     s === :delta_objective_value && return fill(T(_ad_s(o, 1)))
     s === :current_step_size && return fill(T(_ad_s(o, 2)))
     s === :previous_step_size && return fill(T(_ad_s(o, 3)))
+    if s in (:delta_point, :current_gradient, :delta_gradient)
+        # re-fetched on every access: delta_gradient moves between two buffers from step to step, and the
+        # library re-reads what it cached about an array whose pointer was handed out (include/dzo.h)
+        w = findfirst(==(s), (:current_point, :delta_point, :current_gradient, :delta_gradient)) - 1
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dzo_adgd_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), getfield(o, :handle), w, p))
+        return HipVector{T}(p[], length(getfield(o, :current_point)))
+    end
     return getfield(o, s)
 end
 
@@ -480,15 +560,68 @@ mutable struct BatchedBFGSOptimizer{T}
     handle::Ptr{Cvoid}
     batch::Int
     n::Int
-    function BatchedBFGSOptimizer(kind::Integer, x0::HipVector{T}, n::Integer, step::Real) where {T}
+    function BatchedBFGSOptimizer(kind::Integer, x0::HipVector{T}, n::Integer, step::Real; device::Union{Nothing,Integer}=nothing) where {T}
         ensure_init()
         h = Ref{Ptr{Cvoid}}(C_NULL)
         batch = div(length(x0), n)
-        check(ccall((:dzo_bfgs_batch_create, libdzo), Cint, (Cint, Int64, Int64, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
-                    kind, batch, n, dtype_code(T), x0.ptr, step, h))
+        if device === nothing
+            check(ccall((:dzo_bfgs_batch_create, libdzo), Cint, (Cint, Int64, Int64, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                        kind, batch, n, dtype_code(T), x0.ptr, step, h))
+        else   # a shard on an explicit GPU (x0 must live there: `init(device); x0 = HipVector(...)`)
+            check(ccall((:dzo_bfgs_batch_create_on, libdzo), Cint, (Cint, Cint, Int64, Int64, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
+                        device, kind, batch, n, dtype_code(T), x0.ptr, step, h))
+        end
         return finalizer(o -> ccall((:dzo_bfgs_batch_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)),
                          new{T}(h[], batch, n))
     end
+end
+
+"""`ShardComm(devices)`: RCCL communicator over the GPUs of one node for ONE host process
+(`ncclCommInitAll` behind `dzo_comm_init_all`); `ShardComm(id, nranks, rank)` joins a
+process-per-GPU communicator whose 128-byte `id = ShardComm.unique_id()` rank 0 created.  The only
+collective of the design is the convergence flag: `all_done(comm, shards)` is true when every instance of
+every shard `has_terminated` (`dzo_bfgs_batch_all_done`: local counts + one 4-byte all-reduce(MIN) over
+xGMI).  "run multiple optimizers in parallel" (README.md:12):
+
+    comm   = ShardComm(0:7)
+    shards = [ (init(d); BatchedBFGSOptimizer(1, HipVector(x0[d]), 256, 1.0; device=d)) for d in 0:7 ]
+    while !all_done(comm, shards); foreach(s -> step!(s, 10), shards); end
+"""
+mutable struct ShardComm
+    handle::Ptr{Cvoid}
+    ShardComm(h::Ptr{Cvoid}) = finalizer(c -> ccall((:dzo_comm_destroy, libdzo), Cint, (Ptr{Cvoid},), c.handle), new(h))
+end
+function ShardComm(devices::AbstractVector{<:Integer})
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    devs = Cint.(collect(devices))
+    check(ccall((:dzo_comm_init_all, libdzo), Cint, (Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}), devs, length(devs), h))
+    _initialised[] = true
+    return ShardComm(h[])
+end
+function unique_id()
+    ensure_init()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:dzo_comm_unique_id, libdzo), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function ShardComm(id::Vector{UInt8}, nranks::Integer, rank::Integer)
+    ensure_init()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:dzo_comm_init_rank, libdzo), Cint, (Ptr{UInt8}, Cint, Cint, Ref{Ptr{Cvoid}}), id, nranks, rank, h))
+    return ShardComm(h[])
+end
+function all_done(comm::Union{ShardComm,Nothing}, shards::AbstractVector{<:BatchedBFGSOptimizer})
+    hs = Ptr{Cvoid}[s.handle for s in shards]
+    r = Ref{Cint}(0)
+    check(ccall((:dzo_bfgs_batch_all_done, libdzo), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Ref{Cint}),
+                comm === nothing ? C_NULL : comm.handle, hs, length(hs), r))
+    return r[] != 0
+end
+"""`allreduce_min(comm, local_flags)`: the raw 4-byte collective (one flag per local rank)."""
+function allreduce_min(comm::ShardComm, local_flags::AbstractVector{<:Integer})
+    fl = Cint.(collect(local_flags)); r = Ref{Cint}(0)
+    check(ccall((:dzo_flag_allreduce_min, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ref{Cint}), comm.handle, fl, r))
+    return Int(r[])
 end
 step!(b::BatchedBFGSOptimizer, steps::Integer=1) =
     (check(ccall((:dzo_bfgs_batch_step, libdzo), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}), b.handle, steps, C_NULL)); b)

@@ -75,6 +75,7 @@ typedef struct dzo_lbfgs_s *dzo_lbfgs_t;
 typedef struct dzo_adgd_s *dzo_adgd_t;
 typedef struct dzo_bfgs_s *dzo_bfgs_t;
 typedef struct dzo_bfgs_batch_s *dzo_bfgs_batch_t;
+typedef struct dzo_comm_s *dzo_comm_t;
 
 /* User callbacks, in the reference's order constraint / objective / gradient
  * (src/DZOptimization.jl:323-325).  They receive DEVICE pointers and must enqueue their
@@ -89,6 +90,11 @@ typedef void (*dzo_gradient_fn)(void *ctx, void *g_dev, const void *x_dev);
 /* ---------------------------------------------------------------------------------------
  * lifecycle
  * ------------------------------------------------------------------------------------- */
+/* dzo_init selects `device` for the CALLING THREAD (hipSetDevice + the library's per-device context:
+ * stream, scratch) and may be called for several devices; handle-less entry points (vector primitives,
+ * dzo_malloc, constructors) work on the device the calling thread selected last.  dzo_memcpy_* find the
+ * device from the pointer.  Optimizer handles other than the batched one must be driven with their
+ * creating device selected. */
 int32_t dzo_init(int32_t device);
 int32_t dzo_shutdown(void);
 int32_t dzo_version(void);
@@ -136,6 +142,18 @@ int32_t dzo_isequal(int64_t n, int32_t dtype, const void *a_dev, const void *b_d
  *                         legacy/DZOptimization.jl:33, src/DZOptimization.jl:69-70 */
 int32_t dzo_trial_point(int64_t n, int32_t dtype, void *dst_dev, double t, const void *d_dev,
                         const void *x_dev);
+
+/* The legacy primitives that have no LinearAlgebra twin above:
+ *   norm2(x)            sum of squares -- NOT its square root     legacy/Kernels.jl:49-55,139
+ *   inv_norm(x)         rsqrt(norm2(x))                           legacy/Kernels.jl:141
+ *   negate!(x)          x[i] = -x[i]                              legacy/Kernels.jl:76-83,143
+ *   scale!(dst, a, x)   dst[i] = a*x[i], out of place             legacy/Kernels.jl:96-104
+ * (in-place scale! is dzo_scal, delta! is dzo_axpby(1, x, -1, y), both axpy! forms are dzo_axpy /
+ * dzo_trial_point, dot is dzo_dot.) */
+int32_t dzo_norm2(int64_t n, int32_t dtype, const void *x_dev, double *result);
+int32_t dzo_inv_norm(int64_t n, int32_t dtype, const void *x_dev, double *result);
+int32_t dzo_negate(int64_t n, int32_t dtype, void *x_dev);
+int32_t dzo_scal_oop(int64_t n, int32_t dtype, void *dst_dev, double alpha, const void *x_dev);
 
 /* ---------------------------------------------------------------------------------------
  * built-in objectives (device-side twins of the user's callbacks)
@@ -339,6 +357,15 @@ int32_t dzo_bfgs_reset(dzo_bfgs_t opt);
 int32_t dzo_bfgs_get_i(dzo_bfgs_t opt, int32_t what, int64_t *value);
 int32_t dzo_bfgs_get_s(dzo_bfgs_t opt, int32_t what, double *value);
 int32_t dzo_bfgs_get_ptr(dzo_bfgs_t opt, int32_t what, void **ptr_dev);
+/* Install state ("save/load data in the middle of optimization", README.md:11; the re-precision
+ * constructor :812-862 moves a whole optimizer the same way).  The device arrays (x, g, delta_point,
+ * delta_gradient, next_step_direction, H) are the optimizer's state itself: write them through the
+ * pointers of dzo_bfgs_get_ptr (dzo_memcpy_h2d / d2d) between steps.  The host-side fields:
+ *   set_s: 0 current_objective_value (NaN -> DZO_ERR_ASSERT, :773)  1 last_step_length
+ *          2 delta_objective_value (gradient-descent handles)
+ *   set_i: 0 has_terminated  1 iteration_count  3 last_step_type  4 objective evaluations so far */
+int32_t dzo_bfgs_set_s(dzo_bfgs_t opt, int32_t what, double value);
+int32_t dzo_bfgs_set_i(dzo_bfgs_t opt, int32_t what, int64_t value);
 
 /* ---------------------------------------------------------------------------------------
  * Legacy GradientDescentOptimizer (legacy/DZOptimization.jl:305-449) with
@@ -373,6 +400,43 @@ int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done
  *          10 last_step_type (B int32) */
 int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev);
 int32_t dzo_bfgs_batch_count_active(dzo_bfgs_batch_t b, int64_t *active);
+/* The arrays behind dzo_bfgs_batch_get_ptr ARE the state of the instances (x, g, H, d, delta_point,
+ * delta_gradient, f, last_step_length, last_step_type, has_terminated, iteration_count): writing them
+ * between two dzo_bfgs_batch_step calls installs state (checkpoint / resume, README.md:11; the per-step
+ * parity tests upload the CPU reference's state that way). */
+
+/* The same constructor on an explicit device, for a host that drives the shards of several GPUs from
+ * one process (dzo_comm_init_all).  x0_dev must live on `device`.  Every entry point of a batched
+ * handle enters the handle's device by itself. */
+int32_t dzo_bfgs_batch_create_on(int32_t device, int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype,
+                                 const void *x0_dev, double initial_step_length, dzo_bfgs_batch_t *out);
+int32_t dzo_bfgs_batch_device(dzo_bfgs_batch_t b, int32_t *device);
+
+/* ---------------------------------------------------------------------------------------
+ * The one collective: the global convergence flag of sharded independent optimizers
+ * (block partition of instances over the GPUs of a node, no data-path collective;
+ * "run multiple optimizers in parallel", README.md:12).  all-reduce(MIN) of one int32 per rank over
+ * RCCL / xGMI.  RCCL is loaded with dlopen at first use (no link-time dependency).
+ *   dzo_comm_init_all   one process, several devices (ncclCommInitAll): local rank i = devices[i]
+ *   dzo_comm_unique_id + dzo_comm_init_rank
+ *                       one process per GPU: rank 0 creates the 128-byte id, the launcher carries
+ *                       it to the other ranks, every rank joins with the device it selected (dzo_init)
+ *   dzo_flag_allreduce_min   local_flags: one int32 per LOCAL rank; blocking
+ *   dzo_bfgs_batch_all_done  counts the live instances of every local shard (concurrently), then one
+ *                       all-reduce: *all_done = 1 when every instance of every shard has_terminated.
+ *                       comm may be NULL (no collective); otherwise batches[i] must live on the
+ *                       device of local rank i.
+ * ------------------------------------------------------------------------------------- */
+#define DZO_COMM_UNIQUE_ID_BYTES 128
+int32_t dzo_comm_unique_id(void *id128);
+int32_t dzo_comm_init_rank(const void *id128, int32_t nranks, int32_t rank, dzo_comm_t *out);
+int32_t dzo_comm_init_all(const int32_t *devices, int32_t ndev, dzo_comm_t *out);
+int32_t dzo_comm_destroy(dzo_comm_t comm);
+/* any of the outputs may be NULL; collectives = all-reduces issued so far */
+int32_t dzo_comm_info(dzo_comm_t comm, int32_t *nranks, int32_t *nlocal, int32_t *first_rank, int64_t *collectives);
+int32_t dzo_flag_allreduce_min(dzo_comm_t comm, const int32_t *local_flags, int32_t *global_flag);
+int32_t dzo_bfgs_batch_all_done(dzo_comm_t comm_or_null, const dzo_bfgs_batch_t *batches, int32_t nbatches,
+                                int32_t *all_done);
 
 #ifdef __cplusplus
 }

@@ -1127,6 +1127,19 @@ T *FN(orc_bfgs_get_v)(const FN(orc_bfgs) *o, int what) {
     return NULL;
 }
 void FN(orc_bfgs_set_max_increases)(FN(orc_bfgs) *o, int32_t v) { o->max_increases = v; }
+/* state installation for the per-step parity tests (every field of the reference's struct is public,
+ * legacy/DZOptimization.jl:733-751; the vectors and H are written through orc_bfgs_get_v) */
+void FN(orc_bfgs_set_s)(FN(orc_bfgs) *o, int what, T v) {
+    if (what == 0) o->f = v; else o->last_step_length = v;
+}
+void FN(orc_bfgs_set_i)(FN(orc_bfgs) *o, int what, int64_t v) {
+    switch (what) {
+    case 0: o->has_terminated = v != 0; break;
+    case 1: o->iteration_count = v; break;
+    case 3: o->last_step_type = (int32_t)v; break;
+    case 4: o->evals = v; break;
+    }
+}
 /* exposed for unit tests of the search itself */
 void FN(orc_bfgs_line_search)(FN(orc_bfgs) *o, int use_gradient_dir, T t0, T *t_best, T *f_best) {
     FN(bfgs_quadratic_search)(o, use_gradient_dir ? o->g : o->d, o->f, t0, t_best, f_best);

@@ -120,6 +120,8 @@ def _declare(L):
         f("orc_bfgs_get_s", ct, [vp, C.c_int])
         f("orc_bfgs_get_v", vp, [vp, C.c_int])
         f("orc_bfgs_set_max_increases", None, [vp, i32])
+        f("orc_bfgs_set_s", None, [vp, C.c_int, ct])
+        f("orc_bfgs_set_i", None, [vp, C.c_int, i64])
         f("orc_bfgs_update", None, [vp, ct, vp, vp, vp, i64])
         f("orc_symv", None, [vp, vp, vp, i64])
         f("orc_bfgs_line_search", None, [vp, C.c_int, ct, vp, vp])
@@ -447,6 +449,27 @@ class BFGS:
     @property
     def approximate_inverse_hessian(self):
         return self._v(5, n=self.n * self.n).reshape(self.n, self.n, order="F")
+
+    def set_max_increases(self, v):
+        getattr(lib(), "orc_bfgs_set_max_increases" + self.suf)(self.h, int(v))
+
+    def install_state(self, x, g, H, d, f, last_step_length, iteration_count=0, last_step_type=0, dx=None, dg=None):
+        """Overwrite the optimizer's state (all fields are public in the reference, legacy :733-751).
+        H: (n, n) symmetric or column-major."""
+        self.current_point[:] = x
+        self.current_gradient[:] = g
+        self._v(5, n=self.n * self.n)[:] = np.asarray(H, dtype=self.dtype).reshape(-1, order="F")
+        self.next_step_direction[:] = d
+        if dx is not None:
+            self.delta_point[:] = dx
+        if dg is not None:
+            self.delta_gradient[:] = dg
+        L = lib()
+        getattr(L, "orc_bfgs_set_s" + self.suf)(self.h, 0, f)
+        getattr(L, "orc_bfgs_set_s" + self.suf)(self.h, 1, last_step_length)
+        getattr(L, "orc_bfgs_set_i" + self.suf)(self.h, 0, 0)
+        getattr(L, "orc_bfgs_set_i" + self.suf)(self.h, 1, int(iteration_count))
+        getattr(L, "orc_bfgs_set_i" + self.suf)(self.h, 3, int(last_step_type))
 
     def line_search(self, use_gradient_dir: bool, t0: float):
         ct = _ct(self.dtype)

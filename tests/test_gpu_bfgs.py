@@ -416,6 +416,73 @@ def test_adgd_fused_run_to_stuck_leaves_a_consistent_state(dtype):
     assert opt.iteration_count == its and np.array_equal(opt.current_point.to_host(), x)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,step0", [(4100, 0.1), (100_000, 0.1), (4100, 200.0)])
+def test_adgd_fused_halo_handover_without_touching_pointers(n, step0, dtype, monkeypatch):
+    """The default path of the one-pass AdGD step: the row-boundary vectors of x_new / g_new that a pass
+    leaves behind are consumed by the NEXT pass (no snapshot kernel).  Reading opt.current_point goes
+    through dzo_adgd_get_ptr, which invalidates that hand-over -- so here K steps run with NO pointer
+    access in between (many wave-rows, so inter-row halos matter), and only then the state is compared
+    with the separate-kernel path and the oracle.  step0 = 200 makes the first trials fail, so halos
+    written by a RETRY pass are consumed as well."""
+    K = 24
+    x0 = orc.rosenbrock_chain_x0(n).astype(dtype)
+    monkeypatch.setenv("DZO_TUNE_ADGD_FUSED", "1")
+    a = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
+    monkeypatch.setenv("DZO_TUNE_ADGD_FUSED", "0")
+    b = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)                    # the device sums in fp64
+    try:
+        ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0)
+        for _ in range(K):
+            a.step(); b.step(); ref.step()               # scalars only: no get_ptr between the steps
+        assert a.fused_steps == K and b.fused_steps == 0
+        if step0 > 1.0:
+            assert a.fused_rejections >= 1
+        assert a.iteration_count == b.iteration_count == ref.iteration_count == K
+        tol = 1e-12 if dtype == np.float64 else 2e-5
+        assert a.current_step_size == pytest.approx(b.current_step_size, rel=tol)
+        assert a.current_objective_value == pytest.approx(b.current_objective_value, rel=tol)
+        xa, ga = a.current_point.to_host(), a.current_gradient.to_host()
+        assert rel(xa, b.current_point.to_host()) <= tol
+        assert rel(ga, b.current_gradient.to_host()) <= 10 * tol
+        assert rel(a.delta_point.to_host(), b.delta_point.to_host()) <= 1e3 * tol
+        assert rel(a.delta_gradient.to_host(), b.delta_gradient.to_host()) <= 1e3 * tol
+        # a wrong boundary vector would put a wrong gradient next to a row end: the gradient must be
+        # the gradient of the point, exactly
+        assert np.array_equal(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype).grad(xa), ga)
+        otol = 1e-10 if dtype == np.float64 else 1e-4
+        assert rel(xa, ref.current_point) <= otol
+        assert a.current_step_size == pytest.approx(ref.current_step_size, rel=1e-9 if dtype == np.float64 else 1e-4)
+    finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_adgd_stuck_step_leaves_the_reference_deltas(fused, monkeypatch):
+    """take_backtracking_step! returns at :128-130 with delta_point == x_old (the :118 copy) and
+    delta_gradient untouched since the previous step; the one-pass step must leave the same."""
+    n = 64
+    monkeypatch.setenv("DZO_TUNE_ADGD_FUSED", fused)
+    x0 = orc.rosenbrock_chain_x0(n)
+    opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 0.1)
+    ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 0.1)
+    prev_dg = None
+    for it in range(200_000):
+        dg_before = opt.delta_gradient.to_host()
+        opt.step()
+        if opt.is_stuck:
+            prev_dg = dg_before
+            break
+    assert opt.is_stuck
+    assert np.array_equal(opt.delta_point.to_host(), opt.current_point.to_host())     # :118
+    assert np.array_equal(opt.delta_gradient.to_host(), prev_dg)                       # untouched
+    while not ref.is_stuck:
+        ref.step()
+    assert np.array_equal(ref.delta_point, ref.current_point)
+
+
 def test_bfgs_reset_restores_identity_and_gradient_direction():
     """dzo_bfgs_reset = the reset step! performs after a gradient-descent step (legacy :981-986)."""
     n = 48

@@ -1,0 +1,182 @@
+"""Per-step parity of the dense BFGS ``step!`` (legacy/DZOptimization.jl:891-994) and of the batched
+mode from IDENTICAL state: before every step the oracle's complete state (x, g, H, d, f,
+last_step_length, counters) is installed in the GPU optimizer through the C ABI
+(dzo_bfgs_set_s / set_i + the get_ptr arrays), both sides take one step, and the results must agree
+to the north-star tolerance (1e-10 relative; H 1e-12).  Free-running trajectories cannot be held to
+that bar by any implementation (the searches branch on comparisons of sums whose order differs), which
+is why tests/test_gpu_bfgs.py uses looser bounds there.
+"""
+import numpy as np
+import pytest
+
+from dzo_loader import dzo
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10        # BASELINE.json north_star: per-step output within 1e-10 relative of the CPU reference
+TOL_H = 1e-12
+
+
+def rel(a, b, scale=None):
+    return np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(
+        np.linalg.norm(np.asarray(b, np.float64)) if scale is None else scale, 1e-300)
+
+
+def _oracle_state(ref):
+    return dict(x=ref.current_point.copy(), g=ref.current_gradient.copy(),
+                H=np.ascontiguousarray(ref.approximate_inverse_hessian), d=ref.next_step_direction.copy(),
+                f=ref.current_objective_value, last_step_length=ref.last_step_length,
+                iteration_count=ref.iteration_count, last_step_type=ref.last_step_type,
+                dx=ref.delta_point.copy(), dg=ref.delta_gradient.copy())
+
+
+def _check_step(opt_state, ref, x_scale, f_scale, where):
+    """opt_state: dict of host arrays / scalars read back from the device after the step."""
+    assert opt_state["iteration_count"] == ref.iteration_count, where
+    assert opt_state["last_step_type"] == ref.last_step_type, where
+    assert opt_state["has_terminated"] == ref.has_terminated, where
+    assert rel(opt_state["x"], ref.current_point, x_scale) <= TOL, where
+    assert abs(opt_state["f"] - ref.current_objective_value) <= TOL * f_scale, where
+    if ref.has_terminated:
+        return
+    assert abs(opt_state["last_step_length"] - ref.last_step_length) <= TOL * max(abs(ref.last_step_length), 1e-300), where
+    assert rel(opt_state["dx"], ref.delta_point) <= TOL, where
+    g_scale = max(np.linalg.norm(ref.current_gradient), np.linalg.norm(ref.delta_gradient))
+    assert rel(opt_state["g"], ref.current_gradient, g_scale) <= TOL, where
+    assert rel(opt_state["dg"], ref.delta_gradient, g_scale) <= TOL, where
+    H = opt_state["H"]
+    assert np.array_equal(H, H.T), where                                   # exact symmetry survives the step
+    assert rel(H, np.ascontiguousarray(ref.approximate_inverse_hessian)) <= TOL_H, where
+    # d = H g is a sum with cancellation once g is at rounding level: the error of a matrix-vector
+    # product is bounded relative to |H| |g| (tolerances relative to sum |a_i b_i|)
+    Href = np.ascontiguousarray(ref.approximate_inverse_hessian)
+    d_scale = max(np.linalg.norm(ref.next_step_direction), np.linalg.norm(np.abs(Href) @ np.abs(ref.current_gradient)))
+    assert rel(opt_state["d"], ref.next_step_direction, d_scale) <= TOL, where
+
+
+def _read(opt):
+    n = opt.n
+    return dict(x=opt.current_point.to_host(), g=opt.current_gradient.to_host(), dx=opt.delta_point.to_host(),
+                dg=opt.delta_gradient.to_host(), d=opt.next_step_direction.to_host(),
+                H=opt.approximate_inverse_hessian.to_host().reshape(n, n), f=opt.current_objective_value,
+                last_step_length=opt.last_step_length, iteration_count=opt.iteration_count,
+                last_step_type=opt.last_step_type, has_terminated=opt.has_terminated)
+
+
+@pytest.mark.parametrize("n,steps", [(2, 40), (16, 40), (200, 30), (4096, 10)])
+def test_each_bfgs_step_matches_oracle_on_identical_state_quadratic(n, steps):
+    """BASELINE config 2 (dense quadratic, up to the full n = 4096: H = 128 MiB)."""
+    A = orc.quadratic_matrix(n)
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    ref_p = orc.Problem(orc.QUADRATIC, n, A=A)
+    ref = orc.BFGS(ref_p, x0, 1.0)
+    opt = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+    x_scale, f_scale = np.linalg.norm(x0), abs(ref_p.eval(x0))
+    orc.set_threads(8 if n >= 1024 else 1)
+    try:
+        types = set()
+        for it in range(steps):
+            opt.install_state(**_oracle_state(ref))
+            opt.step(); ref.step()
+            _check_step(_read(opt), ref, x_scale, f_scale, (n, it))
+            types.add(ref.last_step_type)
+            if ref.has_terminated:
+                break
+        assert dzo.STEP_BFGS in types                     # the rank-2 update + fused direction ran
+    finally:
+        orc.set_threads(1)
+
+
+@pytest.mark.parametrize("n,steps", [(2, 60), (16, 60), (200, 40)])
+def test_each_bfgs_step_matches_oracle_on_identical_state_rosenbrock(n, steps):
+    """Non-quadratic objective: the sequential (not side-by-side) line searches, gradient-descent
+    steps with the H <- I reset (:962-986) and BFGS steps all occur."""
+    x0 = orc.pcg_fill(n, 1000 + n)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+    ref = orc.BFGS(ref_p, x0, 1.0)
+    opt = dzo.BFGSOptimizer(dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0)
+    x_scale, f_scale = np.linalg.norm(x0), abs(ref_p.eval(x0))
+    types = set()
+    for it in range(steps):
+        opt.install_state(**_oracle_state(ref))
+        opt.step(); ref.step()
+        _check_step(_read(opt), ref, x_scale, max(abs(ref.current_objective_value), 1e-30) if it > 5 else f_scale, (n, it))
+        types.add(ref.last_step_type)
+        if ref.has_terminated:
+            break
+    assert dzo.STEP_BFGS in types
+
+
+def test_bfgs_state_setters_round_trip_and_checkpoint_resume():
+    """README.md:11 "save/load data in the middle of optimization": a run checkpointed after 7 steps and
+    resumed in a NEW optimizer continues bit for bit."""
+    n = 96
+    A = orc.quadratic_matrix(n)
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    a = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+    for _ in range(7):
+        a.step()
+    snap = _read(a)
+    b = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+    b.install_state(snap["x"], snap["g"], snap["H"], snap["d"], snap["f"], snap["last_step_length"],
+                    snap["iteration_count"], snap["last_step_type"], snap["dx"], snap["dg"])
+    assert b.iteration_count == 7 and b.last_step_type == snap["last_step_type"]
+    assert b.current_objective_value == snap["f"] and b.last_step_length == snap["last_step_length"]
+    for _ in range(6):
+        a.step(); b.step()
+        ra, rb = _read(a), _read(b)
+        for key in ("x", "g", "dx", "dg", "d", "H"):
+            assert np.array_equal(ra[key], rb[key]), key
+        assert ra["f"] == rb["f"] and ra["last_step_length"] == rb["last_step_length"]
+    with pytest.raises(AssertionError):                                  # :773 @assert !isnan(f)
+        dzo._check(dzo.lib().dzo_bfgs_set_s(b.h, 0, float("nan")))
+    with pytest.raises(dzo.DzoError):
+        dzo._check(dzo.lib().dzo_bfgs_set_i(b.h, 3, 7))                  # not a StepType (:727-731)
+    dzo._check(dzo.lib().dzo_bfgs_set_i(b.h, 0, 1))
+    its = b.iteration_count
+    b.step()
+    assert b.has_terminated and b.iteration_count == its                 # :893 terminated optimizers never move
+
+
+# ------------------------------------------------------------------------------ batched (K11)
+def _batch_read(batch):
+    B, n = batch.batch, batch.n
+    H = batch.approximate_inverse_hessian.to_host().reshape(B, n, n)
+    return dict(x=batch.current_point.to_host(), g=batch.current_gradient.to_host(), H=H,
+                d=batch.next_step_direction.to_host(), dx=batch.delta_point.to_host(), dg=batch.delta_gradient.to_host(),
+                f=batch.current_objective_value.to_host(), last_step_length=batch.last_step_length.to_host(),
+                iteration_count=batch.iteration_count.to_host(), last_step_type=batch.last_step_type.to_host(),
+                has_terminated=batch.has_terminated.to_host())
+
+
+@pytest.mark.parametrize("n,B,steps", [(2, 6, 30), (16, 5, 30), (256, 4, 12), (512, 3, 8), (1024, 2, 6)])
+def test_each_batched_step_matches_per_instance_oracle_on_identical_state(n, B, steps):
+    """Config 5's kernel, one oracle per instance; n = 512 / 1024 take the two- and four-row-pair
+    instantiations with more than 48 KiB of dynamic LDS."""
+    X0 = np.stack([orc.pcg_fill(n, 1000 + b) for b in range(B)])
+    batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
+    refs = [orc.BFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), X0[b].copy(), 1.0) for b in range(B)]
+    x_scale = [np.linalg.norm(X0[b]) for b in range(B)]
+    f_scale = [abs(r.current_objective_value) for r in refs]
+    types = set()
+    for it in range(steps):
+        st = [_oracle_state(r) for r in refs]
+        batch.install_state(x=np.stack([s["x"] for s in st]), g=np.stack([s["g"] for s in st]),
+                            H=np.stack([s["H"] for s in st]), d=np.stack([s["d"] for s in st]),
+                            f=[s["f"] for s in st], last_step_length=[s["last_step_length"] for s in st],
+                            iteration_count=[s["iteration_count"] for s in st],
+                            last_step_type=[s["last_step_type"] for s in st],
+                            has_terminated=[int(r.has_terminated) for r in refs],
+                            dx=np.stack([s["dx"] for s in st]), dg=np.stack([s["dg"] for s in st]))
+        batch.step(1, poll=False)
+        for r in refs:
+            r.step()
+        got = _batch_read(batch)
+        for b in range(B):
+            one = {k: (v[b] if isinstance(v, np.ndarray) else v) for k, v in got.items()}
+            one["has_terminated"] = bool(one["has_terminated"])
+            fs = f_scale[b] if it <= 5 else max(abs(refs[b].current_objective_value), 1e-30)
+            _check_step(one, refs[b], x_scale[b], fs, (n, it, b))
+            types.add(refs[b].last_step_type)
+    assert dzo.STEP_BFGS in types
