@@ -97,6 +97,15 @@ def _dist_setup(gpus):
     return world, rank, local
 
 
+def _make_comm(dzo, world):
+    """N > 1 over RCCL: the convergence flag goes through dzo_flag_allreduce_min (the C-ABI collective a
+    Julia host uses too); the unique id travels over the torch.distributed group.  The gloo rehearsal
+    (two ranks on one GPU, which RCCL refuses) keeps torch.distributed for the flag."""
+    if world <= 1 or os.environ.get("BENCH_DIST_BACKEND", "nccl") != "nccl":
+        return None
+    return dzo.Comm.from_torch_distributed()
+
+
 def _barrier(world):
     import torch
     if world > 1:
@@ -130,8 +139,10 @@ def _kernel_bytes(name, n, k, esize):
     return None
 
 
-def cpu_baseline(n, m, warm, steps, threads):
-    """The oracle (C restatement of the reference's unfused op sequence) timed on host cores."""
+def cpu_baseline(n, m, warm, steps, threads, steps_single=None):
+    """The oracle (C restatement of the reference's unfused op sequence) timed on the host cores:
+    `warm` untimed steps on all cores to fill the history, `steps` timed steps on `threads` cores, then
+    `steps_single` timed steps of the same optimizer on ONE core (both)."""
     from oracle import oracle as orc
     orc.set_threads(threads)
     try:
@@ -143,14 +154,116 @@ def cpu_baseline(n, m, warm, steps, threads):
         for _ in range(steps):
             opt.step()
         dt = time.perf_counter() - t0
-        f = opt.current_objective_value
+        single = None
+        if steps_single:
+            orc.set_threads(1)
+            t0 = time.perf_counter()
+            for _ in range(steps_single):
+                opt.step()
+            single = steps_single / (time.perf_counter() - t0)
         opt.close()
     finally:
         orc.set_threads(1)
-    return steps / dt, f
+    return steps / dt, single
+
+
+def cpu_baseline_object(unit, threads, fn_all, fn_single, sample):
+    """{"value": all-core rate, "cores": nproc, "single_thread": {...}} from two timed closures."""
+    v = fn_all()
+    out = {"value": round(v, 4), "unit": unit, "cores": threads, "kind": "port", "sample": sample}
+    if fn_single is not None:
+        out["single_thread"] = {"value": round(fn_single(), 4), "cores": 1}
+    return out
+
+
+def host_cores():
+    """Host cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is
+    one; a GPU box of the pool reports all of the host's hardware threads but gives one GPU's job a share of 16
+    (task statement), so an implausibly large count falls back to that share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    if n > 64:
+        n = int(os.environ.get("BENCH_HOST_CORES", "16"))
+    return max(1, n)
 
 
 # ------------------------------------------------------------------------------ secondary workloads
+def _timed(fn, reps):
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return reps / (time.perf_counter() - t0)
+
+
+def cpu_baseline_secondary(workload, n, m=10, A=None):
+    """CPU baselines of the secondary workloads: the oracle on a bounded sample, all cores and one core."""
+    from oracle import oracle as orc
+    threads = host_cores()
+    try:
+        if workload == "bfgs_dense":
+            x0 = pcg32_uniform(n, 4) - 0.5
+            orc.set_threads(threads)
+            ref = orc.BFGS(orc.Problem(orc.QUADRATIC, n, A=A), x0, 1.0)
+            for _ in range(3):
+                ref.step()
+            v = _timed(ref.step, 10)
+            orc.set_threads(1)
+            v1 = _timed(ref.step, 4)
+            return {"value": round(v, 3), "unit": "step!() calls/s", "cores": threads, "kind": "port",
+                    "single_thread": {"value": round(v1, 3), "cores": 1, "steps": 4},
+                    "sample": f"oracle dense BFGS on the same quadratic, n={n}: 3 untimed steps, 10 timed on OpenMP x{threads}, 4 on one core"}
+        if workload == "bfgs_batched":
+            # independent instances, one per host thread (the reference's "run multiple optimizers in parallel")
+            from concurrent.futures import ThreadPoolExecutor
+            steps, per = 12, 2
+            prob = orc.Problem(orc.ROSENBROCK_CHAIN, n)
+            refs = [orc.BFGS(prob, pcg32_uniform(n, 1000 + b), 1.0) for b in range(threads * per + 1)]   # built before the clock starts
+            def run(ref):
+                for _ in range(steps):
+                    ref.step()
+                return ref.iteration_count
+            orc.set_threads(1)
+            t0 = time.perf_counter(); it1 = run(refs[-1]); dt1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                its = list(ex.map(run, refs[:-1]))
+            dta = time.perf_counter() - t0
+            return {"value": round(sum(its) / dta, 2), "unit": "instance-step!() calls/s", "cores": threads, "kind": "port",
+                    "single_thread": {"value": round(it1 / dt1, 2), "cores": 1, "steps": steps},
+                    "sample": f"oracle dense BFGS, chained Rosenbrock n={n}: {threads * per} independent instances x {steps} steps, "
+                              f"one instance per host thread ({threads} threads); one instance alone for the single-core rate"}
+        if workload == "adgd":
+            orc.set_threads(threads)
+            ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n), orc.rosenbrock_chain_x0(n), 1.0)
+            for _ in range(5):
+                ref.step()
+            v = _timed(ref.step, 20)
+            orc.set_threads(1)
+            v1 = _timed(ref.step, 10)
+            return {"value": round(v, 3), "unit": "step!() calls/s", "cores": threads, "kind": "port",
+                    "single_thread": {"value": round(v1, 3), "cores": 1, "steps": 10},
+                    "sample": f"oracle AdGD on the chained Rosenbrock objective, n={n}: 5 untimed, 20 timed steps on OpenMP x{threads}, 10 on one core"}
+        if workload == "lbfgs_lse_f32":
+            g, S, Y = orc.frozen_two_loop_state(n, m, np.float32)
+            rho = np.array([orc.dot(S[i], Y[i]) for i in range(m)], np.float32)
+            orc.set_threads(threads)
+            v = _timed(lambda: orc.lbfgs_direction(g, S, Y, rho), 40)
+            orc.set_threads(1)
+            v1 = _timed(lambda: orc.lbfgs_direction(g, S, Y, rho), 10)
+            return {"value": round(v, 3), "unit": "compute_lbfgs_step_direction! calls/s", "cores": threads, "kind": "port",
+                    "single_thread": {"value": round(v1, 3), "cores": 1, "steps": 10},
+                    "sample": f"oracle two-loop (4k+3 unfused BLAS-1 calls) on the same frozen state, n={n}, k={m}, fp32: 40 calls on "
+                              f"OpenMP x{threads}, 10 on one core"}
+    finally:
+        orc.set_threads(1)
+    return None
+
+
 def quadratic_matrix(n, r=8):
     """C2: A = D + U U'/r, D = diag(1 + 99 u) (seed 2), U entries u - 1/2 (seed 3)."""
     dvec = 1.0 + 99.0 * pcg32_uniform(n, 2)
@@ -246,7 +359,9 @@ def secondary_workload(args):
         lo = rank * B                                              # weak scaling: B instances per GPU
         X0 = np.stack([pcg32_uniform(n, 1000 + lo + b) for b in range(B)])
         batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
-        flag = sharding.ConvergenceFlag(poll=1)
+        comm = _make_comm(dzo, world)                              # RCCL communicator behind the C ABI when N > 1
+        flag = sharding.ConvergenceFlag(poll=1, comm=comm)
+        polls = 0
         batch.step(args.warmup, poll=False)
         dzo.synchronize()
         dzo.profile_reset(); dzo.profile_enable(True)
@@ -259,7 +374,11 @@ def secondary_workload(args):
             k = min(chunk, args.steps - done_steps)
             batch.step(k, poll=False)
             done_steps += k
-            flag.update(batch.count_active() == 0)                 # RCCL all-reduce of the flag when N > 1
+            if comm is not None:
+                comm.all_done([batch])                             # dzo_bfgs_batch_all_done: local count + one 4-byte all-reduce
+            else:
+                flag.update(batch.count_active() == 0)             # (single GPU, or the gloo rehearsal)
+            polls += 1
         dzo.synchronize(); _barrier(world)
         el = sharding.max_over_ranks(time.perf_counter() - t0)
         dzo.profile_enable(False)
@@ -272,8 +391,10 @@ def secondary_workload(args):
                     "value": round(inst_steps / el, 1), "unit": "instance-step!() calls/s",
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
                     "config": {"workload": f"batched BFGS, {B} instances/GPU x n={n}, chained Rosenbrock, fp64 (BASELINE configs[4])",
-                               "instances_per_gpu": B, "active_at_end": batch.count_active(),
-                               "parallelism": "instances sharded by rank, RCCL all-reduce of the convergence flag only",
+                               "instances_per_gpu": B, "instances_total": B * world, "active_at_end": batch.count_active(),
+                               "parallelism": (f"instances sharded by rank (block partition), world size {world}; the only collective is "
+                                               f"the convergence flag: {'dzo_bfgs_batch_all_done (RCCL behind the C ABI)' if comm is not None else flag.transport}, "
+                                               f"{polls} polls in the timed region"),
                                "device": info["name"]},
                     "roofline": {"bound": "hbm", "kernel": "bfgs_batch_step", "achieved": None if ach is None else round(ach, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
@@ -366,10 +487,57 @@ def secondary_workload(args):
                                  "note": "launch-latency-bound at this size: 4 launches move 168 MB"},
                     "kernels": kern})
     if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_secondary(args.workload, n, m=(10 if args.m == 20 else args.m),
+                                                         A=A if args.workload == "bfgs_dense" else None)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def _two_pass_leg(dzo, n, m, esize, args):
+    os.environ["DZO_TUNE_SINGLE_PASS"] = "0"             # read when an optimizer is created
+    try:
+        x2 = dzo.DeviceArray.from_host(rosenbrock_chain_x0(n, seed=5))
+        opt2 = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, x2, 1.0, m)
+    finally:
+        del os.environ["DZO_TUNE_SINGLE_PASS"]
+    for _ in range(m + args.warmup):
+        opt2.step()
+    steps2 = max(20, min(args.steps, 50))
+    dzo.synchronize()
+    dzo.profile_reset(); dzo.profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps2):
+        opt2.step()
+    dzo.synchronize()
+    el = time.perf_counter() - t0
+    dzo.profile_enable(False)
+    tab = dzo.profile_table()
+    k = opt2.history_count
+    assert opt2.single_pass_steps == 0
+    out = {"steps": steps2, "ms_per_step": round(1e3 * el / steps2, 4), "step_calls_per_s": round(steps2 / el, 2),
+           "note": "same workload, optimizer created with DZO_TUNE_SINGLE_PASS=0 in this process; HIP events on the "
+                   "launching stream; algorithmic bytes: gram (2k+1) n T, combine (2k+1) n T, two-loop (4k+2) n T"}
+
+    def leg(name, nbytes):
+        if name not in tab or not tab[name][0]:
+            return None
+        us = 1e3 * tab[name][1] / tab[name][0]
+        return {"launches": tab[name][0], "avg_us": round(us, 2), "algorithmic_bytes": nbytes,
+                "achieved": round(nbytes / (us * 1e-6) / 1e9, 1), "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    out["gram"] = leg("lbfgs_gram_pass", (2 * k + 1) * n * esize)
+    out["combine"] = leg("lbfgs_combine", (2 * k + 1) * n * esize)
+    names = ("lbfgs_gram_pass", "lbfgs_gram_reduce", "lbfgs_gram_finish", "lbfgs_combine")
+    if all(x in tab for x in ("lbfgs_gram_pass", "lbfgs_combine")):
+        # per direction: every launch of the four kernels in the timed region / directions computed
+        us = sum(1e3 * tab[x][1] for x in names if x in tab) / max(tab["lbfgs_combine"][0], 1)
+        nb = (4 * k + 2) * n * esize
+        out["two_loop"] = {"directions": tab["lbfgs_combine"][0], "avg_us": round(us, 1), "algorithmic_bytes": nb,
+                           "achieved": round(nb / (us * 1e-6) / 1e9, 1), "frac": round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    opt2.close()
+    return out
 
 
 # ------------------------------------------------------------------------------ main
@@ -383,8 +551,10 @@ def main():
     ap.add_argument("--mode", choices=["gram", "chain"], default="gram")
     ap.add_argument("--poll", type=int, default=10, help="all-reduce the convergence flag every POLL steps (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-pass", action="store_true", help="skip the two-pass (Gram + combine) roofline leg at N = 1")
     ap.add_argument("--cpu-dim", dest="cpu_n", type=int, default=None, help="n of the CPU sample (default: same n)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU steps on all cores")
+    ap.add_argument("--cpu-steps-single", type=int, default=5, help="timed CPU steps on one core")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--kernel-events", type=int, default=1, choices=[1, 2],
                     help="HIP events in the timed region: 1 = the two-loop (roofline) kernels only, 2 = every kernel")
@@ -419,7 +589,8 @@ def main():
 
     import importlib
     sharding = importlib.import_module("dzoptimization_jl_amd.sharding")
-    flag = sharding.ConvergenceFlag(poll=args.poll)     # RCCL all-reduce(MIN) of one int32 when N > 1
+    comm = _make_comm(dzo, world)                        # the library's own RCCL communicator (C ABI) when N > 1
+    flag = sharding.ConvergenceFlag(poll=args.poll, comm=comm)   # all-reduce(MIN) of one int32
     if world > 1:
         import torch.distributed as dist
 
@@ -446,6 +617,14 @@ def main():
             dist.destroy_process_group()
         return
 
+    # The two-loop recursion proper ((4k+2) n T per direction): the same workload on the
+    # two-pass path -- Gram pass + reduce + finish + combine per step, what callbacks / any other
+    # objective run -- measured in this process on a second optimizer created with the single-pass step
+    # switched off.  N = 1 only (a reported roofline leg, not part of `value`).
+    two_pass = None
+    if world == 1 and "lbfgs_single_pass" in table and not args.no_two_pass and args.mode == "gram":
+        two_pass = _two_pass_leg(dzo, n, m, esize, args)
+
     k = opt.history_count
     kernels = {}
     for name, (launches, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
@@ -469,26 +648,18 @@ def main():
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize),
                         "avg_launch_us": kernels[dom]["avg_us"]}
-            # the two-loop as a unit of work ((4k+2) n T per direction).  On the single-pass
-            # path one sweep serves the combine half of this step's two-loop AND the dot-product half
-            # of the next one, so a step moves less than the per-loop contract figure: `achieved`
-            # above is by the kernel's own bytes; this entry restates the step in contract units.
-            loop_names = ("lbfgs_single_pass", "lbfgs_gram_pass", "lbfgs_gram_reduce", "lbfgs_gram_finish", "lbfgs_combine",
-                          "lbfgs_chain_head", "lbfgs_chain_link")
-            two_loop_us = sum(1e3 * table[x][1] for x in loop_names if x in table) / max(args.steps, 1)
-            roofline["two_loop"] = {"algorithmic_bytes": (4 * k + 2) * n * esize, "avg_us": round(two_loop_us, 1),
-                                    "achieved": round((4 * k + 2) * n * esize / (two_loop_us * 1e-6) / 1e9, 1),
-                                    "frac": round((4 * k + 2) * n * esize / (two_loop_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "note": "all two-loop kernel time of the timed region / steps; contract bytes per "
-                                            "direction, not bytes moved, when lbfgs_single_pass is in use"}
+            roofline["traffic_source"] = (None if traffic is None else
+                                          "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command (separate runs, gfx950 x2 read correction), not measured in this process")
             if "lbfgs_single_pass" in table:
                 roofline["single_pass"] = {"launches": table["lbfgs_single_pass"][0],
                                            "fallback_gram_passes": table.get("lbfgs_gram_pass", (0, 0))[0],
                                            "note": "first trial rejected -> the step finishes on the two-pass kernels and the "
                                                    "next step needs a Gram pass"}
+            if two_pass is not None:
+                roofline["two_pass"] = two_pass
 
     value = world * args.steps / elapsed
-    step_bytes = (4 * k + 10) * n * esize                     # one step ex-objective, 1 trial
     out = {
         "metric": "step!() calls/sec and achieved HBM GB/s, L-BFGS n=10^7 m=20 fp64",
         "value": round(value, 3), "unit": "step!() calls/s", "n_gpus": world, "steps": args.steps,
@@ -498,25 +669,24 @@ def main():
                    "n": n, "m": m, "history_full": k == m,
                    "two_loop": ("single_pass (one sweep over the history per accepted step; gram + combine after a "
                                 "rejected first trial)" if "lbfgs_single_pass" in table else args.mode),
-                   "parallelism": "1 optimizer instance per GPU, RCCL all-reduce of the convergence flag only"
+                   "parallelism": (f"1 optimizer instance per GPU (replicas), world size {world}; convergence flag: "
+                                   f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",
                    "objective_evals_per_step": round(trials / args.steps, 3), "any_stuck": any_stuck,
                    "f_start": f_start, "f_end": opt.current_objective_value, "device": info["name"]},
-        "step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 1),
-        "step_algorithmic_note": "SURVEY 8(d) contract bytes per step, (4k+10) n T, over wall time -- NOT bytes moved: the "
-                                 "single-pass step moves (2k+9) n T per accepted step (roofline.achieved uses that figure)",
         "roofline": roofline, "kernels": kernels,
     }
     if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N = 1 only
-        threads = min(os.cpu_count() or 1, 16)
+        threads = host_cores()
         cn = args.cpu_n or n
-        cwarm = m if cn == n else m
-        v, _ = cpu_baseline(cn, m, cwarm, args.cpu_steps, threads)
-        out["cpu_baseline"] = {"value": round(v * (1.0 if cn == n else cn / n), 4), "unit": "step!() calls/s",
-                               "cores": threads, "kind": "port",
-                               "sample": f"oracle/dzo_oracle.c (unfused op sequence of the reference, OpenMP x{threads}), "
-                                         f"n={cn}, m={m}: {cwarm} untimed steps to fill the history, then {args.cpu_steps} "
-                                         f"timed step!() calls" + ("" if cn == n else f"; rate scaled by {cn}/{n}")}
+        scale = 1.0 if cn == n else cn / n
+        v, v1 = cpu_baseline(cn, m, m, args.cpu_steps, threads, args.cpu_steps_single)
+        out["cpu_baseline"] = {"value": round(v * scale, 4), "unit": "step!() calls/s", "cores": threads, "kind": "port",
+                               "single_thread": {"value": round(v1 * scale, 4), "cores": 1, "steps": args.cpu_steps_single},
+                               "sample": f"oracle/dzo_oracle.c (unfused op sequence of the reference), n={cn}, m={m}: {m} untimed "
+                                         f"steps to fill the history, then {args.cpu_steps} timed step!() calls with OpenMP x{threads} "
+                                         f"(= the host cores this job may use) and {args.cpu_steps_single} more on one core"
+                                         + ("" if cn == n else f"; rates scaled by {cn}/{n}")}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -92,6 +92,11 @@ inline int stream_grid(int64_t n, int elems_per_thread) {
     return (int)blocks;
 }
 
+// Optimizers may keep the current point / gradient in an internal twin of the array they alias (see
+// dzo_lbfgs.hip); every entry point through which the HOST is about to look at device memory
+// (dzo_synchronize, dzo_memcpy_*) first writes them back.  Cheap when nothing is pending.
+int32_t settle_all_optimizers();
+
 // ------------------------------------------------------------------------------ profiling
 // HIP-event pairs recorded on the launching stream around each kernel (bench roofline leg).
 struct ProfileEntry {

@@ -197,6 +197,7 @@ int32_t dzo_device_info(char *name, int32_t name_len, int32_t *compute_units, in
 
 int32_t dzo_synchronize(void) {
     DZO_TRY(require_init());
+    DZO_TRY(settle_all_optimizers());
     DZO_HIP(hipDeviceSynchronize());
     return DZO_OK;
 }
@@ -265,6 +266,7 @@ int32_t dzo_free(void *ptr_dev) {
 
 int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes) {
     DZO_TRY(require_init());
+    DZO_TRY(settle_all_optimizers());          // (a write into an aliased array must land in the live copy)
     DeviceScope scope(device_of(dst_dev));
     DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
@@ -274,6 +276,7 @@ int32_t dzo_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes) {
 
 int32_t dzo_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes) {
     DZO_TRY(require_init());
+    DZO_TRY(settle_all_optimizers());
     DeviceScope scope(device_of(src_dev));
     // every library stream is non-blocking w.r.t. the null stream: drain the device first
     DZO_HIP(hipDeviceSynchronize());
@@ -283,6 +286,7 @@ int32_t dzo_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes) {
 
 int32_t dzo_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes) {
     DZO_TRY(require_init());
+    DZO_TRY(settle_all_optimizers());
     DeviceScope scope(device_of(dst_dev));
     DZO_HIP(hipDeviceSynchronize());
     if (bytes > 0) DZO_HIP(hipMemcpy(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice));

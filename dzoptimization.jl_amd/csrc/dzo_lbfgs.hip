@@ -88,15 +88,21 @@ struct dzo_lbfgs_s {
     bool gram_ready = false;        // gram_partials hold the dots of the CURRENT history (from the last single pass)
     int gram_ready_grid = 0;
     bool scalars_ready = false;     // alpha / coef / scale are valid for the current history and gradient
-    void *halo = nullptr, *xbak = nullptr, *gbak = nullptr;   // halo: two snapshots, ping-pong
-    void *bak_slab = nullptr, *d_alloc = nullptr;
-    int halo_cur = 0;               // which half the next pass reads
-    bool halo_valid = false;        // ... and whether the last pass already filled it
+    // The pass never writes x or g: the trial point and its gradient go to TWIN buffers and the two
+    // pairs of pointers swap when the trial is accepted (no backups of x_old / g_old, nothing to restore
+    // after a rejected trial).  x_user / g_user are the arrays the optimizer aliases (:393, :395);
+    // whenever the host looks (get_ptr, dzo_synchronize, dzo_memcpy_*, destroy) the current point and
+    // gradient are settled back into them.
+    void *twin_slab = nullptr, *x_twin = nullptr, *g_twin = nullptr, *d_alloc = nullptr;
+    void *x_user = nullptr, *g_user = nullptr;
+    bool unsettled = false;         // registered in the list that dzo_synchronize / dzo_memcpy_* settle
+    std::recursive_mutex mu;        // a step vs a settle coming from another host thread (recursive: a callback may call a getter)
     int64_t single_pass_steps = 0, single_pass_rejections = 0;
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 0, gram_bpc = 0;   // tuning knobs (DZO_TUNE_* env, dev only)
 
+    int device = 0;                 // the GPU this optimizer lives on
     int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
     int spare() const { return (newest + 1) % (m + 1); }
     // layout 1 (default): ONE slab, slots interleaved s_0 y_0 s_1 y_1 ... (Y = S + stride, pair
@@ -751,10 +757,8 @@ template <typename T> struct FusedParams {
     int k;                                     // pairs read (history before the push)
     int k_next;                                // pairs after the push = min(k + 1, m)
     T t;                                       // first trial step size (1)
-    T *x, *g;                                  // current_point / current_gradient, updated in place
-    const T *halo;                             // [rows][2 sides][x, g] boundary vectors of x_old / g_old
-    T *halo_next;                              // the same for the next pass (boundary vectors of x_new / g_new)
-    T *xbak, *gbak;                            // x_old / g_old for a rejected trial
+    const T *x, *g;                            // current_point / current_gradient: READ ONLY in this pass
+    T *x_out, *g_out;                          // the trial point and its gradient go to the twin buffers
     T *d;                                      // step_direction
     T *s_new, *y_new;                          // delta_point / delta_gradient (spare slots)
     const double *alpha, *coef, *scale;
@@ -766,26 +770,9 @@ template <typename T> struct FusedParams {
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain
 };
 
-// boundary vectors of every wave-row (left halo = vector kRowOwn r - 1, right halo = kRowOwn r + kRowOwn)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void halo_snapshot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ g,
-                                                               T *__restrict__ halo) {
-    constexpr int N = Vec16<T>::N;
-    const int64_t nvec = n / N;
-    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= rows * 2) return;
-    const int64_t row = id >> 1;
-    const int64_t v = (id & 1) ? row * kRowOwn + kRowOwn : row * kRowOwn - 1;
-    if (v < 0 || v >= nvec) return;
-    T xv[N], gv[N];
-    load16(x + v * N, xv);
-    load16(g + v * N, gv);
-    store16(halo + id * 2 * N, xv);
-    store16(halo + id * 2 * N + N, gv);
-}
-
-template <typename T, int K>
+// PLAIN: ablation build with plain instead of non-temporal history loads (DZO_TUNE_SP_DEBUG bit 256,
+// fp64 K = 20 only); a run-time switch inside the kernel costs SGPRs the production kernel does not have
+template <typename T, int K, bool PLAIN = false>
 __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
     constexpr int kOwn = kRowOwn, kLead = kRowLead;
@@ -807,7 +794,6 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     const int64_t nvec = p.n / N;
     const int64_t rows = (nvec + kOwn - 1) / kOwn;
     const int64_t stride = (int64_t)gridDim.x * kWaves;
-    const bool halo_lane = lane == kLead - 1 || lane == kLead + kOwn;
     double acc[kGramValues];
 #pragma unroll
     for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
@@ -825,10 +811,10 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     auto at = [](const T *base, uint32_t boff) { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + boff); };
     auto atw = [](T *base, uint32_t boff) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff); };
     auto load_xg = [&](int64_t row, uint32_t boff, T (&xo)[N], T (&go)[N]) {
-        // halo lanes take x_old / g_old from the snapshot (their owners may already have moved on)
-        const T *h = p.halo + ((row * 2 + (lane == kLead + kOwn ? 1 : 0)) * 2) * N;
-        load16(halo_lane ? h : at(p.x, boff), xo);
-        load16(halo_lane ? h + N : at(p.g, boff), go);
+        // x and g are not written by this pass (the trial point goes to the twin buffers), so the halo
+        // lanes simply read their neighbours' vectors
+        load16(at(p.x, boff), xo);
+        load16(at(p.g, boff), go);
     };
 
     // TWO register sets for the 2K history vectors of a row: all loads of row r+1 are in flight
@@ -839,6 +825,13 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     // register set refilled pair by pair during the dots, 537 us for the loads alone.
     auto issue = [&](int64_t row, uint32_t boff, T (&sv)[K][N], T (&yv)[K][N], T (&xo)[N], T (&go)[N]) {
         load_xg(row, boff, xo, go);
+        if constexpr (PLAIN) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) load16(at(p.y[i], boff), yv[i]);
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) load16(at(p.s[i], boff), sv[i]);
+            return;
+        }
         if (p.debug_skip & 16) { load16(at(p.y[0], boff), yv[0]); load16(at(p.s[0], boff), sv[0]); }
         else { load16_nt(at(p.y[0], boff), yv[0]); load16_nt(at(p.s[0], boff), sv[0]); }
 #pragma unroll
@@ -895,22 +888,10 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             // non-temporal stores throughout: 7 n T of fresh dirty lines otherwise sit in the Infinity
             // Cache and their write-back lands on the next pass (measured inside step!: 910 -> 815 us)
             if (!(p.debug_skip & 128)) store16_nt(atw(p.d, boff), q);
-            store16_nt(atw(p.x, boff), xn);
-            if (!(p.debug_skip & 32)) store16_nt(atw(p.xbak, boff), xo);                      // :118
-            store16_nt(atw(p.g, boff), gn);
-            if (!(p.debug_skip & 32)) store16_nt(atw(p.gbak, boff), go);
+            store16_nt(atw(p.x_out, boff), xn);
+            store16_nt(atw(p.g_out, boff), gn);
             if (!(p.debug_skip & 64)) store16_nt(atw(p.s_new, boff), sn);
             if (!(p.debug_skip & 64)) store16_nt(atw(p.y_new, boff), yn);
-            // the first / last owned vector of a row is the right / left halo of the neighbouring row
-            // in the NEXT pass: leave it there now and that pass needs no snapshot kernel
-            if (lane == kLead && row > 0) {
-                T *h = p.halo_next + (((row - 1) * 2 + 1) * 2) * N;
-                store16(h, xn); store16(h + N, gn);
-            }
-            if (lane == kLead + kOwn - 1 && row + 1 < rows) {
-                T *h = p.halo_next + (((row + 1) * 2 + 0) * 2) * N;
-                store16(h, xn); store16(h + N, gn);
-            }
         }
         if (!owner) {
 #pragma unroll
@@ -1366,7 +1347,7 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
     dzo_lbfgs_s *o = static_cast<dzo_lbfgs_s *>(self);
     OptCore &c = o->core;
     int grid = 0;
-    DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, gate, c.xold_src, c.gold_src));
+    DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, gate));
     o->tail_grid = grid;
     if (o->mode == DZO_TWOLOOP_GRAM) return DZO_OK;      // rho rides on the next gram_reduce launch
     return lbfgs_rho_finish(o, grid, gate);
@@ -1515,7 +1496,7 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     OptCore &c = o->core;
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
     o->scalars_ready = false; o->gram_ready = false;      // x, g and the history are about to change
-    o->spec_scalars = false; o->halo_valid = false;
+    o->spec_scalars = false;
     const bool safeguards = o->descent_check || o->sd_fallback;
     if (o->line_search == 1) {
         bool accepted = false;
@@ -1534,12 +1515,6 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     }
     const bool fused = o->fused_post && !c.objective && !c.gradient && !c.constraint &&
                        problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
-    if (c.xold_src && !fused) {                           // (cannot happen with the single pass's own conditions; keep the plain path whole)
-        const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
-        DZO_HIP(hipMemcpyAsync(c.dx, c.xold_src, bytes, hipMemcpyDeviceToDevice, c.stream));
-        DZO_HIP(hipMemcpyAsync(c.g, c.gold_src, bytes, hipMemcpyDeviceToDevice, c.stream));
-        c.xold_src = nullptr; c.gold_src = nullptr;
-    }
     c.defer_delta = fused;
     c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
     c.speculative_self = o;
@@ -1551,7 +1526,6 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     if (c.is_stuck) {                                     // :474-476
         // delta_point holds x_old (:118, the first trial's backup); delta_gradient is still the
         // previous step's, which lives in the newest pair of the ring
-        if (c.xold_src) DZO_HIP(hipMemcpyAsync(c.dx, c.xold_src, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
         if (o->k > 0) c.dg = o->y_slot_v(o->newest);
         return DZO_OK;
     }
@@ -1561,7 +1535,7 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     } else if (fused) {
         // :145 + :478-480 + partials of :505 in one pass
         int grid = 0;
-        DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, nullptr, c.xold_src, c.gold_src));
+        DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, nullptr));
         done = lbfgs_finish_push(o, grid, false);
     } else {
         DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
@@ -1589,23 +1563,72 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
     if (c.n % vecn != 0 || c.n < 4 * vecn || (uint64_t)c.n * dtype_size(c.dtype) >= (1ull << 32)) return false;   // 32-bit byte offsets
     o->refresh_delta_ptrs();
     if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg) || !al16v(o->d)) return false;
-    // optional buffers of the pass (row-boundary vectors, x / g backups): allocated here, before the step
-    // touches anything; a failed allocation only switches this optimizer to the two-pass kernels
-    if (!o->halo) {
-        const int64_t rows = (c.n / vecn + kRowOwn - 1) / kRowOwn;
-        if (hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16) != hipSuccess) { (void)hipGetLastError(); o->halo = nullptr; o->single_pass = false; return false; }
-    }
-    if (!o->bak_slab) {
+    // the twin buffers of x and g: allocated here, before the step touches anything; a failed allocation
+    // only switches this optimizer to the two-pass kernels
+    if (!o->twin_slab) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * dtype_size(c.dtype);
         // one slab, the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator
-        // hands out: x, g, d and the backups are written at the same element offset at the same
+        // hands out: x, g, d and the twins are accessed at the same element offset at the same
         // time, and equal offsets into equally aligned buffers hit the same HBM channel
         const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;
-        if (hipMalloc(&o->bak_slab, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->bak_slab = nullptr; o->single_pass = false; return false; }
-        o->xbak = (char *)o->bak_slab + 5 * 1024;
-        o->gbak = (char *)o->xbak + slot;
+        if (hipMalloc(&o->twin_slab, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->twin_slab = nullptr; o->single_pass = false; return false; }
+        o->x_twin = (char *)o->twin_slab + 5 * 1024;
+        o->g_twin = (char *)o->x_twin + slot;
     }
     return true;
+}
+
+// ---- aliasing of the caller's arrays (:393, :395) with twin buffers
+static std::mutex g_unsettled_mu;
+static std::vector<dzo_lbfgs_s *> g_unsettled;
+
+static void lbfgs_mark_unsettled(dzo_lbfgs_s *o) {
+    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user;
+    std::lock_guard<std::mutex> lk(g_unsettled_mu);
+    if (dirty && !o->unsettled) { g_unsettled.push_back(o); o->unsettled = true; }
+    if (!dirty && o->unsettled) {
+        for (size_t i = 0; i < g_unsettled.size(); ++i)
+            if (g_unsettled[i] == o) { g_unsettled.erase(g_unsettled.begin() + (long)i); break; }
+        o->unsettled = false;
+    }
+}
+
+// current_point / current_gradient back into the arrays the optimizer aliases (a device copy each, only
+// when they currently live in the twins).  Caller holds o->mu.
+static int32_t lbfgs_settle_locked(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
+    if (c.x != o->x_user) {
+        DZO_HIP(hipMemcpyAsync(o->x_user, c.x, bytes, hipMemcpyDeviceToDevice, c.stream));
+        o->x_twin = c.x; c.x = o->x_user;
+    }
+    if (c.g != o->g_user) {
+        DZO_HIP(hipMemcpyAsync(o->g_user, c.g, bytes, hipMemcpyDeviceToDevice, c.stream));
+        o->g_twin = c.g; c.g = o->g_user;
+    }
+    lbfgs_mark_unsettled(o);
+    return DZO_OK;
+}
+
+static int32_t lbfgs_settle(dzo_lbfgs_s *o) {
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    return lbfgs_settle_locked(o);
+}
+
+// every optimizer whose point lives in a twin (called by dzo_synchronize and dzo_memcpy_*: the host is
+// about to look at device memory)
+int32_t settle_all_optimizers() {
+    for (;;) {
+        dzo_lbfgs_s *o = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_unsettled_mu);
+            if (g_unsettled.empty()) return DZO_OK;
+            o = g_unsettled.back();
+        }
+        DeviceScope scope(o->device);
+        DZO_TRY(lbfgs_settle(o));
+        DZO_HIP(hipStreamSynchronize(o->core.stream));
+    }
 }
 
 template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
@@ -1621,10 +1644,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     FusedParams<T> fp;
     memset(&fp, 0, sizeof(fp));
     fp.n = c.n; fp.k = k; fp.k_next = k < o->m ? k + 1 : o->m; fp.t = (T)1;
-    const size_t halo_elems = (size_t)rows * 2 * 2 * N;
-    fp.x = (T *)c.x; fp.g = (T *)c.g; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
-    fp.halo = (const T *)o->halo + (size_t)o->halo_cur * halo_elems;
-    fp.halo_next = (T *)o->halo + (size_t)(o->halo_cur ^ 1) * halo_elems;
+    fp.x = (const T *)c.x; fp.g = (const T *)c.g; fp.x_out = (T *)o->x_twin; fp.g_out = (T *)o->g_twin;
     fp.d = (T *)o->d; fp.s_new = (T *)c.dx; fp.y_new = (T *)c.dg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     for (int i = 0; i < kFusedMaxK; ++i) {                // entries >= k: any valid vector (zero coefficient)
@@ -1639,6 +1659,9 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     void (*kern)(FusedParams<T>) = o->m <= 8 ? lbfgs_single_pass_kernel<T, 8>
                                    : o->m <= 16 ? lbfgs_single_pass_kernel<T, 16>
                                    : lbfgs_single_pass_kernel<T, 20>;
+    if constexpr (std::is_same<T, double>::value) {
+        if ((fp.debug_skip & 256) && o->m > 16) kern = lbfgs_single_pass_kernel<double, 20, true>;
+    }
     int64_t blocks = (rows + kWaves - 1) / kWaves;
     const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
     if (blocks > res) blocks = res;
@@ -1647,13 +1670,6 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int grid = (int)(blocks < 1 ? 1 : blocks);
     if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
     c.flag_armed = false;
-    if (!o->halo_valid) {                                 // (after an accepted single pass the halos are already there)
-        DZO_TIMED("lbfgs_halo_snapshot", s);
-        const int hgrid = (int)((rows * 2 + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(halo_snapshot_kernel<T>, dim3(hgrid), dim3(kBlock), 0, s, c.n, (const T *)c.x, (const T *)c.g,
-                           (T *)o->halo + (size_t)o->halo_cur * halo_elems);
-    }
-    o->halo_valid = false;
     {
         DZO_TIMED("lbfgs_single_pass", s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
@@ -1682,11 +1698,11 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int32_t status = reinterpret_cast<int32_t *>(c.host + 3)[0];
     c.last_trials = 0;
     o->single_pass_steps += 1;
-    if (status == 2) {                                    // :128-131 (x_new == x_old everywhere, so x and g are intact)
+    if (status == 2) {                                    // :128-131 (x_new == x_old everywhere; x and g were never written)
         c.is_stuck = true;
         // the fields as take_backtracking_step! leaves them: delta_point = x_old (:118), delta_gradient
         // still the previous step's (= the newest pair of the ring; the pass wrote only spare slots)
-        DZO_HIP(hipMemcpyAsync(c.dx, o->xbak, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));
+        DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));
         if (o->k > 0) c.dg = o->y_slot_v(o->newest);
         return DZO_OK;
     }
@@ -1699,28 +1715,22 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
         o->spec_scalars = true;                           // alpha_sp / coef_sp / scale_sp hold the next step's scalars
         o->gram_ready = false;
         o->gram_stale = 0;
-        o->halo_cur ^= 1;
-        o->halo_valid = true;
+        // the trial point and its gradient become the current ones: swap the buffers' roles
+        std::swap(c.x, o->x_twin);
+        std::swap(c.g, o->g_twin);
+        lbfgs_mark_unsettled(o);
         return DZO_OK;
     }
-    // rejected: continue the reference loop at its first halving.  x_old and g_old are read from the
-    // backups the pass wrote (the trial kernel rebuilds x from x_old, the accepted-step tail overwrites
-    // g and the deltas); only a search that ends stuck needs them copied back.
+    // rejected: x and g are untouched, so the reference's loop simply continues at its first halving on
+    // the two-pass kernels (whose first trial saves x_old in delta_point, :118)
     o->single_pass_rejections += 1;
-    const size_t bytes = (size_t)c.n * sizeof(T);
-    c.xold_src = o->xbak; c.gold_src = o->gbak;
-    const int32_t rc = lbfgs_search_and_post(o, true);
-    c.xold_src = nullptr; c.gold_src = nullptr;
-    DZO_TRY(rc);
-    if (c.is_stuck) {                                     // (:151 restored x already -- from the backup; g still holds the rejected trial's gradient)
-        DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
-    }
-    return DZO_OK;
+    return lbfgs_search_and_post(o, true);
 }
 
 static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (c.is_stuck) return DZO_OK;                        // :456-458
+    std::lock_guard<std::recursive_mutex> step_lock(o->mu);
     DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
                 "step! needs objective and gradient (callbacks or a built-in problem)");
     if (c.problem && c.problem->parent) {                 // decorators may have been changed on the user's handle
@@ -1776,6 +1786,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     dzo_lbfgs_s *o = new dzo_lbfgs_s();
     OptCore &c = o->core;
     c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
+    o->x_user = x_dev; o->g_user = g_dev; o->device = ctx().device;
     c.f = round_to_dtype(dtype, initial_objective_value);
     o->m = history_length;
     const size_t es = dtype_size(dtype);
@@ -1875,12 +1886,17 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
 
 int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (!o) return DZO_OK;
+    if (o->core.stream && o->x_user) (void)lbfgs_settle(o);   // the caller's arrays end up holding the final point / gradient
+    {
+        std::lock_guard<std::mutex> lk(g_unsettled_mu);
+        for (size_t i = 0; i < g_unsettled.size(); ++i)
+            if (g_unsettled[i] == o) { g_unsettled.erase(g_unsettled.begin() + (long)i); break; }
+    }
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->S) (void)hipFree(o->S);
     if (o->Y && !o->interleaved) (void)hipFree(o->Y);
     if (o->d_alloc) (void)hipFree(o->d_alloc);
-    if (o->halo) (void)hipFree(o->halo);
-    if (o->bak_slab) (void)hipFree(o->bak_slab);
+    if (o->twin_slab) (void)hipFree(o->twin_slab);
     if (o->xt) (void)hipFree(o->xt);
     if (o->gt) (void)hipFree(o->gt);
     if (o->rho) (void)hipFree(o->rho);
@@ -1978,7 +1994,7 @@ int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_TRY(lbfgs_flush_rho(o));                          // a host-driven step follows: settle what the single pass deferred
-    o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false; o->halo_valid = false;
+    o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false;
     o->refresh_delta_ptrs();
     return core_begin_search(o->core);
 }
@@ -2080,6 +2096,7 @@ int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t o, int32_t is_stuck) {
 
 int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DZO_TRY(lbfgs_settle(o));                             // current_point / current_gradient ARE the caller's arrays again
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     switch (what) {
     case 0: *ptr_dev = o->core.x; break;
@@ -2126,7 +2143,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
     o->rho_pending = false;                              // the whole history (and its rho) is replaced
-    o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false; o->halo_valid = false;
+    o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false;
     OptCore &c = o->core;
     hipStream_t s = c.stream;
     const size_t es = dtype_size(c.dtype);

@@ -33,9 +33,6 @@ struct OptCore {
     double *host = nullptr;       // pinned host mirror of result[8]
     double *host_dev = nullptr;   // the same buffer as the device sees it (decide_kernel writes the outcome there)
     bool flag_armed = false;      // flag() is known to be zero (decide_kernel resets it after reading)
-    // after a rejected single-pass trial: x_old / g_old live in these backups instead of dx / g (saves
-    // two restore copies); cleared when the search ends
-    const void *xold_src = nullptr, *gold_src = nullptr;
     int64_t max_halvings = 4096;  // build-added escape from the NaN loop
     int64_t last_trials = 0;
     bool search_open = false;     // begin_search called, first trial not yet taken

@@ -165,8 +165,7 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
     const bool trial_fused = speculate && fuse_trial && !c.box_on &&
                              problem_trial_eval_async(c.problem, s, c.x, c.dx, dir, t, first, c.flag(), &partials, &count, &scale);
     if (!trial_fused) {
-        DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)(c.xold_src && !first ? const_cast<void *>(c.xold_src) : c.dx),
-                                              (const T *)dir, (T)t, first, c.flag()));
+        DZO_DISPATCH(c.dtype, launch_trial<T>(s, c.n, (T *)c.x, (T *)c.dx, (const T *)dir, (T)t, first, c.flag()));
         DZO_HIP(hipGetLastError());
     }
     // built-in box constraint: projection is always feasible, so it can ride in the stream (:134-135)
@@ -204,8 +203,7 @@ int32_t core_accept(OptCore &c, double f_new) {
 }
 
 int32_t core_reject(OptCore &c) {
-    const void *src = c.xold_src ? c.xold_src : c.dx;            // where this search keeps x_old
-    DZO_HIP(hipMemcpyAsync(c.x, src, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :151
+    DZO_HIP(hipMemcpyAsync(c.x, c.dx, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :151
     return DZO_OK;
 }
 
@@ -247,13 +245,14 @@ int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, bo
     if (!first_trial_rejected) {
         DZO_TRY(core_begin_search(c));                           // :118
     } else {
-        // the caller already evaluated x_old + step_size*dir (backup of x_old in delta_point) and
-        // found no decrease: continue the loop at its first halving (:151-152)
-        c.search_open = false;
+        // the caller already evaluated x_old + step_size*dir OUT OF PLACE (x still holds x_old) and found
+        // no decrease: continue the loop at its first halving (:151-152); the next trial is the first
+        // one that writes x, so it is the one that saves x_old in delta_point (:118)
+        c.search_open = true;
         c.last_trials = 1;
         step_size = round_to_dtype(c.dtype, step_size * 0.5);
         if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
-            DZO_TRY(core_reject(c));
+            DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));   // :118
             c.is_stuck = true;
             return DZO_OK;
         }

