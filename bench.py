@@ -420,7 +420,7 @@ def secondary_workload(args):
         tab = dzo.profile_table()
         kern = {kk: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for kk, v in tab.items()}
         us = 1e3 * tab["adgd_fused_step"][1] / tab["adgd_fused_step"][0] if "adgd_fused_step" in tab else None
-        ach = None if us is None else 8 * n * 8 / (us * 1e-6) / 1e9
+        ach = None if us is None else 6 * n * 8 / (us * 1e-6) / 1e9
         out.update({"metric": "step!() calls/sec, AdGD n=10^7 fp64 (SURVEY 8(f) rank 1)",
                     "value": round(world * args.steps / el, 2), "unit": "step!() calls/s",
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
@@ -431,7 +431,7 @@ def secondary_workload(args):
                     "roofline": {"bound": "hbm", "kernel": "adgd_fused_step", "achieved": None if ach is None else round(ach, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
                                  "traffic": None, "avg_launch_us": None if us is None else round(us, 2),
-                                 "note": "8 n T per pass: reads x, g; writes x, g, delta_point, delta_gradient and the two backups"},
+                                 "note": "6 n T per pass: reads x, g; writes the trial point and its gradient (twin buffers), delta_point, delta_gradient"},
                     "kernels": kern})
     else:  # lbfgs_lse_f32 (config 4)
         n = 1_000_000 if args.n == 10_000_000 else args.n
@@ -465,7 +465,7 @@ def secondary_workload(args):
         _barrier(world)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            fro.compute_step_direction()
+            fro.compute_step_direction(sync=False)               # enqueue only; the stream keeps the GPU busy
         dzo.synchronize(); _barrier(world)
         el = sharding.max_over_ranks(time.perf_counter() - t0)
         dzo.profile_enable(False)

@@ -627,10 +627,11 @@ class LBFGSOptimizer(_OptBase):
     single_pass_steps = property(lambda s: s._i(11))          # informational
     single_pass_rejections = property(lambda s: s._i(12))
 
-    def compute_step_direction(self):
-        """``compute_lbfgs_step_direction!`` (:430-451)."""
+    def compute_step_direction(self, sync=True):
+        """``compute_lbfgs_step_direction!`` (:430-451).  ``sync=False`` only enqueues the kernels (the
+        C entry point is asynchronous, include/dzo.h) and returns None."""
         _check(lib().dzo_lbfgs_direction(self.h))
-        return self.step_direction
+        return self.step_direction if sync else None
 
     def set_history(self, S, Y, rho=None, iteration_count=None):
         S, Y = _as_dev(S, self.dtype), _as_dev(Y, self.dtype)

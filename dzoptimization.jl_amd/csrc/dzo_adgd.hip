@@ -11,12 +11,17 @@ struct dzo_adgd_s {
     double previous_step_size = 0;   // :196
     void *dx_buf = nullptr, *dg_buf = nullptr, *dg_alt = nullptr;
     // fused step (built-in chained Rosenbrock): one pass does :301 (first trial), :306-308 and the
-    // two sums of squares that :292 / :294 of the NEXT step need
+    // two sums of squares that :292 / :294 of the NEXT step need.  The pass never writes x or g: the
+    // trial point and its gradient go to TWIN buffers, which swap roles with x / g when the trial is
+    // accepted (no backups, nothing to restore after a rejected trial, no boundary snapshots).  x_user /
+    // g_user are the arrays the optimizer aliases (:253-254 of the reference constructor); they are
+    // settled whenever the host looks (get_ptr, dzo_synchronize, dzo_memcpy_*, destroy).
     bool fused = true;               // DZO_TUNE_ADGD_FUSED=0 forces the generic kernel sequence
-    void *halo = nullptr;            // [2][rows][2 sides][x, g]: boundary vectors of the wave-rows
-    int halo_cur = 0;
-    bool halo_valid = false;         // the last fused pass left the boundary vectors of x_new / g_new
-    void *bak = nullptr, *xbak = nullptr, *gbak = nullptr;   // x_old / g_old for a rejected first trial
+    void *twin = nullptr, *x_twin = nullptr, *g_twin = nullptr;
+    void *x_user = nullptr, *g_user = nullptr;
+    bool unsettled = false;
+    int device = 0;
+    std::recursive_mutex mu;
     bool norms_ready = false;        // |delta_point|^2, |delta_gradient|^2 of the last step are in norm2[]
     double norm2[2] = {0, 0};
     int64_t fused_steps = 0, fused_rejections = 0;
@@ -27,49 +32,28 @@ namespace dzo {
 // ---------------------------------------------------------------------------------------------
 // Fused AdGD step for the built-in chained Rosenbrock objective.  Wave-rows of 62 owned 16-B vectors
 // plus one halo vector on each side (the 3-point stencil of the gradient needs x_new of both
-// neighbours); halo lanes take x_old / g_old from a boundary buffer, because x and g are updated in
-// place and the neighbouring row may already have moved on.  Per element:
+// neighbours; the halo lanes recompute it from x_old / g_old, which this pass only reads).  Per element:
 //   x_new = fma(-step, g_old, x_old)                 take_backtracking_step! :124 (first trial)
 //   objective terms of x_new, changed flag            :128, :138
 //   g_new = grad f(x_new)                             :307
 //   delta_point = x_new - x_old                       :145
 //   delta_gradient = g_new - g_old                    :306, :308
 //   partial sums of |delta_point|^2, |delta_gradient|^2   (:292, :294 of the next step)
-// 2 reads + 6 writes per element instead of the 16 element passes of the separate kernels.
+// 2 reads + 4 writes per element instead of the 16 element passes of the separate kernels.
 constexpr int kAdgdOwn = 62;
 
 template <typename T> struct AdgdFusedParams {
     int64_t n;
     T t;                                       // -step size
-    T *x, *g;
-    const T *halo;
-    T *halo_next;
-    T *xbak, *gbak, *dx, *dg;                  // RETRY: xbak / gbak are the SOURCE (x_old, g_old), x / g only written
+    const T *x, *g;                            // read only
+    T *x_out, *g_out, *dx, *dg;
     double *partials;                          // [3][gridDim.x]: objective, |dx|^2, |dg|^2
     int32_t *changed;
 };
 
+// One kernel for the first trial and for every later trial of the same step (:151-152): x and g still hold
+// x_old / g_old, whatever happened before.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void adgd_halo_snapshot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ g,
-                                                                    T *__restrict__ halo) {
-    constexpr int N = Vec16<T>::N;
-    const int64_t nvec = n / N;
-    const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
-    const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (id >= rows * 2) return;
-    const int64_t row = id >> 1;
-    const int64_t v = (id & 1) ? row * kAdgdOwn + kAdgdOwn : row * kAdgdOwn - 1;
-    if (v < 0 || v >= nvec) return;
-    T xv[N], gv[N];
-    load16(x + v * N, xv);
-    load16(g + v * N, gv);
-    store16(halo + id * 2 * N, xv);
-    store16(halo + id * 2 * N + N, gv);
-}
-
-// RETRY = a later trial of the same step (:151-152): x_old / g_old come from the backups the first pass
-// wrote, so nothing is read from the arrays being written and the halo lanes read their neighbours directly.
-template <typename T, bool RETRY>
 __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
     __shared__ double lds[kWaves];
@@ -88,14 +72,8 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
         const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);          // clamped: the value is never used
         const int64_t e0 = v * N;
         T xo[N], go[N];
-        if constexpr (RETRY) {
-            load16(p.xbak + vc * N, xo);
-            load16(p.gbak + vc * N, go);
-        } else {
-            const T *h = p.halo + ((row * 2 + (lane == 63 ? 1 : 0)) * 2) * N;
-            load16(halo_lane ? h : p.x + vc * N, xo);
-            load16(halo_lane ? h + N : p.g + vc * N, go);
-        }
+        load16(p.x + vc * N, xo);                                            // halo lanes read their neighbours directly
+        load16(p.g + vc * N, go);
         T xn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -119,23 +97,10 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
             }
         }
         if (owner) {
-            store16_nt(p.x + v * N, xn);
-            store16_nt(p.g + v * N, gn);
-            if constexpr (!RETRY) {
-                store16_nt(p.xbak + v * N, xo);
-                store16_nt(p.gbak + v * N, go);
-            }
+            store16_nt(p.x_out + v * N, xn);
+            store16_nt(p.g_out + v * N, gn);
             store16_nt(p.dx + v * N, sn);
             store16_nt(p.dg + v * N, yn);
-            // the first / last owned vector of a row is the right / left halo of its neighbour in the NEXT pass
-            if (lane == 1 && row > 0) {
-                T *hn = p.halo_next + (((row - 1) * 2 + 1) * 2) * N;
-                store16(hn, xn); store16(hn + N, gn);
-            }
-            if (lane == kAdgdOwn && row + 1 < rows) {
-                T *hn = p.halo_next + (((row + 1) * 2 + 0) * 2) * N;
-                store16(hn, xn); store16(hn + N, gn);
-            }
         }
     }
     block_raise_flag(diff, p.changed, &lds_flag);
@@ -178,9 +143,43 @@ __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__res
     }
 }
 
-// Eligibility of the one-pass step, INCLUDING its optional buffers (boundary vectors, x / g backups):
-// they are allocated here, before step! changes anything, and a failed allocation only switches the
-// optimizer to the generic kernel sequence (which needs no extra memory) instead of failing the step.
+static int32_t adgd_settle_entry(void *h);
+
+static void adgd_mark_unsettled(dzo_adgd_s *o) {
+    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user;
+    if (dirty && !o->unsettled) { unsettled_add(o, adgd_settle_entry); o->unsettled = true; }
+    if (!dirty && o->unsettled) { unsettled_remove(o); o->unsettled = false; }
+}
+
+// current_point / current_gradient back into the arrays the optimizer aliases
+static int32_t adgd_settle(dzo_adgd_s *o) {
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    OptCore &c = o->core;
+    const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
+    if (c.x != o->x_user) {
+        DZO_HIP(hipMemcpyAsync(o->x_user, c.x, bytes, hipMemcpyDeviceToDevice, c.stream));
+        o->x_twin = c.x; c.x = o->x_user;
+    }
+    if (c.g != o->g_user) {
+        DZO_HIP(hipMemcpyAsync(o->g_user, c.g, bytes, hipMemcpyDeviceToDevice, c.stream));
+        o->g_twin = c.g; c.g = o->g_user;
+    }
+    adgd_mark_unsettled(o);
+    return DZO_OK;
+}
+
+static int32_t adgd_settle_entry(void *h) {
+    dzo_adgd_s *o = static_cast<dzo_adgd_s *>(h);
+    DeviceScope scope(o->device);
+    DZO_TRY(adgd_settle(o));
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    return DZO_OK;
+}
+
+// Eligibility of the one-pass step, INCLUDING its buffers (the twins of x and g, the second
+// delta_gradient buffer): they are allocated here, before step! changes anything, and a failed
+// allocation only switches the optimizer to the generic kernel sequence (which needs no extra memory)
+// instead of failing the step.
 static bool adgd_fused_ok(dzo_adgd_s *o) {
     OptCore &c = o->core;
     if (!o->fused || c.objective || c.gradient || c.constraint || c.box_on || !c.problem) return false;
@@ -188,16 +187,12 @@ static bool adgd_fused_ok(dzo_adgd_s *o) {
     if (c.n % vecn != 0 || c.n < 4 * vecn) return false;
     if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg)) return false;
     const size_t es = dtype_size(c.dtype);
-    if (!o->halo) {
-        const int64_t rows = (c.n / vecn + kAdgdOwn - 1) / kAdgdOwn;
-        if (hipMalloc(&o->halo, 2 * (size_t)rows * 2 * 2 * 16) != hipSuccess) { (void)hipGetLastError(); o->halo = nullptr; o->fused = false; return false; }
-    }
-    if (!o->bak) {
+    if (!o->twin) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * es;
         const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;             // an odd number of KiB apart
-        if (hipMalloc(&o->bak, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->bak = nullptr; o->fused = false; return false; }
-        o->xbak = (char *)o->bak + 5 * 1024;
-        o->gbak = (char *)o->xbak + slot;
+        if (hipMalloc(&o->twin, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->twin = nullptr; o->fused = false; return false; }
+        o->x_twin = (char *)o->twin + 5 * 1024;
+        o->g_twin = (char *)o->x_twin + slot;
     }
     if (!o->dg_alt) {
         const size_t bytes = (size_t)((c.n + 63) / 64 * 64) * es;
@@ -206,9 +201,9 @@ static bool adgd_fused_ok(dzo_adgd_s *o) {
     return true;
 }
 
-// The whole step on fused passes: first trial in place; after a rejection the halving loop of
-// take_backtracking_step! (:121-152) re-runs the pass from the backups.  *done = false: not eligible
-// or nothing touched, the caller runs the generic sequence.
+// The whole step on fused passes: the first trial and, after a rejection, the halving loop of
+// take_backtracking_step! (:121-152) re-run the same pass with half the step (x and g are intact).
+// *done = false: not eligible or nothing touched, the caller runs the generic sequence.
 template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step, bool *done) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
@@ -216,17 +211,14 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     *done = false;
     const int64_t nvec = c.n / N;
     const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
-    const size_t halo_elems = (size_t)rows * 2 * 2 * N;
     AdgdFusedParams<T> fp;
     fp.n = c.n;
-    fp.x = (T *)c.x; fp.g = (T *)c.g; fp.xbak = (T *)o->xbak; fp.gbak = (T *)o->gbak;
+    fp.x = (const T *)c.x; fp.g = (const T *)c.g; fp.x_out = (T *)o->x_twin; fp.g_out = (T *)o->g_twin;
     // delta_gradient is written into the OTHER of two buffers and the pointers swap when the step is
     // accepted: a step that ends stuck leaves the previous step's delta_gradient untouched, as
     // take_backtracking_step! does (:128-130 returns before anything but delta_point was written)
     void *dg_new = (c.dg == o->dg_buf) ? o->dg_alt : o->dg_buf;
     fp.dx = (T *)c.dx; fp.dg = (T *)dg_new;
-    fp.halo = (const T *)o->halo + (size_t)o->halo_cur * halo_elems;
-    fp.halo_next = (T *)o->halo + (size_t)(o->halo_cur ^ 1) * halo_elems;
     fp.partials = c.partials();
     fp.changed = c.flag();
     int64_t blocks = (rows + kWaves - 1) / kWaves;
@@ -234,18 +226,8 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     const int grid = (int)(blocks < 1 ? 1 : blocks);
     if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
     c.flag_armed = false;
-    if (!o->halo_valid) {
-        DZO_TIMED("adgd_halo_snapshot", s);
-        const int hgrid = (int)((rows * 2 + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(adgd_halo_snapshot_kernel<T>, dim3(hgrid), dim3(kBlock), 0, s, c.n, (const T *)c.x, (const T *)c.g,
-                           (T *)o->halo + (size_t)o->halo_cur * halo_elems);
-    }
-    o->halo_valid = false;
-    auto restore = [&]() -> int32_t {                                        // :151 (and g, which the pass also replaced)
-        const size_t bytes = (size_t)c.n * sizeof(T);
-        DZO_HIP(hipMemcpyAsync(c.x, o->xbak, bytes, hipMemcpyDeviceToDevice, s));
-        DZO_HIP(hipMemcpyAsync(c.g, o->gbak, bytes, hipMemcpyDeviceToDevice, s));
-        DZO_HIP(hipMemcpyAsync(c.dx, o->xbak, bytes, hipMemcpyDeviceToDevice, s));   // :118 delta_point holds x_old when the search gives up
+    auto give_up = [&]() -> int32_t {                                        // :118 delta_point holds x_old when the search gives up
+        DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));
         return DZO_OK;
     };
     *done = true;
@@ -256,8 +238,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
         fp.t = (T)(-t);
         {
             DZO_TIMED(first ? "adgd_fused_step" : "adgd_fused_retry", s);
-            if (first) hipLaunchKernelGGL((adgd_fused_rosen_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, fp);
-            else hipLaunchKernelGGL((adgd_fused_rosen_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, fp);
+            hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
         }
         hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), c.f,
                            c.dtype == DZO_F32 ? 1 : 0, c.host_dev);
@@ -266,7 +247,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
         DZO_HIP(hipStreamSynchronize(s));
         const int32_t st = reinterpret_cast<const int32_t *>(c.host + 3)[0];
         if (st == 2) {                                                       // :128-130 (x_new == x_old bit for bit)
-            DZO_TRY(restore());
+            DZO_TRY(give_up());
             c.is_stuck = true;
             return DZO_OK;
         }
@@ -278,14 +259,16 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
             o->norm2[0] = c.host[5]; o->norm2[1] = c.host[6];
             o->norms_ready = true;
             c.dg = dg_new;                                                   // (the previous delta_gradient buffer is the next step's target)
-            o->halo_cur ^= 1; o->halo_valid = true;
+            std::swap(c.x, o->x_twin);                                       // the trial point and its gradient are the current ones now
+            std::swap(c.g, o->g_twin);
+            adgd_mark_unsettled(o);
             o->fused_steps += 1;
             if (!first) o->fused_rejections += 1;
             return DZO_OK;
         }
         t = round_to_dtype(c.dtype, t * 0.5);                                // :152
         if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
-            DZO_TRY(restore());
+            DZO_TRY(give_up());
             c.is_stuck = true;
             return DZO_OK;
         }
@@ -302,6 +285,7 @@ static int32_t norm_blocking(OptCore &c, const void *v, double *out) {
 static int32_t adgd_step(dzo_adgd_s *o) {
     OptCore &c = o->core;
     if (c.is_stuck) return DZO_OK;                                   // :276-278
+    std::lock_guard<std::recursive_mutex> step_lock(o->mu);
     DZO_REQUIRE(c.has_objective() && c.has_gradient(), DZO_ERR_STATE,
                 "step! needs objective and gradient (callbacks or a built-in problem)");
     if (c.problem && c.problem->parent) {
@@ -344,7 +328,6 @@ static int32_t adgd_step(dzo_adgd_s *o) {
             return DZO_OK;
         }
     }
-    o->halo_valid = false;
     DZO_TRY(core_backtracking_step(c, -next, c.g));                  // :301
     if (c.is_stuck) return DZO_OK;                                   // :302-304
     DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(dt), hipMemcpyDeviceToDevice, c.stream));  // :306
@@ -370,6 +353,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     dzo_adgd_s *o = new dzo_adgd_s();
     OptCore &c = o->core;
     c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
+    o->x_user = x_dev; o->g_user = g_dev; o->device = ctx().device;
     c.f = round_to_dtype(dtype, initial_objective_value);
     int32_t rc = core_alloc(c);
     if (rc != DZO_OK) { delete o; return rc; }
@@ -414,12 +398,13 @@ int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initi
 
 int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (!o) return DZO_OK;
+    if (o->core.stream && o->x_user) (void)adgd_settle(o);           // the caller's arrays end up holding the final point / gradient
+    unsettled_remove(o);
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->dx_buf) (void)hipFree(o->dx_buf);
     if (o->dg_buf) (void)hipFree(o->dg_buf);
     if (o->dg_alt) (void)hipFree(o->dg_alt);
-    if (o->halo) (void)hipFree(o->halo);
-    if (o->bak) (void)hipFree(o->bak);
+    if (o->twin) (void)hipFree(o->twin);
     core_free(o->core);
     delete o;
     return DZO_OK;
@@ -430,7 +415,6 @@ int32_t dzo_adgd_set_callbacks(dzo_adgd_t o, dzo_constraint_fn constraint, dzo_o
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     o->core.constraint = constraint; o->core.objective = objective; o->core.gradient = gradient;
     o->core.cb_ctx = cb_ctx;
-    o->halo_valid = false;
     return DZO_OK;
 }
 
@@ -466,9 +450,9 @@ int32_t dzo_adgd_get_s(dzo_adgd_t o, int32_t what, double *value) {
 
 int32_t dzo_adgd_get_ptr(dzo_adgd_t o, int32_t what, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DZO_TRY(adgd_settle(o));                                         // current_point / current_gradient ARE the caller's arrays again
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     // the caller may write through the pointer: do not trust what the fused step cached about it
-    if (what == 0 || what == 2) o->halo_valid = false;
     if (what == 1 || what == 3) o->norms_ready = false;
     switch (what) {
     case 0: *ptr_dev = o->core.x; break;

@@ -96,6 +96,10 @@ inline int stream_grid(int64_t n, int elems_per_thread) {
 // dzo_lbfgs.hip); every entry point through which the HOST is about to look at device memory
 // (dzo_synchronize, dzo_memcpy_*) first writes them back.  Cheap when nothing is pending.
 int32_t settle_all_optimizers();
+// registry behind it: a handle registers itself (with the function that settles it and removes it again)
+// while its live copy sits in a twin
+void unsettled_add(void *handle, int32_t (*settle)(void *handle));
+void unsettled_remove(void *handle);
 
 // ------------------------------------------------------------------------------ profiling
 // HIP-event pairs recorded on the launching stream around each kernel (bench roofline leg).

@@ -53,6 +53,36 @@ int32_t require_init() {
     return DZO_OK;
 }
 
+// ---------------------------------------------------------------------------- twin-buffer registry
+static std::mutex g_unsettled_mu;
+static std::vector<std::pair<void *, int32_t (*)(void *)>> g_unsettled;
+
+void unsettled_add(void *handle, int32_t (*settle)(void *)) {
+    std::lock_guard<std::mutex> lk(g_unsettled_mu);
+    for (auto &e : g_unsettled) if (e.first == handle) return;
+    g_unsettled.emplace_back(handle, settle);
+}
+
+void unsettled_remove(void *handle) {
+    std::lock_guard<std::mutex> lk(g_unsettled_mu);
+    for (size_t i = 0; i < g_unsettled.size(); ++i)
+        if (g_unsettled[i].first == handle) { g_unsettled.erase(g_unsettled.begin() + (long)i); return; }
+}
+
+int32_t settle_all_optimizers() {
+    for (int guard = 0; guard < 1 << 20; ++guard) {
+        std::pair<void *, int32_t (*)(void *)> e;
+        {
+            std::lock_guard<std::mutex> lk(g_unsettled_mu);
+            if (g_unsettled.empty()) return DZO_OK;
+            e = g_unsettled.back();
+        }
+        const int32_t rc = e.second(e.first);            // settles, waits for the copies, removes itself
+        if (rc != DZO_OK) { unsettled_remove(e.first); return rc; }
+    }
+    return DZO_OK;
+}
+
 // ---------------------------------------------------------------------------- profiling
 // HIP-event pairs around kernel launches, recorded on the launching stream.  Events come from
 // a pool (creating two events per launch cost ~7 % of a 1.3 ms step); level 1 times only the

@@ -66,6 +66,7 @@ struct dzo_lbfgs_s {
     double *link_partials = nullptr;        // [4][kMaxPartialBlocks] ping-pong + yy
     int gram_grid = 0;
     bool speculate = true;          // enqueue the accepted-step tail before the host sees the decision
+    unsigned int *gram_ticket = nullptr;   // (base of the scalar block)
     int gram_variant = 1;           // 1 = lane-distributed accumulators
     int gram_peel = 1;              // predicate-free path for full tiles
     int gram_fresh_plain = 1, gram_skip0 = 1, combine_fresh_plain = 1;
@@ -354,6 +355,135 @@ __device__ __forceinline__ void wave_sum5(const double (&t)[5], int lane, double
     tot[4] = readlane_f64(e, 3);
 }
 
+struct GramFinishParams {
+    int k;
+    int m1;                     // m + 1 (leading dimension of the slot-indexed Gram caches)
+    int pivot;                  // logical index of the pivot pair
+    int grid;                   // blocks of the Gram pass
+    int do_recurrence;
+    SlotMap map;
+    const double *partials;     // reduced values [kGramValues * k]
+    double *rho;                // by slot
+    int rho_from_vals;          // 1: rho[pivot] = s_p.y_p taken from the reduced values (single-pass step)
+    int rho_to_f32;
+    const int32_t *gate;        // speculative launch: run only if *gate == 1
+    double *Gyy, *Gsy;
+    double *sg, *yg;
+    double *alpha, *coef, *scale;
+};
+
+// Second stage of the Gram pass: one block per value sums that value's per-block partials in
+// a fixed order (value-major layout -> contiguous reads).
+// The last block (index nvals) optionally finishes the pending rho = delta_point.delta_gradient
+// of the pair pushed by the previous step (:505), saving that step a launch of its own.
+__global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
+                                                             double *__restrict__ vals, int nvals,
+                                                             const double *__restrict__ rho_partials, int rho_count,
+                                                             double *__restrict__ rho_dst, int rho_to_f32,
+                                                             const int32_t *__restrict__ gate = nullptr) {
+    __shared__ double lds[kWaves];
+    if (gate && *gate != 1) return;            // speculative launch: only after an accepted trial
+    if ((int)blockIdx.x == nvals) {
+        const double r = reduce_partials_all(rho_partials, rho_count, lds);
+        if (threadIdx.x == 0) rho_dst[0] = rho_to_f32 ? (double)(float)r : r;
+        return;
+    }
+    const double *src = partials + (int64_t)blockIdx.x * grid;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int b = threadIdx.x; b < grid; b += 4 * kBlock) {
+        a0 += src[b];
+        if (b + kBlock < grid) a1 += src[b + kBlock];
+        if (b + 2 * kBlock < grid) a2 += src[b + 2 * kBlock];
+        if (b + 3 * kBlock < grid) a3 += src[b + 3 * kBlock];
+    }
+    const double r = block_sum((a0 + a1) + (a2 + a3), lds);
+    if (threadIdx.x == 0) vals[blockIdx.x] = r;
+}
+
+// (1) refresh of the pivot row/column of the slot-indexed Gram caches from the reduced values,
+// (2) the two-loop recursion on SCALARS by one wave, lane i owning pair i:
+//     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
+//     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
+// One block.  vals: kGramValues*k reduced values already in LDS; yy / sy: k x (k+1) LDS scratch.
+__device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, double *vals, double *yy, double *sy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = p.k, ld = k + 1;
+    // logical k x k views of the caches (entries of non-pivot pairs were computed by the
+    // passes in which THEY were the pivot)
+    for (int e = threadIdx.x; e < k * k; e += kBlock) {
+        const int i = e / k, j = e % k;
+        yy[i * ld + j] = p.Gyy[p.map.slot[i] * p.m1 + p.map.slot[j]];
+        sy[i * ld + j] = p.Gsy[p.map.slot[i] * p.m1 + p.map.slot[j]];
+    }
+    __syncthreads();
+    const int pv = p.pivot, ps = p.map.slot[pv];
+    if (p.rho_from_vals && threadIdx.x == 0) {                     // :505 for the pair pushed by the single pass
+        const double r = vals[pv * kGramValues + 4];
+        p.rho[ps] = p.rho_to_f32 ? (double)(float)r : r;
+    }
+    if (threadIdx.x < k) {
+        const int i = threadIdx.x, si = p.map.slot[i];
+        const double *v = vals + i * kGramValues;
+        p.sg[i] = v[0];
+        p.yg[i] = v[1];
+        yy[i * ld + pv] = v[2]; yy[pv * ld + i] = v[2];
+        p.Gyy[si * p.m1 + ps] = v[2]; p.Gyy[ps * p.m1 + si] = v[2];
+        sy[pv * ld + i] = v[3];                 // s_p . y_i
+        p.Gsy[ps * p.m1 + si] = v[3];
+        sy[i * ld + pv] = v[4];                 // s_i . y_p
+        p.Gsy[si * p.m1 + ps] = v[4];
+    }
+    __syncthreads();
+    if (!p.do_recurrence || wave != 0) return;
+
+    const bool on = lane < k;
+    const double rho_i = on ? p.rho[p.map.slot[lane]] : 1.0;
+    double acc = on ? vals[lane * kGramValues + 0] : 0.0;          // s_i.g
+    double alpha_i = 0;
+    for (int j = 0; j < k; ++j) {                                  // :439 newest -> oldest
+        const double cand = acc / rho_i;                           // :440 (lane j's value counts)
+        const double aj = __shfl(cand, j, 64);
+        if (lane == j) alpha_i = cand;
+        if (on && lane > j) acc = __builtin_fma(-aj, sy[lane * ld + j], acc);
+    }
+    if (on) p.alpha[lane] = alpha_i;
+    const double scale = -p.rho[p.map.slot[0]] / yy[0];            // :444
+    if (lane == 0) p.scale[0] = scale;
+    // y_i.q_k with q_k = g - sum_j alpha_j y_j
+    double base = on ? vals[lane * kGramValues + 1] : 0.0;         // y_i.g
+    for (int j = 0; j < k; ++j) {
+        const double aj = __shfl(alpha_i, j, 64);
+        if (on) base = __builtin_fma(-aj, yy[lane * ld + j], base);
+    }
+    acc = scale * base;
+    double c_i = 0;
+    for (int l = k - 1; l >= 0; --l) {                             // :446 oldest -> newest
+        const double cand = alpha_i + acc / rho_i;                 // :447-448
+        const double cl = __shfl(cand, l, 64);
+        if (lane == l) c_i = cand;
+        if (on && lane < l) acc = __builtin_fma(-cl, sy[l * ld + lane], acc);
+    }
+    if (on) p.coef[lane] = c_i;
+}
+
+// bytes of dynamic LDS gram_finish_body needs: vals + yy + sy
+static inline size_t gram_finish_lds_bytes(int k) { return sizeof(double) * ((size_t)kGramValues * k + 2 * (size_t)k * (k + 1)); }
+
+// (Tried for config 4, n = 1e6, where the scalar stage's launches cost as much as a pass over the data:
+// this block summing the raw partials itself -- 25.5 us instead of 6.6 + 8.3 for the two kernels, one
+// block cannot pull 50 x 1000 values through one CU fast enough -- and a last-ticket epilogue inside the
+// Gram pass, which needs either cache-wide fences, 195 us per pass, or write-through stores and the same
+// single-block sum, 87 us.  The three-launch form stays.)
+__global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p) {
+    if (p.gate && *p.gate != 1) return;
+    extern __shared__ __attribute__((aligned(16))) double fin_lds[];
+    const int k = p.k;
+    double *vals = fin_lds, *yy = vals + kGramValues * k, *sy = yy + k * (k + 1);
+    for (int v = threadIdx.x; v < kGramValues * k; v += kBlock) vals[v] = p.partials[v];
+    __syncthreads();
+    gram_finish_body(p, vals, yy, sy);
+}
+
 // Gram pass, lane-distributed accumulators (the default).  All waves of all blocks walk the
 // pairs in the same order and read 16-B-per-lane contiguous chunks of ONE stream at a time --
 // the access pattern of combine_kernel, which HBM serves ~10 % faster than the pair-per-wave
@@ -509,121 +639,6 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             p.partials[(int64_t)(lane * kGramValues + c) * gridDim.x + blockIdx.x] = r;
         }
     }
-}
-
-struct GramFinishParams {
-    int k;
-    int m1;                     // m + 1 (leading dimension of the slot-indexed Gram caches)
-    int pivot;                  // logical index of the pivot pair
-    int grid;                   // blocks of the Gram pass
-    int do_recurrence;
-    SlotMap map;
-    const double *partials;     // reduced values [kGramValues * k]
-    double *rho;                // by slot
-    int rho_from_vals;          // 1: rho[pivot] = s_p.y_p taken from the reduced values (single-pass step)
-    int rho_to_f32;
-    const int32_t *gate;        // speculative launch: run only if *gate == 1
-    double *Gyy, *Gsy;
-    double *sg, *yg;
-    double *alpha, *coef, *scale;
-};
-
-// Second stage of the Gram pass: one block per value sums that value's per-block partials in
-// a fixed order (value-major layout -> contiguous reads).
-// The last block (index nvals) optionally finishes the pending rho = delta_point.delta_gradient
-// of the pair pushed by the previous step (:505), saving that step a launch of its own.
-__global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
-                                                             double *__restrict__ vals, int nvals,
-                                                             const double *__restrict__ rho_partials, int rho_count,
-                                                             double *__restrict__ rho_dst, int rho_to_f32,
-                                                             const int32_t *__restrict__ gate = nullptr) {
-    __shared__ double lds[kWaves];
-    if (gate && *gate != 1) return;            // speculative launch: only after an accepted trial
-    if ((int)blockIdx.x == nvals) {
-        const double r = reduce_partials_all(rho_partials, rho_count, lds);
-        if (threadIdx.x == 0) rho_dst[0] = rho_to_f32 ? (double)(float)r : r;
-        return;
-    }
-    const double *src = partials + (int64_t)blockIdx.x * grid;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int b = threadIdx.x; b < grid; b += 4 * kBlock) {
-        a0 += src[b];
-        if (b + kBlock < grid) a1 += src[b + kBlock];
-        if (b + 2 * kBlock < grid) a2 += src[b + 2 * kBlock];
-        if (b + 3 * kBlock < grid) a3 += src[b + 3 * kBlock];
-    }
-    const double r = block_sum((a0 + a1) + (a2 + a3), lds);
-    if (threadIdx.x == 0) vals[blockIdx.x] = r;
-}
-
-// One block.  (1) refresh of the pivot row/column of the slot-indexed Gram caches from the
-// reduced values, (2) the two-loop recursion on SCALARS by one wave, lane i owning pair i:
-//     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
-//     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
-__global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p) {
-    if (p.gate && *p.gate != 1) return;
-    __shared__ double vals[kGramValues * kMaxHistory];
-    __shared__ double yy[kMaxHistory][kMaxHistory + 1];
-    __shared__ double sy[kMaxHistory][kMaxHistory + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = p.k;
-    for (int v = threadIdx.x; v < kGramValues * k; v += kBlock) vals[v] = p.partials[v];
-    // logical k x k views of the caches (entries of non-pivot pairs were computed by the
-    // passes in which THEY were the pivot)
-    for (int e = threadIdx.x; e < k * k; e += kBlock) {
-        const int i = e / k, j = e % k;
-        yy[i][j] = p.Gyy[p.map.slot[i] * p.m1 + p.map.slot[j]];
-        sy[i][j] = p.Gsy[p.map.slot[i] * p.m1 + p.map.slot[j]];
-    }
-    __syncthreads();
-    const int pv = p.pivot, ps = p.map.slot[pv];
-    if (p.rho_from_vals && threadIdx.x == 0) {                     // :505 for the pair pushed by the single pass
-        const double r = vals[pv * kGramValues + 4];
-        p.rho[ps] = p.rho_to_f32 ? (double)(float)r : r;
-    }
-    if (threadIdx.x < k) {
-        const int i = threadIdx.x, si = p.map.slot[i];
-        const double *v = vals + i * kGramValues;
-        p.sg[i] = v[0];
-        p.yg[i] = v[1];
-        yy[i][pv] = v[2]; yy[pv][i] = v[2];
-        p.Gyy[si * p.m1 + ps] = v[2]; p.Gyy[ps * p.m1 + si] = v[2];
-        sy[pv][i] = v[3];                       // s_p . y_i
-        p.Gsy[ps * p.m1 + si] = v[3];
-        sy[i][pv] = v[4];                       // s_i . y_p
-        p.Gsy[si * p.m1 + ps] = v[4];
-    }
-    __syncthreads();
-    if (!p.do_recurrence || wave != 0) return;
-
-    const bool on = lane < k;
-    const double rho_i = on ? p.rho[p.map.slot[lane]] : 1.0;
-    double acc = on ? vals[lane * kGramValues + 0] : 0.0;          // s_i.g
-    double alpha_i = 0;
-    for (int j = 0; j < k; ++j) {                                  // :439 newest -> oldest
-        const double cand = acc / rho_i;                           // :440 (lane j's value counts)
-        const double aj = __shfl(cand, j, 64);
-        if (lane == j) alpha_i = cand;
-        if (on && lane > j) acc = __builtin_fma(-aj, sy[lane][j], acc);
-    }
-    if (on) p.alpha[lane] = alpha_i;
-    const double scale = -p.rho[p.map.slot[0]] / yy[0][0];         // :444
-    if (lane == 0) p.scale[0] = scale;
-    // y_i.q_k with q_k = g - sum_j alpha_j y_j
-    double base = on ? vals[lane * kGramValues + 1] : 0.0;         // y_i.g
-    for (int j = 0; j < k; ++j) {
-        const double aj = __shfl(alpha_i, j, 64);
-        if (on) base = __builtin_fma(-aj, yy[lane][j], base);
-    }
-    acc = scale * base;
-    double c_i = 0;
-    for (int l = k - 1; l >= 0; --l) {                             // :446 oldest -> newest
-        const double cand = alpha_i + acc / rho_i;                 // :447-448
-        const double cl = __shfl(cand, l, 64);
-        if (lane == l) c_i = cand;
-        if (on && lane < l) acc = __builtin_fma(-cl, sy[l][lane], acc);
-    }
-    if (on) p.coef[lane] = c_i;
 }
 
 template <typename T> struct CombineParams {
@@ -1120,9 +1135,8 @@ static int tune(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals, bool rho_from_vals = false,
-                                  const int32_t *gate = nullptr) {
-    hipStream_t s = o->core.stream;
+static GramFinishParams gram_finish_params(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals, bool rho_from_vals,
+                                           const int32_t *gate) {
     GramFinishParams fp;
     fp.gate = gate;
     fp.k = o->k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = 0; fp.do_recurrence = recurrence ? 1 : 0;
@@ -1131,9 +1145,16 @@ static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, co
     fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     if (gate) { fp.alpha = o->alpha_sp; fp.coef = o->coef_sp; fp.scale = o->scale_sp; }   // next step's set
+    return fp;
+}
+
+static int32_t gram_finish_launch(dzo_lbfgs_s *o, int pivot, bool recurrence, const double *vals, bool rho_from_vals = false,
+                                  const int32_t *gate = nullptr) {
+    hipStream_t s = o->core.stream;
+    const GramFinishParams fp = gram_finish_params(o, pivot, recurrence, vals, rho_from_vals, gate);
     {
         DZO_TIMED("lbfgs_gram_finish", s);
-        hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(kBlock), 0, s, fp);
+        hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(kBlock), gram_finish_lds_bytes(o->k), s, fp);
     }
     DZO_HIP(hipGetLastError());
     return DZO_OK;
@@ -1167,6 +1188,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         // grid = the blocks that are resident at once (occupancy x CUs): every block then walks
         // the same number of tiles (+-1) and there is no second, partially filled round of
         // blocks.  Measured at n = 1e7, k = 20: 494 us against 527 us with 8 blocks per CU.
+        double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
 #define GL(UU)                                                                                                  \
     do {                                                                                                        \
         auto kern = vec ? gram_pass_lanes_kernel<T, true, UU> : gram_pass_lanes_kernel<T, false, UU>;           \
@@ -1181,7 +1203,6 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         if (gu == 1) GL(1); else if (gu == 2) GL(2); else if (gu == 8) GL(8); else GL(4);
 #undef GL
         const int pcount = lgrid;
-        double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
         {
             DZO_TIMED("lbfgs_gram_reduce", s);
             const int nvals = kGramValues * k;
@@ -1579,23 +1600,18 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
 }
 
 // ---- aliasing of the caller's arrays (:393, :395) with twin buffers
-static std::mutex g_unsettled_mu;
-static std::vector<dzo_lbfgs_s *> g_unsettled;
+static int32_t lbfgs_settle_entry(void *h);
 
 static void lbfgs_mark_unsettled(dzo_lbfgs_s *o) {
     const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user;
-    std::lock_guard<std::mutex> lk(g_unsettled_mu);
-    if (dirty && !o->unsettled) { g_unsettled.push_back(o); o->unsettled = true; }
-    if (!dirty && o->unsettled) {
-        for (size_t i = 0; i < g_unsettled.size(); ++i)
-            if (g_unsettled[i] == o) { g_unsettled.erase(g_unsettled.begin() + (long)i); break; }
-        o->unsettled = false;
-    }
+    if (dirty && !o->unsettled) { unsettled_add(o, lbfgs_settle_entry); o->unsettled = true; }
+    if (!dirty && o->unsettled) { unsettled_remove(o); o->unsettled = false; }
 }
 
 // current_point / current_gradient back into the arrays the optimizer aliases (a device copy each, only
-// when they currently live in the twins).  Caller holds o->mu.
-static int32_t lbfgs_settle_locked(dzo_lbfgs_s *o) {
+// when they currently live in the twins)
+static int32_t lbfgs_settle(dzo_lbfgs_s *o) {
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
     const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
     if (c.x != o->x_user) {
@@ -1610,25 +1626,13 @@ static int32_t lbfgs_settle_locked(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
-static int32_t lbfgs_settle(dzo_lbfgs_s *o) {
-    std::lock_guard<std::recursive_mutex> lk(o->mu);
-    return lbfgs_settle_locked(o);
-}
-
-// every optimizer whose point lives in a twin (called by dzo_synchronize and dzo_memcpy_*: the host is
-// about to look at device memory)
-int32_t settle_all_optimizers() {
-    for (;;) {
-        dzo_lbfgs_s *o = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(g_unsettled_mu);
-            if (g_unsettled.empty()) return DZO_OK;
-            o = g_unsettled.back();
-        }
-        DeviceScope scope(o->device);
-        DZO_TRY(lbfgs_settle(o));
-        DZO_HIP(hipStreamSynchronize(o->core.stream));
-    }
+// called by dzo_synchronize / dzo_memcpy_* (the host is about to look at device memory)
+static int32_t lbfgs_settle_entry(void *h) {
+    dzo_lbfgs_s *o = static_cast<dzo_lbfgs_s *>(h);
+    DeviceScope scope(o->device);
+    DZO_TRY(lbfgs_settle(o));
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    return DZO_OK;
 }
 
 template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
@@ -1838,13 +1842,14 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         const int64_t tiles = (n / (16 / (int64_t)es) + tile_v - 1) / tile_v;
         if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
     }
-    const size_t nscal = (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
+    const size_t nscal = 2 + (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
                          (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1) + 4 * (size_t)kMaxPartialBlocks;
     double *base = nullptr;
     ALLOC(base, nscal * sizeof(double));
 #undef ALLOC
     (void)hipMemset(base, 0, nscal * sizeof(double));
     (void)hipDeviceSynchronize();
+    o->gram_ticket = reinterpret_cast<unsigned int *>(base); base += 2;   // (zeroed with the rest; re-armed by the kernel)
     o->rho = base; base += m1;
     o->alpha = base; base += kMaxHistory;
     o->coef = base; base += kMaxHistory;
@@ -1887,11 +1892,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
 int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (!o) return DZO_OK;
     if (o->core.stream && o->x_user) (void)lbfgs_settle(o);   // the caller's arrays end up holding the final point / gradient
-    {
-        std::lock_guard<std::mutex> lk(g_unsettled_mu);
-        for (size_t i = 0; i < g_unsettled.size(); ++i)
-            if (g_unsettled[i] == o) { g_unsettled.erase(g_unsettled.begin() + (long)i); break; }
-    }
+    unsettled_remove(o);
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->S) (void)hipFree(o->S);
     if (o->Y && !o->interleaved) (void)hipFree(o->Y);
@@ -1899,7 +1900,7 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (o->twin_slab) (void)hipFree(o->twin_slab);
     if (o->xt) (void)hipFree(o->xt);
     if (o->gt) (void)hipFree(o->gt);
-    if (o->rho) (void)hipFree(o->rho);
+    if (o->gram_ticket) (void)hipFree(o->gram_ticket);
     core_free(o->core);
     delete o;
     return DZO_OK;
@@ -1986,9 +1987,10 @@ int32_t dzo_lbfgs_step(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
-    DZO_TRY(lbfgs_direction(o));
-    DZO_HIP(hipStreamSynchronize(o->core.stream));
-    return DZO_OK;
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    // returns after the enqueue (include/dzo.h, asynchrony): step_direction is complete once a getter
+    // (dzo_lbfgs_get_ptr ...) or dzo_synchronize has returned, or for work enqueued on the handle's stream
+    return lbfgs_direction(o);
 }
 
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
