@@ -224,8 +224,7 @@ def cpu_baseline_secondary(workload, n, m=10, A=None):
             prob = orc.Problem(orc.ROSENBROCK_CHAIN, n)
             refs = [orc.BFGS(prob, pcg32_uniform(n, 1000 + b), 1.0) for b in range(threads * per + 1)]   # built before the clock starts
             def run(ref):
-                for _ in range(steps):
-                    ref.step()
+                ref.steps(steps)                                   # one C call: no interpreter lock between the threads
                 return ref.iteration_count
             orc.set_threads(1)
             t0 = time.perf_counter(); it1 = run(refs[-1]); dt1 = time.perf_counter() - t0
@@ -386,7 +385,9 @@ def secondary_workload(args):
         inst_steps = sharding.sum_over_ranks(float(it1 - it0))
         tab = dzo.profile_table()
         kern = {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in tab.items()}
-        ach = 3 * n * n * 8 * (it1 - it0) / (1e-3 * tab["bfgs_batch_step"][1]) / 1e9 if "bfgs_batch_step" in tab else None
+        # the step kernel reads and writes the LOWER triangle of every H only: 1.5 n^2 T per BFGS instance-step
+        # (a gradient-descent step resets the triangle: 0.5 n^2 T; counted as a BFGS step here, an upper bound)
+        ach = 1.5 * n * n * 8 * (it1 - it0) / (1e-3 * tab["bfgs_batch_step"][1]) / 1e9 if "bfgs_batch_step" in tab else None
         out.update({"metric": "instance-step!() calls/sec, batched dense BFGS n=256 fp64 (config 5)",
                     "value": round(inst_steps / el, 1), "unit": "instance-step!() calls/s",
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
@@ -398,7 +399,7 @@ def secondary_workload(args):
                                "device": info["name"]},
                     "roofline": {"bound": "hbm", "kernel": "bfgs_batch_step", "achieved": None if ach is None else round(ach, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                                 "traffic": None, "note": "3 n^2 T per accepted BFGS instance-step; line searches included in the time"},
+                                 "traffic": None, "note": "1.5 n^2 T per accepted instance-step (lower triangle of H: read twice, written once); line searches included in the time"},
                     "kernels": kern})
     elif args.workload == "adgd":
         # AdGDOptimizer (src/DZOptimization.jl:179-312) on the headline objective

@@ -5,18 +5,24 @@
 // parallel", README.md:12).
 //
 // Per instance: vectors (x, g, d, ...) live in LDS for the duration of the launch; H (n x n,
-// column-major, 512 KiB at n = 256 fp64) streams from HBM / Infinity Cache.  A thread owns a
-// PAIR of rows (16-B loads, coalesced along each column) and walks the columns of one parity
-// (the two 128-thread halves of the workgroup take even / odd columns), so
-//     t_i      = sum_j H[i,j] * dg_j                         (the true gemv, no symmetry needed)
-//     H[i,j]  += delta*(d'_i d'_j) - (t_i d'_j + d'_i t_j)   (:882-884, reference order)
-//     dnext_i  = sum_j Hnew[i,j] * g_j                       (fused into the update pass)
-// need no cross-thread reduction; the two halves are combined through LDS in a fixed order.
-// Traffic per instance-step: 3*n^2 elements.
+// column-major, 512 KiB at n = 256 fp64) streams from HBM.  H is symmetric bit for bit (the update
+// expression :882-884 commutes in i and j), so the step kernel reads and writes its LOWER triangle only:
+// a thread owns a PAIR of rows (16-B accesses, coalesced along each column), the two 128-thread halves of
+// the workgroup take even / odd columns, and of column j a thread touches the rows >= j.  A symmetric
+// product u = H v is then a row part (thread-local) plus a column part (summed across the wave by a
+// transposed DPP butterfly, eight or four columns at a time):
+//     t        = H * dg                                      (:875)
+//     H[i,j]  += delta*(d'_i d'_j) - (t_i d'_j + d'_i t_j)   (:882-884, reference order; i >= j)
+//     dnext    = Hnew * g                                    (fused into the update pass, :958-960)
+// Traffic per BFGS instance-step: 1.5 n^2 elements (the reference's pass structure moves 4 n^2, SURVEY.md
+// 8(d) counts 3 n^2 for a full-storage implementation).  The upper triangle in memory is stale between
+// host accesses; dzo_bfgs_batch_get_ptr mirrors it before handing out H.  The two line searches of a step
+// run on one wave (see Inst below).
 //
 // The objective is the chained Rosenbrock function (n = 2 is exactly the README's 2-D
 // Rosenbrock); the search logic mirrors oracle/dzo_oracle_impl.h line for line.
 #include <cmath>
+#include <cstdlib>
 
 #include "dzo_common.h"
 
@@ -30,6 +36,7 @@ struct BatchState {
     double *f, *last_step_length;
     int32_t *last_step_type, *has_terminated;
     int64_t *iteration_count;
+    unsigned long long *stats;       // [0..7] dev: cycle sums per phase (DZO_TUNE_BATCH_DEBUG bit 2); [8..15] target of masked stores
 };
 
 __device__ __forceinline__ double bsum(double v, double *red) {
@@ -79,8 +86,18 @@ template <typename T> __device__ __forceinline__ T b_rosen_grad(int i, int n, T 
     return gi;
 }
 
+// The line searches of an instance run on ONE wave (lane-strided loops over the LDS vectors, sums and
+// votes across the wave by DPP / ballot): at n = 256 a thread of the workgroup would own a single
+// element, and every objective evaluation would be a handful of workgroup barriers and LDS round trips --
+// measured, that was 99 of the 222 us of a step.  The other three waves wait at one barrier per step.
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave execute in order; only the compiler must not move them across
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T> struct Inst {
-    int n;
+    int n, lane;
     T *x, *g, *d, *dg, *dx, *y, *yref, *tv;     // LDS vectors
     double *red;                                // LDS [4]
     int *flag;                                  // LDS
@@ -88,33 +105,28 @@ template <typename T> struct Inst {
 
     __device__ T objective(const T *p) {
         double acc = 0;
-        for (int i = threadIdx.x; i + 1 < n; i += kBlock) acc += b_rosen_term<T>(p[i], p[i + 1]);
+        for (int i = lane; i + 1 < n; i += 64) acc += b_rosen_term<T>(p[i], p[i + 1]);
         evals += 1;
-        return (T)bsum(acc, red);
-    }
-    __device__ void gradient(T *out, const T *p) {
-        for (int i = threadIdx.x; i < n; i += kBlock)
-            out[i] = b_rosen_grad<T>(i, n, i > 0 ? p[i - 1] : (T)0, p[i], i + 1 < n ? p[i + 1] : (T)0);
-        __syncthreads();
+        return (T)wave_sum_all_dpp(acc);
     }
     __device__ T norm(const T *p) {
         double acc = 0;
-        for (int i = threadIdx.x; i < n; i += kBlock) acc = __builtin_fma((double)p[i], (double)p[i], acc);
-        return t_sqrt<T>((T)bsum(acc, red));
+        for (int i = lane; i < n; i += 64) acc = __builtin_fma((double)p[i], (double)p[i], acc);
+        return t_sqrt<T>((T)wave_sum_all_dpp(acc));
     }
     // y = x - t*dir with the bracket flags (legacy :71-80)
     __device__ void point(const T *dir, T t, bool *changed, bool *nonzero) {
         bool ch = false, nz = false;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += kBlock) {
+        wave_lds_fence();
+        for (int i = lane; i < n; i += 64) {
             const T nw = dfma(-t, dir[i], x[i]);
             y[i] = nw;
             ch |= (x[i] != nw);
             nz |= (dir[i] != (T)0);
         }
-        __syncthreads();
-        if (changed) *changed = bany(ch, flag);
-        if (nonzero) *nonzero = bany(nz, flag);
+        wave_lds_fence();
+        if (changed) *changed = __any(ch) != 0;
+        if (nonzero) *nonzero = __any(nz) != 0;
     }
     __device__ T phi(const T *dir, T t) {
         point(dir, t, nullptr, nullptr);
@@ -122,13 +134,13 @@ template <typename T> struct Inst {
     }
     __device__ bool same(const T *a, const T *b) {
         bool df = false;
-        for (int i = threadIdx.x; i < n; i += kBlock) df |= !is_equal(a[i], b[i]);
-        return !bany(df, flag);
+        for (int i = lane; i < n; i += 64) df |= !is_equal(a[i], b[i]);
+        return __any(df) == 0;
     }
     __device__ void copy(T *dst, const T *src) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
-        __syncthreads();
+        wave_lds_fence();
+        for (int i = lane; i < n; i += 64) dst[i] = src[i];
+        wave_lds_fence();
     }
 
     // find_three_point_bracket (legacy :49-172) started at t0; see oracle bfgs_bracket
@@ -192,9 +204,16 @@ template <typename T> struct Inst {
     }
 };
 
+// block-wide gradient of the move phase (all threads; one element each at n = 256)
+template <typename T> __device__ __forceinline__ void block_gradient(int n, T *out, const T *p) {
+    for (int i = threadIdx.x; i < n; i += kBlock)
+        out[i] = b_rosen_grad<T>(i, n, i > 0 ? p[i - 1] : (T)0, p[i], i + 1 < n ? p[i + 1] : (T)0);
+    __syncthreads();
+}
+
 // RP = row pairs per thread: n <= 256*RP, n even
 template <typename T, int RP>
-__global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int steps) {
+__global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch_step_kernel(BatchState st, int steps, int debug) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = (int)st.n;
     const int64_t b = blockIdx.x;
@@ -203,13 +222,14 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int s
     T *lds = reinterpret_cast<T *>(smem);
     const int np = (n + 1) & ~1;
     Inst<T> in;
-    in.n = n;
+    in.n = n; in.lane = threadIdx.x & 63;
     in.x = lds; in.g = lds + np; in.d = lds + 2 * np; in.dg = lds + 3 * np; in.dx = lds + 4 * np;
     in.y = lds + 5 * np; in.yref = lds + 6 * np; in.tv = lds + 7 * np;
     T *gold = lds + 8 * np;                       // previous gradient (also the GD direction)
     double *part = reinterpret_cast<double *>(lds + 9 * np);   // [n] half-combine scratch
-    in.red = part + np;
-    in.flag = reinterpret_cast<int *>(in.red + 4);
+    double *wpart = part + np;                                  // [4 waves][n] column parts of the symmetric products
+    in.red = wpart + 4 * np;                                    // [16]: block sums use [0..3], the searches' results [8..13]
+    in.flag = reinterpret_cast<int *>(in.red + 16);
     in.evals = 0;
 
     T *gx = (T *)st.x + b * n, *gg = (T *)st.g + b * n, *gd = (T *)st.d + b * n;
@@ -225,12 +245,21 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int s
 
     const int half = threadIdx.x / kHalf, lane_h = threadIdx.x % kHalf;
 
+    double *res = in.red + 8;                                     // [6] results of wave 0's searches
     for (int s = 0; s < steps && !terminated; ++s) {
-        const T grad_norm = in.norm(in.g);                        // :921
-        T t_g, f_g, t_b, f_b;
-        in.search(in.g, f, last_len / grad_norm, t_g, f_g);       // :922-925
-        const T bfgs_norm = in.norm(in.d);                        // :928
-        in.search(in.d, f, last_len / bfgs_norm, t_b, f_b);       // :929-932
+        __syncthreads();                                          // the LDS vectors of the previous step are complete
+        long long tk0 = (debug & 2) ? clock64() : 0;
+        if (threadIdx.x < 64) {
+            const T gn = in.norm(in.g);                           // :921
+            T tg, fg, tb, fb;
+            in.search(in.g, f, last_len / gn, tg, fg);            // :922-925
+            const T bn = in.norm(in.d);                           // :928
+            in.search(in.d, f, last_len / bn, tb, fb);            // :929-932
+            if (threadIdx.x == 0) { res[0] = (double)gn; res[1] = (double)tg; res[2] = (double)fg; res[3] = (double)bn; res[4] = (double)tb; res[5] = (double)fb; }
+        }
+        __syncthreads();
+        const T grad_norm = (T)res[0], t_g = (T)res[1], f_g = (T)res[2], bfgs_norm = (T)res[3], t_b = (T)res[4], f_b = (T)res[5];
+        if ((debug & 2) && threadIdx.x == 0) { const long long tk = clock64(); atomicAdd(st.stats + 0, (unsigned long long)(tk - tk0)); tk0 = tk; }
         const bool take_bfgs = f_b < f && !(f_b > f_g);           // :934
         const bool take_grad = !take_bfgs && f_g < f;             // :962
         if (!take_bfgs && !take_grad) { terminated = true; break; }   // :989
@@ -251,40 +280,112 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int s
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += kBlock) { in.x[i] = in.y[i]; gold[i] = in.g[i]; }
         __syncthreads();
-        in.gradient(in.g, in.x);
+        block_gradient<T>(n, in.g, in.x);
         for (int i = threadIdx.x; i < n; i += kBlock) in.dg[i] = in.g[i] - gold[i];
         __syncthreads();
 
-        if (take_bfgs) {
-            // ---- t = H*dg (:875): own row pairs, columns of this half's parity
+        if ((debug & 2) && threadIdx.x == 0) { const long long tk = clock64(); atomicAdd(st.stats + 1, (unsigned long long)(tk - tk0)); tk0 = tk; }
+        if (take_bfgs && !(debug & 1)) {
+            // H is symmetric bit for bit (the update expression :882-884 commutes in i, j), so only its LOWER
+            // triangle (row >= column) is read and written here: 1.5 n^2 T per step instead of 3 n^2 T.  A
+            // thread owns row pairs and walks the columns of its half's parity; of column j it touches the
+            // rows >= j only.  A symmetric product u = H v then has two parts:
+            //   row part   u_i += H[i,j] v_j   (j <= i)   thread-local, as before
+            //   col part   u_j += H[i,j] v_i   (i >  j)   a sum over the threads of the wave -> wpart[wave][j]
+            // The upper triangle of the stored matrix is stale until somebody asks for H (dzo_bfgs_batch_get_ptr
+            // mirrors it first).
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            auto load2 = [&](const T *p, T (&hv)[2]) {
+                if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+                else { const float2 q = *reinterpret_cast<const float2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+            };
+            auto store2 = [&](T *p, const T (&hv)[2]) {
+                if constexpr (sizeof(T) == 8) { double2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<double2 *>(p) = q; }
+                else { float2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<float2 *>(p) = q; }
+            };
+            // combine the two halves' row parts and the waves' column parts: u_i, fixed order
+            auto finish_symmetric = [&](double (&acc)[RP][2], T *out) {
+                if (half == 1) {
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { part[row] = acc[r][0]; part[row + 1] = acc[r][1]; } }
+                }
+                __syncthreads();
+                if (half == 0) {
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) {
+                        const int row = 2 * (lane_h + kHalf * r);
+                        if (row < n) {
+                            // column `row` is even -> half 0 = waves 0, 1; column row + 1 is odd -> waves 2, 3
+                            const double c0 = wpart[0 * np + row] + wpart[1 * np + row];
+                            const double c1 = wpart[2 * np + row + 1] + wpart[3 * np + row + 1];
+                            out[row] = (T)((acc[r][0] + part[row]) + c0);
+                            out[row + 1] = (T)((acc[r][1] + part[row + 1]) + c1);
+                        }
+                    }
+                }
+                __syncthreads();
+            };
+            // Columns are taken UJ at a time and software-pipelined two chunks deep: the loads of chunk c + 1
+            // are in flight while chunk c is computed, and the column parts of a chunk share one transposed
+            // butterfly (wave_sum8).  Every load is UNCONDITIONAL -- lanes outside the lower triangle read
+            // the first 16 bytes of H instead (a broadcast) and their values are zeroed -- because a load
+            // behind a branch makes the compiler wait for it at the join (vmcnt(0) per load: measured 6.6 us
+            // per chunk of eight columns, i.e. eight serial round trips).
+            constexpr int UJ = RP == 1 ? 4 : (RP == 2 ? 4 : 2);
+            const int my_cols = (n - half + 1) / 2;                // columns half, half + 2, ... < n
+            auto issue = [&](int c0, T (&hv)[UJ][RP][2]) {
+#pragma unroll
+                for (int u = 0; u < UJ; ++u) {
+                    const int j = half + 2 * (c0 + u);
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) {
+                        const int row = 2 * (lane_h + kHalf * r);
+                        const bool act = j < n && row < n && row + 1 >= j;
+                        load2(act ? H + (int64_t)j * n + row : H, hv[u][r]);
+                    }
+                }
+            };
+            // ---- t = H*dg (:875)
             double acc[RP][2];
 #pragma unroll
             for (int r = 0; r < RP; ++r) { acc[r][0] = 0; acc[r][1] = 0; }
-#pragma unroll 4
-            for (int j = half; j < n; j += 2) {
-                const double vj = (double)in.dg[j];
+            auto symv_chunk = [&](int c0, const T (&hv)[UJ][RP][2]) {
+                double col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int r = 0; r < RP; ++r) {
-                    const int row = 2 * (lane_h + kHalf * r);
-                    if (row < n) {
-                        T hv[2];
-                        if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(H + (int64_t)j * n + row); hv[0] = q.x; hv[1] = q.y; }
-                        else { const float2 q = *reinterpret_cast<const float2 *>(H + (int64_t)j * n + row); hv[0] = q.x; hv[1] = q.y; }
-                        acc[r][0] = __builtin_fma((double)hv[0], vj, acc[r][0]);
-                        acc[r][1] = __builtin_fma((double)hv[1], vj, acc[r][1]);
+                for (int u = 0; u < UJ; ++u) {
+                    const int j = half + 2 * (c0 + u);
+                    const double vj = j < n ? (double)in.dg[j] : 0.0;
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) {
+                        const int row = 2 * (lane_h + kHalf * r);
+                        const bool act = j < n && row < n && row + 1 >= j;   // the pair reaches the lower triangle of column j
+                        const double h0 = (act && row >= j) ? (double)hv[u][r][0] : 0.0;   // (row == j - 1: an upper element)
+                        const double h1 = act ? (double)hv[u][r][1] : 0.0;
+                        const int rc = row < n ? row : 0;
+                        acc[r][0] = __builtin_fma(h0, vj, acc[r][0]);
+                        acc[r][1] = __builtin_fma(h1, vj, acc[r][1]);
+                        const double m0 = row > j ? h0 : 0.0, m1 = row + 1 > j ? h1 : 0.0;   // strictly lower: the mirror part
+                        col[u] = __builtin_fma(m0, (double)in.dg[rc], col[u]);
+                        col[u] = __builtin_fma(m1, (double)in.dg[rc + 1], col[u]);
                     }
                 }
+                const double tot = wave_sum8(col, ln);
+                const int own = wave_sum8_owner(ln);
+                const int ju = half + 2 * (c0 + own);
+                if (ln < 8 && own < UJ && ju < n) wpart[wv * np + ju] = tot;
+            };
+            {
+                T hvA[UJ][RP][2], hvB[UJ][RP][2];
+                issue(0, hvA);
+                for (int c0 = 0; c0 < my_cols; c0 += 2 * UJ) {
+                    issue(c0 + UJ, hvB);
+                    symv_chunk(c0, hvA);
+                    issue(c0 + 2 * UJ, hvA);
+                    symv_chunk(c0 + UJ, hvB);
+                }
             }
-            if (half == 1) {
-#pragma unroll
-                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { part[row] = acc[r][0]; part[row + 1] = acc[r][1]; } }
-            }
-            __syncthreads();
-            if (half == 0) {
-#pragma unroll
-                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { in.tv[row] = (T)(acc[r][0] + part[row]); in.tv[row + 1] = (T)(acc[r][1] + part[row + 1]); } }
-            }
-            __syncthreads();
+            finish_symmetric(acc, in.tv);
+            if ((debug & 2) && threadIdx.x == 0) { const long long tk = clock64(); atomicAdd(st.stats + 2, (unsigned long long)(tk - tk0)); tk0 = tk; }
             // ---- scalars (:873-876) with lambda = -t_b (:954)
             double a = 0, c = 0;
             for (int i = threadIdx.x; i < n; i += kBlock) {
@@ -297,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int s
             const T delta = (-t_b) * overlap + dgt;              // :876
             for (int i = threadIdx.x; i < n; i += kBlock) in.d[i] = in.d[i] * inv;   // :874
             __syncthreads();
-            // ---- rank-2 update (:878-886) fused with dnext = Hnew*g (:958-960)
+            // ---- rank-2 update (:878-886) of the lower triangle fused with dnext = Hnew*g (:958-960)
             T di[RP][2], ti[RP][2];
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
@@ -307,42 +408,66 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(BatchState st, int s
                 ti[r][0] = ok ? in.tv[row] : (T)0; ti[r][1] = ok ? in.tv[row + 1] : (T)0;
                 acc[r][0] = 0; acc[r][1] = 0;
             }
-#pragma unroll 4
-            for (int j = half; j < n; j += 2) {
-                const T sj = in.d[j], tj = in.tv[j];             // :879-880
-                const double gj = (double)in.g[j];
+            T *dummy = reinterpret_cast<T *>(st.stats + 8) + 2 * (threadIdx.x & 1);   // 32 bytes nobody reads: target of the masked lanes' stores
+            auto update_chunk = [&](int c0, const T (&hv)[UJ][RP][2]) {
+                double col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int r = 0; r < RP; ++r) {
-                    const int row = 2 * (lane_h + kHalf * r);
-                    if (row < n) {
-                        T *p = H + (int64_t)j * n + row;
-                        T hv[2];
-                        if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(p); hv[0] = q.x; hv[1] = q.y; }
-                        else { const float2 q = *reinterpret_cast<const float2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+                for (int u = 0; u < UJ; ++u) {
+                    const int j = half + 2 * (c0 + u);
+                    const int jc = j < n ? j : 0;
+                    const T sj = in.d[jc], tj = in.tv[jc];         // :879-880
+                    const double gj = j < n ? (double)in.g[jc] : 0.0;
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            hv[q] = hv[q] + (delta * (di[r][q] * sj) - (ti[r][q] * sj + di[r][q] * tj));   // :882-884
-                            acc[r][q] = __builtin_fma((double)hv[q], gj, acc[r][q]);
-                        }
-                        if constexpr (sizeof(T) == 8) { double2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<double2 *>(p) = q; }
-                        else { float2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<float2 *>(p) = q; }
+                    for (int r = 0; r < RP; ++r) {
+                        const int row = 2 * (lane_h + kHalf * r);
+                        const bool act = j < n && row < n && row + 1 >= j;
+                        const bool lo0 = act && row >= j;          // (row == j - 1: an upper element, written back as it was)
+                        T nv[2];
+                        nv[0] = hv[u][r][0] + (delta * (di[r][0] * sj) - (ti[r][0] * sj + di[r][0] * tj));   // :882-884
+                        nv[1] = hv[u][r][1] + (delta * (di[r][1] * sj) - (ti[r][1] * sj + di[r][1] * tj));
+                        if (!lo0) nv[0] = hv[u][r][0];
+                        const double h0 = lo0 ? (double)nv[0] : 0.0, h1 = act ? (double)nv[1] : 0.0;
+                        const int rc = row < n ? row : 0;
+                        acc[r][0] = __builtin_fma(h0, gj, acc[r][0]);
+                        acc[r][1] = __builtin_fma(h1, gj, acc[r][1]);
+                        const double m0 = row > j ? h0 : 0.0, m1 = row + 1 > j ? h1 : 0.0;
+                        col[u] = __builtin_fma(m0, (double)in.g[rc], col[u]);
+                        col[u] = __builtin_fma(m1, (double)in.g[rc + 1], col[u]);
+                        store2(act ? H + (int64_t)j * n + row : dummy, nv);
                     }
+                }
+                const double tot = wave_sum8(col, ln);
+                const int own = wave_sum8_owner(ln);
+                const int ju = half + 2 * (c0 + own);
+                if (ln < 8 && own < UJ && ju < n) wpart[wv * np + ju] = tot;
+            };
+            {
+                T hvA[UJ][RP][2], hvB[UJ][RP][2];
+                issue(0, hvA);
+                for (int c0 = 0; c0 < my_cols; c0 += 2 * UJ) {
+                    issue(c0 + UJ, hvB);
+                    update_chunk(c0, hvA);
+                    issue(c0 + 2 * UJ, hvA);
+                    update_chunk(c0 + UJ, hvB);
                 }
             }
             __syncthreads();   // every read of the scaled d / t above is done before d is overwritten
-            if (half == 1) {
-#pragma unroll
-                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { part[row] = acc[r][0]; part[row + 1] = acc[r][1]; } }
-            }
-            __syncthreads();
-            if (half == 0) {
-#pragma unroll
-                for (int r = 0; r < RP; ++r) { const int row = 2 * (lane_h + kHalf * r); if (row < n) { in.d[row] = (T)(acc[r][0] + part[row]); in.d[row + 1] = (T)(acc[r][1] + part[row + 1]); } }
-            }
-            __syncthreads();
+            finish_symmetric(acc, in.d);
+            if ((debug & 2) && threadIdx.x == 0) { const long long tk = clock64(); atomicAdd(st.stats + 3, (unsigned long long)(tk - tk0)); atomicAdd(st.stats + 4, 1ull); tk0 = tk; }
         } else {
-            // :981-986  H = I, d = g
-            for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += kBlock) H[e] = (e / n == e % n) ? (T)1 : (T)0;
+            // :981-986  H = I, d = g.  Only the lower triangle is ever read again (see above): it alone is
+            // reset, with the same row-pair / column-parity ownership and 16-byte stores as the update pass.
+            for (int j = half; j < n; j += 2) {
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    const int row = 2 * (lane_h + kHalf * r);
+                    if (row < n && row + 1 >= j) {
+                        T *p = H + (int64_t)j * n + row;
+                        if constexpr (sizeof(T) == 8) { double2 q; q.x = row == j ? 1.0 : 0.0; q.y = row + 1 == j ? 1.0 : 0.0; *reinterpret_cast<double2 *>(p) = q; }
+                        else { float2 q; q.x = row == j ? 1.0f : 0.0f; q.y = row + 1 == j ? 1.0f : 0.0f; *reinterpret_cast<float2 *>(p) = q; }
+                    }
+                }
+            }
             for (int i = threadIdx.x; i < n; i += kBlock) in.d[i] = in.g[i];
             __syncthreads();
         }
@@ -384,6 +509,17 @@ __global__ __launch_bounds__(kBlock) void batch_init_kernel(BatchState st, doubl
     }
 }
 
+// upper triangle <- lower triangle (the step kernel maintains the lower one only); run before the host looks at H
+template <typename T>
+__global__ __launch_bounds__(kBlock) void batch_mirror_kernel(int64_t n, T *__restrict__ Hall) {
+    T *H = Hall + (int64_t)blockIdx.y * n * n;
+    const int64_t total = n * n;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+        const int64_t col = e / n, row = e % n;
+        if (row < col) H[e] = H[row * n + col];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void batch_count_active_kernel(const int32_t *__restrict__ term, int64_t batch,
                                                                     unsigned long long *__restrict__ out) {
     unsigned long long c = 0;
@@ -402,6 +538,7 @@ struct dzo_bfgs_batch_s {
     unsigned long long *count_host = nullptr;
     size_t lds_bytes = 0;
     int rp = 1;
+    bool upper_stale = false;           // steps ran since the upper triangles of H were last mirrored from the lower ones
 };
 
 using namespace dzo;
@@ -435,7 +572,7 @@ int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b) {
     DeviceScope scope(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->st.x, b->st.g, b->st.dx, b->st.dg, b->st.d, b->st.H, b->st.f, b->st.last_step_length,
-                    b->st.last_step_type, b->st.has_terminated, b->st.iteration_count, b->count_dev};
+                    b->st.last_step_type, b->st.has_terminated, b->st.iteration_count, b->count_dev, b->st.stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (b->count_host) (void)hipHostFree(b->count_host);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -460,7 +597,7 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
     b->rp = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
     const size_t es = dtype_size(dtype);
     const size_t np = (size_t)((n + 1) & ~(int64_t)1);
-    b->lds_bytes = 9 * np * es + (np + 4) * sizeof(double) + 16;
+    b->lds_bytes = 9 * np * es + (5 * np + 16) * sizeof(double) + 16;
     const size_t vb = (size_t)batch * (size_t)n * es;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
@@ -469,6 +606,7 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
     alloc((void **)&b->st.f, batch * sizeof(double)); alloc((void **)&b->st.last_step_length, batch * sizeof(double));
     alloc((void **)&b->st.last_step_type, batch * sizeof(int32_t)); alloc((void **)&b->st.has_terminated, batch * sizeof(int32_t));
     alloc((void **)&b->st.iteration_count, batch * sizeof(int64_t)); alloc((void **)&b->count_dev, sizeof(unsigned long long));
+    alloc((void **)&b->st.stats, 16 * sizeof(unsigned long long));   // [0..7] dev cycle counters, [8..15] dummy store target
     if (e != hipSuccess) {
         dzo_bfgs_batch_destroy(b);
         set_error("out of device memory for %lld instances of %lld x %lld", (long long)batch, (long long)n, (long long)n);
@@ -476,6 +614,7 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
     }
     DZO_HIP(hipHostMalloc((void **)&b->count_host, sizeof(unsigned long long), hipHostMallocDefault));
     DZO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    DZO_HIP(hipMemset(b->st.stats, 0, 16 * sizeof(unsigned long long)));
     DZO_HIP(hipMemcpy(b->st.x, x0_dev, vb, hipMemcpyDeviceToDevice));        // :769 copy
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     if (b->lds_bytes > 48 * 1024) {
@@ -524,9 +663,10 @@ int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done
     DZO_REQUIRE(steps >= 0, DZO_ERR_INVALID, "negative step count");
     DeviceScope scope(b->device);
     if (steps > 0) {
+        b->upper_stale = true;
         DZO_TIMED("bfgs_batch_step", b->stream);
         const dim3 grid((unsigned)b->st.batch), block(kBlock);
-#define L(TT, R) hipLaunchKernelGGL((batch_step_kernel<TT, R>), grid, block, b->lds_bytes, b->stream, b->st, (int)steps)
+#define L(TT, R) hipLaunchKernelGGL((batch_step_kernel<TT, R>), grid, block, b->lds_bytes, b->stream, b->st, (int)steps, getenv("DZO_TUNE_BATCH_DEBUG") ? atoi(getenv("DZO_TUNE_BATCH_DEBUG")) : 0)
         if (b->dtype == DZO_F64) { if (b->rp == 1) L(double, 1); else if (b->rp == 2) L(double, 2); else L(double, 4); }
         else { if (b->rp == 1) L(float, 1); else if (b->rp == 2) L(float, 2); else L(float, 4); }
 #undef L
@@ -543,6 +683,15 @@ int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done
 int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev) {
     DZO_REQUIRE(b && ptr_dev, DZO_ERR_INVALID, "null argument");
     DeviceScope scope(b->device);
+    if (what == 2 && b->upper_stale) {                   // the step kernel keeps the lower triangle of every H only
+        const int64_t n = b->st.n;
+        int gx = (int)((n * n + kBlock - 1) / kBlock);
+        if (gx > 64) gx = 64;
+        DZO_DISPATCH(b->dtype, hipLaunchKernelGGL(batch_mirror_kernel<T>, dim3((unsigned)gx, (unsigned)b->st.batch), dim3(kBlock), 0, b->stream,
+                                                  n, (T *)b->st.H));
+        DZO_HIP(hipGetLastError());
+        b->upper_stale = false;
+    }
     DZO_HIP(hipStreamSynchronize(b->stream));
     switch (what) {
     case 0: *ptr_dev = b->st.x; break;
@@ -556,6 +705,7 @@ int32_t dzo_bfgs_batch_get_ptr(dzo_bfgs_batch_t b, int32_t what, void **ptr_dev)
     case 8: *ptr_dev = b->st.d; break;
     case 9: *ptr_dev = b->st.last_step_length; break;
     case 10: *ptr_dev = b->st.last_step_type; break;
+    case 99: *ptr_dev = b->st.stats; break;             // dev only
     default: set_error("dzo_bfgs_batch_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;

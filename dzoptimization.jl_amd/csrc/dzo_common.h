@@ -187,6 +187,81 @@ __device__ __forceinline__ double wave_sum_all(double v) {
     return v;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-wide sums of FIVE values with 9 cross-lane exchanges instead of 5 x 6: a transposed
+// ("reduce-scatter") butterfly -- at the first three steps a lane keeps only part of the values
+// and ships the rest to its partner, so that afterwards every lane owns ONE value, which three
+// plain pairwise sums finish.  Totals come back through v_readlane (scalar).
+// No LDS anywhere: the exchanges are DPP moves (quad_perm for lane^1 and lane^2, row_ror:8 for
+// lane^8, two bank-masked row shifts for lane^4) and the gfx950 v_permlane16/32_swap for the
+// cross-row sums.  __shfl_xor compiles to ds_bpermute: six dependent LDS round trips per
+// butterfly, which a kernel running one wave per SIMD (the single-pass step) cannot hide.
+// Fixed association order -> deterministic.
+template <int CTRL, int BANK> __device__ __forceinline__ double dpp_f64(double old, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xF, BANK, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_xor1(double v) { return dpp_f64<0xB1, 0xF>(v, v); }    // quad_perm:[1,0,3,2]
+__device__ __forceinline__ double lane_xor2(double v) { return dpp_f64<0x4E, 0xF>(v, v); }    // quad_perm:[2,3,0,1]
+__device__ __forceinline__ double lane_xor8(double v) { return dpp_f64<0x128, 0xF>(v, v); }   // row_ror:8
+__device__ __forceinline__ double lane_xor4(double v) {
+    const double up = dpp_f64<0x104, 0x5>(v, v);        // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
+    return dpp_f64<0x114, 0xA>(up, v);                  // row_shr:4 into banks 1, 3
+}
+// v[l] + v[l ^ 16] (resp. ^ 32) in every lane: the swap leaves {own, own} in one register and
+// {partner, partner} in the other
+__device__ __forceinline__ double sum_xor16(double v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u2 rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u2 rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
+}
+__device__ __forceinline__ double sum_xor32(double v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u2 rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const u2 rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
+}
+
+// wave64 sum in every lane without touching LDS (DPP + permlane swaps; fixed order)
+__device__ __forceinline__ double wave_sum_all_dpp(double v) {
+    v += lane_xor1(v);
+    v += lane_xor2(v);
+    v += lane_xor4(v);
+    v += lane_xor8(v);
+    v = sum_xor16(v);
+    return sum_xor32(v);
+}
+
+// Wave-wide sums of EIGHT values with 10 cross-lane exchanges instead of 8 x 6 (transposed butterfly,
+// like wave_sum5 in dzo_lbfgs.hip): three halving steps leave ONE value per lane, three plain steps
+// finish it.  Afterwards every lane holds the total of value  4*(lane & 1) + 2*((lane >> 1) & 1) +
+// ((lane >> 2) & 1).  Fixed association order -> deterministic.
+__device__ __forceinline__ double wave_sum8(const double (&t)[8], int lane) {
+    const bool A = (lane & 1) != 0, B = (lane & 2) != 0, C = (lane & 4) != 0;
+    double a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (A ? t[i + 4] : t[i]) + lane_xor1(A ? t[i] : t[i + 4]);
+    double b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = (B ? a[i + 2] : a[i]) + lane_xor2(B ? a[i] : a[i + 2]);
+    double e = (C ? b[1] : b[0]) + lane_xor4(C ? b[0] : b[1]);
+    e += lane_xor8(e);
+    e = sum_xor16(e);
+    return sum_xor32(e);
+}
+__device__ __forceinline__ int wave_sum8_owner(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
+
 // Block sum for kBlock threads; `lds` holds kWaves doubles.  Result valid in thread 0.
 __device__ __forceinline__ double block_sum(double v, double *lds) {
     v = wave_sum(v);

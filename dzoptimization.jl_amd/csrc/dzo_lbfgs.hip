@@ -279,52 +279,6 @@ template <typename T> struct GramParams {
     double *partials;           // [kGramValues * k][gridDim.x]
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src_lane);
-    hi = __builtin_amdgcn_readlane(hi, src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// Wave-wide sums of FIVE values with 9 cross-lane exchanges instead of 5 x 6: a transposed
-// ("reduce-scatter") butterfly -- at the first three steps a lane keeps only part of the values
-// and ships the rest to its partner, so that afterwards every lane owns ONE value, which three
-// plain pairwise sums finish.  Totals come back through v_readlane (scalar).
-// No LDS anywhere: the exchanges are DPP moves (quad_perm for lane^1 and lane^2, row_ror:8 for
-// lane^8, two bank-masked row shifts for lane^4) and the gfx950 v_permlane16/32_swap for the
-// cross-row sums.  __shfl_xor compiles to ds_bpermute: six dependent LDS round trips per
-// butterfly, which a kernel running one wave per SIMD (the single-pass step) cannot hide.
-// Fixed association order -> deterministic.
-template <int CTRL, int BANK> __device__ __forceinline__ double dpp_f64(double old, double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xF, BANK, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, BANK, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_xor1(double v) { return dpp_f64<0xB1, 0xF>(v, v); }    // quad_perm:[1,0,3,2]
-__device__ __forceinline__ double lane_xor2(double v) { return dpp_f64<0x4E, 0xF>(v, v); }    // quad_perm:[2,3,0,1]
-__device__ __forceinline__ double lane_xor8(double v) { return dpp_f64<0x128, 0xF>(v, v); }   // row_ror:8
-__device__ __forceinline__ double lane_xor4(double v) {
-    const double up = dpp_f64<0x104, 0x5>(v, v);        // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
-    return dpp_f64<0x114, 0xA>(up, v);                  // row_shr:4 into banks 1, 3
-}
-// v[l] + v[l ^ 16] (resp. ^ 32) in every lane: the swap leaves {own, own} in one register and
-// {partner, partner} in the other
-__device__ __forceinline__ double sum_xor16(double v) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const u2 rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const u2 rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
-}
-__device__ __forceinline__ double sum_xor32(double v) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const u2 rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const u2 rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
-}
-
 __device__ __forceinline__ void wave_sum5(const double (&t)[5], int lane, double (&tot)[5]) {
     const bool A = (lane & 1) != 0, B = (lane & 2) != 0, C = (lane & 8) != 0;
     // lane^1: lanes with A = 0 keep {t0,t1,t2}, lanes with A = 1 keep {t3,t4}

@@ -1127,6 +1127,11 @@ T *FN(orc_bfgs_get_v)(const FN(orc_bfgs) *o, int what) {
     return NULL;
 }
 void FN(orc_bfgs_set_max_increases)(FN(orc_bfgs) *o, int32_t v) { o->max_increases = v; }
+/* k step! calls in one call (the timing baseline runs one optimizer per host thread; a Python-level loop
+ * would hand the interpreter lock around between the threads at every step) */
+void FN(orc_bfgs_steps)(FN(orc_bfgs) *o, int32_t k) {
+    for (int32_t i = 0; i < k; ++i) FN(orc_bfgs_step)(o);
+}
 /* state installation for the per-step parity tests (every field of the reference's struct is public,
  * legacy/DZOptimization.jl:733-751; the vectors and H are written through orc_bfgs_get_v) */
 void FN(orc_bfgs_set_s)(FN(orc_bfgs) *o, int what, T v) {

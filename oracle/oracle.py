@@ -116,6 +116,7 @@ def _declare(L):
         f("orc_bfgs_create_problem", vp, [vp, vp, ct])
         f("orc_bfgs_destroy", None, [vp])
         f("orc_bfgs_step", None, [vp])
+        f("orc_bfgs_steps", None, [vp, i32])
         f("orc_bfgs_get_i", i64, [vp, C.c_int])
         f("orc_bfgs_get_s", ct, [vp, C.c_int])
         f("orc_bfgs_get_v", vp, [vp, C.c_int])
@@ -421,6 +422,11 @@ class BFGS:
 
     def step(self):
         getattr(lib(), "orc_bfgs_step" + self.suf)(self.h)
+        return self
+
+    def steps(self, k):
+        """k step! calls inside one C call (releases the interpreter lock for the whole run)."""
+        getattr(lib(), "orc_bfgs_steps" + self.suf)(self.h, int(k))
         return self
 
     def _i(self, w):
