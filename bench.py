@@ -218,24 +218,20 @@ def cpu_baseline_secondary(workload, n, m=10, A=None):
                     "single_thread": {"value": round(v1, 3), "cores": 1, "steps": 4},
                     "sample": f"oracle dense BFGS on the same quadratic, n={n}: 3 untimed steps, 10 timed on OpenMP x{threads}, 4 on one core"}
         if workload == "bfgs_batched":
-            # independent instances, one per host thread (the reference's "run multiple optimizers in parallel")
-            from concurrent.futures import ThreadPoolExecutor
-            steps, per = 12, 2
-            prob = orc.Problem(orc.ROSENBROCK_CHAIN, n)
-            refs = [orc.BFGS(prob, pcg32_uniform(n, 1000 + b), 1.0) for b in range(threads * per + 1)]   # built before the clock starts
-            def run(ref):
-                ref.steps(steps)                                   # one C call: no interpreter lock between the threads
-                return ref.iteration_count
-            orc.set_threads(1)
-            t0 = time.perf_counter(); it1 = run(refs[-1]); dt1 = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=threads) as ex:
-                its = list(ex.map(run, refs[:-1]))
-            dta = time.perf_counter() - t0
-            return {"value": round(sum(its) / dta, 2), "unit": "instance-step!() calls/s", "cores": threads, "kind": "port",
-                    "single_thread": {"value": round(it1 / dt1, 2), "cores": 1, "steps": steps},
+            # independent instances, one optimizer per host core (the reference's "run multiple optimizers in
+            # parallel"), in worker PROCESSES: must run before this process touches the GPU (a spawned child
+            # of a GPU-initialised process may not exec)
+            import multiprocessing as mp
+            steps, per = 60, 4
+            its1, dt1 = orc.bfgs_rate_worker((n, 1000, 1, steps))
+            with mp.get_context("spawn").Pool(threads) as pool:
+                pool.map(orc.bfgs_rate_worker, [(8, 1, 1, 1)] * (4 * threads), chunksize=1)     # every worker process is up and imported
+                res = pool.map(orc.bfgs_rate_worker, [(n, 1001 + w * per, per, steps) for w in range(threads)], chunksize=1)
+            its, dta = sum(r[0] for r in res), max(r[1] for r in res)
+            return {"value": round(its / dta, 2), "unit": "instance-step!() calls/s", "cores": threads, "kind": "port",
+                    "single_thread": {"value": round(its1 / dt1, 2), "cores": 1, "steps": steps},
                     "sample": f"oracle dense BFGS, chained Rosenbrock n={n}: {threads * per} independent instances x {steps} steps, "
-                              f"one instance per host thread ({threads} threads); one instance alone for the single-core rate"}
+                              f"{per} per worker process ({threads} processes, timed inside the workers); one instance alone for the single-core rate"}
         if workload == "adgd":
             orc.set_threads(threads)
             ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n), orc.rosenbrock_chain_x0(n), 1.0)
@@ -275,6 +271,12 @@ def quadratic_matrix(n, r=8):
 def secondary_workload(args):
     """Configs 2, 4, 5 of BASELINE.json: same JSON shape, their own metric strings."""
     import importlib
+    cpu_line = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        # first of all: the CPU baseline (worker processes for the batched one), while no GPU context exists yet
+        cn = {"bfgs_dense": 4096, "bfgs_batched": 256, "lbfgs_lse_f32": 1_000_000}.get(args.workload, args.n) if args.n == 10_000_000 else args.n
+        cpu_line = cpu_baseline_secondary(args.workload, cn, m=(10 if args.m == 20 else args.m),
+                                          A=quadratic_matrix(cn) if args.workload == "bfgs_dense" else None)
     import torch
     world, rank, local = _dist_setup(args.gpus)
     from dzo_loader import dzo
@@ -488,9 +490,8 @@ def secondary_workload(args):
                                  "note": "launch-latency-bound at this size: 4 launches move 168 MB"},
                     "kernels": kern})
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_secondary(args.workload, n, m=(10 if args.m == 20 else args.m),
-                                                         A=A if args.workload == "bfgs_dense" else None)
+        if cpu_line is not None:
+            out["cpu_baseline"] = cpu_line
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -195,6 +195,7 @@ ABI = {
     "dzo_bfgs_batch_step": [_vp, _i32, _P(_i32)], "dzo_bfgs_batch_get_ptr": [_vp, _i32, _P(_vp)],
     "dzo_bfgs_batch_count_active": [_vp, _P(_i64)],
     "dzo_bfgs_batch_create_on": [_i32, _i32, _i64, _i64, _i32, _vp, _dbl, _P(_vp)], "dzo_bfgs_batch_device": [_vp, _P(_i32)],
+    "dzo_bfgs_batch_create_problem": [_vp, _i64, _vp, _dbl, _i32, _P(_vp)], "dzo_bfgs_batch_set_max_increases": [_vp, _i32],
     "dzo_comm_unique_id": [_vp], "dzo_comm_init_rank": [_vp, _i32, _i32, _P(_vp)],
     "dzo_comm_init_all": [_P(_i32), _i32, _P(_vp)], "dzo_comm_destroy": [_vp],
     "dzo_comm_info": [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i64)],
@@ -888,7 +889,13 @@ class BatchedBFGS:
         self.dtype = x0.dtype
         self._x0 = x0
         h = C.c_void_p()
-        if device is None:
+        if isinstance(problem_kind, Problem):
+            # objective, shared matrix and decorators from a problem handle (dzo_bfgs_batch_create_problem)
+            self.problem = problem_kind
+            assert self.problem.n == self.n and self.problem.dtype == self.dtype
+            _check(lib().dzo_bfgs_batch_create_problem(self.problem.h, self.batch, x0.ptr, initial_step_length,
+                                                       -1 if device is None else int(device), C.byref(h)))
+        elif device is None:
             _check(lib().dzo_bfgs_batch_create(problem_kind, self.batch, self.n, _dt(self.dtype), x0.ptr,
                                                initial_step_length, C.byref(h)))
         else:
@@ -901,6 +908,10 @@ class BatchedBFGS:
         v = C.c_int32()
         _check(lib().dzo_bfgs_batch_device(self.h, C.byref(v)))
         return v.value
+
+    def set_max_increases(self, v):
+        """``QuadraticLineSearch.max_increases`` (legacy/DZOptimization.jl:181-188) of every instance."""
+        _check(lib().dzo_bfgs_batch_set_max_increases(self.h, int(v)))
 
     def step(self, steps=1, poll=True):
         """Runs ``steps`` step! calls on every live instance; returns all_done if ``poll``."""

@@ -25,12 +25,26 @@
 #include <cstdlib>
 
 #include "dzo_common.h"
+#include "dzo_problems.h"
 
 namespace dzo {
 
 constexpr int kHalf = kBlock / 2;
 
+// the objective of every instance: chained Rosenbrock (n = 2: the README's 2-D Rosenbrock) or the dense
+// quadratic 1/2 x'Ax with ONE symmetric A shared by all instances, plus the decorators of
+// legacy/DZOptimization.jl:219-296 and QuadraticLineSearch.max_increases (:181-188)
+struct BatchObjective {
+    int kind = DZO_PROBLEM_ROSENBROCK_CHAIN;
+    const void *A = nullptr;            // QUADRATIC: n x n column-major, device
+    double l2 = 0;                      // L2RegularizationWrapper / L2GradientWrapper lambda (:225-249); 0 = off
+    int bg_on = 0; double bg_lo = 0, bg_hi = 0;       // UniformBoxGradientWrapper (:275-296)
+    int cons_on = 0; double cons_lo = 0, cons_hi = 0; // UniformBoxConstraint (:258-272) as constraint_function!
+    int max_increases = 0;              // 0 = no cap (:138-151)
+};
+
 struct BatchState {
+    BatchObjective ob;
     int64_t batch, n;
     void *x, *g, *dx, *dg, *d, *H;
     double *f, *last_step_length;
@@ -96,7 +110,25 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+template <typename T> __device__ __forceinline__ T b_clamp(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// decorators applied to one gradient component (legacy :241-249 then :289-294), same expressions as
+// dzo_problems.hip / the oracle
+template <typename T> __device__ __forceinline__ T b_decorate_grad(const BatchObjective &ob, T gi, T xi) {
+    if (ob.l2 != 0.0) gi = dfma((T)ob.l2 + (T)ob.l2, xi, gi);                      // :247 g += (lambda + lambda) x
+    if (ob.bg_on && ((xi <= (T)ob.bg_lo && gi >= (T)0) || (xi >= (T)ob.bg_hi && gi <= (T)0))) gi = (T)0;
+    return gi;
+}
+
+// row i of A*p for the shared dense symmetric A (column-major: consecutive i are contiguous)
+template <typename T> __device__ __forceinline__ double b_quad_row(const T *A, int n, int i, const T *p) {
+    double col = 0;
+    for (int j = 0; j < n; ++j) col = __builtin_fma((double)A[(int64_t)j * n + i], (double)p[j], col);
+    return col;
+}
+
 template <typename T> struct Inst {
+    BatchObjective ob;
     int n, lane;
     T *x, *g, *d, *dg, *dx, *y, *yref, *tv;     // LDS vectors
     double *red;                                // LDS [4]
@@ -105,9 +137,21 @@ template <typename T> struct Inst {
 
     __device__ T objective(const T *p) {
         double acc = 0;
-        for (int i = lane; i + 1 < n; i += 64) acc += b_rosen_term<T>(p[i], p[i + 1]);
+        T f;
+        if (ob.kind == DZO_PROBLEM_QUADRATIC) {
+            for (int i = lane; i < n; i += 64) acc = __builtin_fma(b_quad_row<T>((const T *)ob.A, n, i, p), (double)p[i], acc);
+            f = (T)(0.5 * wave_sum_all_dpp(acc));
+        } else {
+            for (int i = lane; i + 1 < n; i += 64) acc += b_rosen_term<T>(p[i], p[i + 1]);
+            f = (T)wave_sum_all_dpp(acc);
+        }
+        if (ob.l2 != 0.0) {                                      // L2RegularizationWrapper (:231-232)
+            double ss = 0;
+            for (int i = lane; i < n; i += 64) ss = __builtin_fma((double)p[i], (double)p[i], ss);
+            f = f + (T)ob.l2 * (T)wave_sum_all_dpp(ss);
+        }
         evals += 1;
-        return (T)wave_sum_all_dpp(acc);
+        return f;
     }
     __device__ T norm(const T *p) {
         double acc = 0;
@@ -120,9 +164,9 @@ template <typename T> struct Inst {
         wave_lds_fence();
         for (int i = lane; i < n; i += 64) {
             const T nw = dfma(-t, dir[i], x[i]);
-            y[i] = nw;
-            ch |= (x[i] != nw);
+            ch |= (x[i] != nw);                                  // the flags look at the raw step (:71-80) ...
             nz |= (dir[i] != (T)0);
+            y[i] = ob.cons_on ? b_clamp<T>(nw, (T)ob.cons_lo, (T)ob.cons_hi) : nw;   // ... the objective at P(x - t dir) (:36)
         }
         wave_lds_fence();
         if (changed) *changed = __any(ch) != 0;
@@ -162,11 +206,13 @@ template <typename T> struct Inst {
         T fa = objective(y);                                     // :126
         if (small && same(x, y)) return;                         // :119-121
         if (fa <= f0) {                                          // :130
+            int increases = 0;
             copy(yref, y);                                       // :136
             for (;;) {                                           // :143-156
                 const T dbl = step + step;
                 const T fb = phi(dir, dbl);
-                if (!t_finite(fb) || fb > fa || same(y, yref)) { // :147-150 (max_increases = 0)
+                increases += 1;
+                if ((ob.max_increases > 0 && increases >= ob.max_increases) || !t_finite(fb) || fb > fa || same(y, yref)) {   // :147-150
                     x1 = step; f1 = fa; x2 = dbl; f2 = fb;
                     return;
                 }
@@ -204,10 +250,14 @@ template <typename T> struct Inst {
     }
 };
 
-// block-wide gradient of the move phase (all threads; one element each at n = 256)
-template <typename T> __device__ __forceinline__ void block_gradient(int n, T *out, const T *p) {
-    for (int i = threadIdx.x; i < n; i += kBlock)
-        out[i] = b_rosen_grad<T>(i, n, i > 0 ? p[i - 1] : (T)0, p[i], i + 1 < n ? p[i + 1] : (T)0);
+// block-wide gradient of the move phase (all threads; one element each at n = 256), decorators included
+template <typename T> __device__ __forceinline__ void block_gradient(const BatchObjective &ob, int n, T *out, const T *p) {
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        T gi;
+        if (ob.kind == DZO_PROBLEM_QUADRATIC) gi = (T)b_quad_row<T>((const T *)ob.A, n, i, p);
+        else gi = b_rosen_grad<T>(i, n, i > 0 ? p[i - 1] : (T)0, p[i], i + 1 < n ? p[i + 1] : (T)0);
+        out[i] = b_decorate_grad<T>(ob, gi, p[i]);
+    }
     __syncthreads();
 }
 
@@ -222,6 +272,7 @@ __global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch
     T *lds = reinterpret_cast<T *>(smem);
     const int np = (n + 1) & ~1;
     Inst<T> in;
+    in.ob = st.ob;
     in.n = n; in.lane = threadIdx.x & 63;
     in.x = lds; in.g = lds + np; in.d = lds + 2 * np; in.dg = lds + 3 * np; in.dx = lds + 4 * np;
     in.y = lds + 5 * np; in.yref = lds + 6 * np; in.tv = lds + 7 * np;
@@ -273,14 +324,15 @@ __global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += kBlock) {
             const T xo = in.x[i];
-            const T xn = dfma(-tt, dir[i], xo);
+            T xn = dfma(-tt, dir[i], xo);
+            if (st.ob.cons_on) xn = b_clamp<T>(xn, (T)st.ob.cons_lo, (T)st.ob.cons_hi);   // :946 constraint_function!(point)
             in.y[i] = xn;
             in.dx[i] = xn - xo;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += kBlock) { in.x[i] = in.y[i]; gold[i] = in.g[i]; }
         __syncthreads();
-        block_gradient<T>(n, in.g, in.x);
+        block_gradient<T>(st.ob, n, in.g, in.x);
         for (int i = threadIdx.x; i < n; i += kBlock) in.dg[i] = in.g[i] - gold[i];
         __syncthreads();
 
@@ -483,20 +535,40 @@ __global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch
     }
 }
 
-// constructor per instance (:762-810): f0, g0, H0 = I, d0 = g
+// constructor per instance (:762-810): constraint on x0 (:770), f0, g0, H0 = I, d0 = g
 template <typename T>
 __global__ __launch_bounds__(kBlock) void batch_init_kernel(BatchState st, double initial_step_length) {
+    extern __shared__ __attribute__((aligned(16))) char init_smem[];
     __shared__ double red[4];
+    const BatchObjective ob = st.ob;
     const int n = (int)st.n;
     const int64_t b = blockIdx.x;
-    const T *x = (const T *)st.x + b * n;
+    T *x = (T *)st.x + b * n;
+    T *xs = reinterpret_cast<T *>(init_smem);                  // the (projected) starting point, shared
     T *g = (T *)st.g + b * n, *d = (T *)st.d + b * n, *dx = (T *)st.dx + b * n, *dg = (T *)st.dg + b * n;
     T *H = (T *)st.H + b * (int64_t)n * n;
-    double acc = 0;
-    for (int i = threadIdx.x; i + 1 < n; i += kBlock) acc += b_rosen_term<T>(x[i], x[i + 1]);
-    const double f = (double)(T)bsum(acc, red);
     for (int i = threadIdx.x; i < n; i += kBlock) {
-        const T gi = b_rosen_grad<T>(i, n, i > 0 ? x[i - 1] : (T)0, x[i], i + 1 < n ? x[i + 1] : (T)0);
+        T xi = x[i];
+        if (ob.cons_on) { xi = b_clamp<T>(xi, (T)ob.cons_lo, (T)ob.cons_hi); x[i] = xi; }   // :770
+        xs[i] = xi;
+    }
+    __syncthreads();
+    double acc = 0, ss = 0;
+    if (ob.kind == DZO_PROBLEM_QUADRATIC) {
+        for (int i = threadIdx.x; i < n; i += kBlock) acc = __builtin_fma(b_quad_row<T>((const T *)ob.A, n, i, xs), (double)xs[i], acc);
+    } else {
+        for (int i = threadIdx.x; i + 1 < n; i += kBlock) acc += b_rosen_term<T>(xs[i], xs[i + 1]);
+    }
+    for (int i = threadIdx.x; i < n; i += kBlock) ss = __builtin_fma((double)xs[i], (double)xs[i], ss);
+    T fT = ob.kind == DZO_PROBLEM_QUADRATIC ? (T)(0.5 * bsum(acc, red)) : (T)bsum(acc, red);
+    const double ssum = bsum(ss, red);
+    if (ob.l2 != 0.0) fT = fT + (T)ob.l2 * (T)ssum;
+    const double f = (double)fT;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        T gi;
+        if (ob.kind == DZO_PROBLEM_QUADRATIC) gi = (T)b_quad_row<T>((const T *)ob.A, n, i, xs);
+        else gi = b_rosen_grad<T>(i, n, i > 0 ? xs[i - 1] : (T)0, xs[i], i + 1 < n ? xs[i + 1] : (T)0);
+        gi = b_decorate_grad<T>(ob, gi, xs[i]);
         g[i] = gi; d[i] = gi; dx[i] = (T)0; dg[i] = (T)0;
     }
     for (int64_t e = threadIdx.x; e < (int64_t)n * n; e += kBlock) H[e] = (e / n == e % n) ? (T)1 : (T)0;
@@ -580,19 +652,23 @@ int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b) {
     return DZO_OK;
 }
 
-int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype, const void *x0_dev,
-                              double initial_step_length, dzo_bfgs_batch_t *out) {
+static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_t n, int32_t dtype, const void *x0_dev,
+                                 double initial_step_length, dzo_bfgs_batch_t *out) {
     DZO_TRY(require_init());
     DZO_REQUIRE(out && x0_dev, DZO_ERR_INVALID, "null argument");
     DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
-    DZO_REQUIRE(problem_kind == DZO_PROBLEM_ROSENBROCK_CHAIN || (problem_kind == DZO_PROBLEM_ROSENBROCK2D && n == 2),
-                DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective only");
+    const int32_t problem_kind = ob.kind;
+    DZO_REQUIRE(problem_kind == DZO_PROBLEM_ROSENBROCK_CHAIN || (problem_kind == DZO_PROBLEM_ROSENBROCK2D && n == 2) ||
+                    (problem_kind == DZO_PROBLEM_QUADRATIC && ob.A),
+                DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective and the dense quadratic with a shared A");
     DZO_REQUIRE(batch >= 1, DZO_ERR_INVALID, "batch must be >= 1");
     DZO_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024, DZO_ERR_UNSUPPORTED,
                 "batched mode needs an even n in 2..1024 (got %lld)", (long long)n);
     dzo_bfgs_batch_s *b = new dzo_bfgs_batch_s();
     b->dtype = dtype;
     b->device = ctx().device;
+    b->st.ob = ob;
+    if (b->st.ob.kind == DZO_PROBLEM_ROSENBROCK2D) b->st.ob.kind = DZO_PROBLEM_ROSENBROCK_CHAIN;   // n = 2: the same function
     b->st.batch = batch; b->st.n = n;
     b->rp = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
     const size_t es = dtype_size(dtype);
@@ -626,11 +702,55 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
     }
     {
         DZO_TIMED("bfgs_batch_init", b->stream);
-        DZO_DISPATCH(dtype, hipLaunchKernelGGL(batch_init_kernel<T>, dim3((unsigned)batch), dim3(kBlock), 0, b->stream, b->st, initial_step_length));
+        DZO_DISPATCH(dtype, hipLaunchKernelGGL(batch_init_kernel<T>, dim3((unsigned)batch), dim3(kBlock), np * es, b->stream, b->st, initial_step_length));
     }
     DZO_HIP(hipGetLastError());
     DZO_HIP(hipStreamSynchronize(b->stream));
     *out = b;
+    return DZO_OK;
+}
+
+int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype, const void *x0_dev,
+                              double initial_step_length, dzo_bfgs_batch_t *out) {
+    DZO_REQUIRE(problem_kind != DZO_PROBLEM_QUADRATIC, DZO_ERR_INVALID,
+                "the quadratic objective needs its matrix: use dzo_bfgs_batch_create_problem");
+    BatchObjective ob;
+    ob.kind = problem_kind;
+    return batch_create_impl(ob, batch, n, dtype, x0_dev, initial_step_length, out);
+}
+
+// The batched constructor from a problem handle: kind, n, dtype, the shared matrix A of the quadratic and
+// the decorators (dzo_problem_set_l2 / set_box_gradient / set_box_constraint) are taken from it at
+// creation time.  device < 0: the device the calling thread selected.
+int32_t dzo_bfgs_batch_create_problem(dzo_problem_t problem, int64_t batch, const void *x0_dev, double initial_step_length,
+                                      int32_t device, dzo_bfgs_batch_t *out) {
+    DZO_REQUIRE(problem && out, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(problem->kind != DZO_PROBLEM_LSE, DZO_ERR_UNSUPPORTED, "batched mode does not implement the log-sum-exp objective");
+    BatchObjective ob;
+    ob.kind = problem->kind; ob.A = problem->A;
+    ob.l2 = problem->l2;
+    ob.bg_on = problem->bg_on ? 1 : 0; ob.bg_lo = problem->bg_lo; ob.bg_hi = problem->bg_hi;
+    ob.cons_on = problem->cons_on ? 1 : 0; ob.cons_lo = problem->cons_lo; ob.cons_hi = problem->cons_hi;
+    if (device < 0) return batch_create_impl(ob, batch, problem->n, problem->dtype, x0_dev, initial_step_length, out);
+    int count = 0;
+    DZO_HIP(hipGetDeviceCount(&count));
+    DZO_REQUIRE(device < count && device < kMaxDevices, DZO_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+    const int prev = ctx().ready ? ctx().device : -1;
+    DZO_TRY(dzo_init(device));
+    int32_t rc;
+    {
+        DeviceScope scope(device);
+        rc = batch_create_impl(ob, batch, problem->n, problem->dtype, x0_dev, initial_step_length, out);
+    }
+    if (prev >= 0 && prev != device) (void)dzo_init(prev);
+    return rc;
+}
+
+// QuadraticLineSearch.max_increases (legacy :181-188, :138-151) of every instance; 0 = no cap
+int32_t dzo_bfgs_batch_set_max_increases(dzo_bfgs_batch_t b, int32_t max_increases) {
+    DZO_REQUIRE(b, DZO_ERR_INVALID, "null batch");
+    DZO_REQUIRE(max_increases >= 0, DZO_ERR_INVALID, "negative max_increases");
+    b->st.ob.max_increases = max_increases;
     return DZO_OK;
 }
 

@@ -892,11 +892,19 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const double sx = (double)sv[i][j], yx = (double)yv[i][j];
-                    t5[0] = __builtin_fma(sx, (double)gn[j], t5[0]);
-                    t5[1] = __builtin_fma(yx, (double)gn[j], t5[1]);
-                    t5[2] = __builtin_fma(yx, (double)yn[j], t5[2]);
-                    t5[3] = __builtin_fma(yx, (double)sn[j], t5[3]);
-                    t5[4] = __builtin_fma(sx, (double)yn[j], t5[4]);
+                    T gq = gn[j], yq = yn[j], sq = sn[j];
+                    if constexpr (sizeof(T) == 4) {
+                        // fp32: keep the compiler from holding fp64 copies of the new pair (12 doubles = 24
+                        // VGPRs) live across the K pairs -- with them the K = 20 instantiation spills, and a
+                        // scratch access in this loop costs far more than its bytes; the three
+                        // conversions per pair and element are re-done instead
+                        asm volatile("" : "+v"(gq), "+v"(yq), "+v"(sq));
+                    }
+                    t5[0] = __builtin_fma(sx, (double)gq, t5[0]);
+                    t5[1] = __builtin_fma(yx, (double)gq, t5[1]);
+                    t5[2] = __builtin_fma(yx, (double)yq, t5[2]);
+                    t5[3] = __builtin_fma(yx, (double)sq, t5[3]);
+                    t5[4] = __builtin_fma(sx, (double)yq, t5[4]);
                 }
                 double tot[kGramValues];
                 wave_sum5(t5, lane, tot);
@@ -1154,7 +1162,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         hipLaunchKernelGGL(kern, dim3(lgrid), dim3(kBlock), 0, s, gp);                                          \
     } while (0)
         int lgrid = 1;
-        if (gu == 1) GL(1); else if (gu == 2) GL(2); else if (gu == 8) GL(8); else GL(4);
+        if (gu == 1) GL(1); else if (gu == 2) GL(2); else GL(4);      // (8 vectors per lane spills: not offered)
 #undef GL
         const int pcount = lgrid;
         {

@@ -560,11 +560,14 @@ mutable struct BatchedBFGSOptimizer{T}
     handle::Ptr{Cvoid}
     batch::Int
     n::Int
-    function BatchedBFGSOptimizer(kind::Integer, x0::HipVector{T}, n::Integer, step::Real; device::Union{Nothing,Integer}=nothing) where {T}
+    function BatchedBFGSOptimizer(kind::Union{Integer,BuiltinProblem}, x0::HipVector{T}, n::Integer, step::Real; device::Union{Nothing,Integer}=nothing) where {T}
         ensure_init()
         h = Ref{Ptr{Cvoid}}(C_NULL)
         batch = div(length(x0), n)
-        if device === nothing
+        if kind isa BuiltinProblem      # objective, shared A of the quadratic and the decorators from the problem handle
+            check(ccall((:dzo_bfgs_batch_create_problem, libdzo), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cdouble, Cint, Ref{Ptr{Cvoid}}),
+                        kind.handle, batch, x0.ptr, step, device === nothing ? -1 : device, h))
+        elseif device === nothing
             check(ccall((:dzo_bfgs_batch_create, libdzo), Cint, (Cint, Int64, Int64, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}),
                         kind, batch, n, dtype_code(T), x0.ptr, step, h))
         else   # a shard on an explicit GPU (x0 must live there: `init(device); x0 = HipVector(...)`)
@@ -625,6 +628,9 @@ function allreduce_min(comm::ShardComm, local_flags::AbstractVector{<:Integer})
 end
 step!(b::BatchedBFGSOptimizer, steps::Integer=1) =
     (check(ccall((:dzo_bfgs_batch_step, libdzo), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}), b.handle, steps, C_NULL)); b)
+"""`set_max_increases!(b, k)`: `QuadraticLineSearch.max_increases` (legacy/DZOptimization.jl:181-188) of every instance."""
+set_max_increases!(b::BatchedBFGSOptimizer, k::Integer) =
+    (check(ccall((:dzo_bfgs_batch_set_max_increases, libdzo), Cint, (Ptr{Cvoid}, Cint), b.handle, k)); b)
 function count_active(b::BatchedBFGSOptimizer)
     v = Ref{Int64}(0)
     check(ccall((:dzo_bfgs_batch_count_active, libdzo), Cint, (Ptr{Cvoid}, Ref{Int64}), b.handle, v))

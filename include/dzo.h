@@ -385,12 +385,22 @@ int32_t dzo_gd_step(dzo_bfgs_t opt);
 /* ---------------------------------------------------------------------------------------
  * Batched dense BFGS: B independent BFGSOptimizer instances on one device, one workgroup per
  * instance, the whole step (both line searches included) on the device.  "run multiple
- * optimizers in parallel" (README.md:12); sharding across GPUs is one process per GPU with
- * the convergence flag all-reduced by the host over RCCL (DESIGN.md section e).
+ * optimizers in parallel" (README.md:12); instances shard over the GPUs of a node with no data-path
+ * collective, only the convergence flag is all-reduced (dzo_comm_* below).  The step kernel keeps
+ * the LOWER triangle of every inverse Hessian only (H is symmetric bit for bit); dzo_bfgs_batch_get_ptr
+ * mirrors it before handing out H.
  * ------------------------------------------------------------------------------------- */
 int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, int32_t dtype,
                               const void *x0_dev /* batch x n row-major */,
                               double initial_step_length, dzo_bfgs_batch_t *out);
+/* From a problem handle: chained Rosenbrock, or the dense quadratic 1/2 x'Ax with ONE matrix A shared by
+ * every instance; the decorators set on the handle (dzo_problem_set_l2 / set_box_gradient /
+ * set_box_constraint, legacy/DZOptimization.jl:219-296) are applied inside the step kernel.  device < 0:
+ * the device the calling thread selected (dzo_init). */
+int32_t dzo_bfgs_batch_create_problem(dzo_problem_t problem, int64_t batch, const void *x0_dev,
+                                      double initial_step_length, int32_t device, dzo_bfgs_batch_t *out);
+/* QuadraticLineSearch.max_increases (legacy/DZOptimization.jl:181-188, :138-151) of every instance; 0 = no cap */
+int32_t dzo_bfgs_batch_set_max_increases(dzo_bfgs_batch_t b, int32_t max_increases);
 int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b);
 /* runs `steps` synchronous step! calls on every live instance; *all_done = 1 when every
  * instance has_terminated.  Does not block unless all_done is non-NULL. */

@@ -520,6 +520,22 @@ class GradientDescent(BFGS):
     delta_objective_value = property(lambda s: getattr(lib(), "orc_gd_delta_f" + s.suf)(s.gd))
 
 
+def bfgs_rate_worker(args):
+    """(n, first_seed, instances, steps) -> (step! calls done, seconds): dense BFGS on chained Rosenbrock
+    instances, single-threaded; run in worker PROCESSES by bench.py's batched CPU baseline (one optimizer
+    per core, the reference's "run multiple optimizers in parallel")."""
+    import time
+    n, first_seed, instances, steps = args
+    set_threads(1)
+    prob = Problem(ROSENBROCK_CHAIN, n)
+    refs = [BFGS(prob, pcg_fill(n, first_seed + b), 1.0) for b in range(instances)]
+    t0 = time.perf_counter()
+    for r in refs:
+        r.steps(steps)
+    dt = time.perf_counter() - t0
+    return sum(r.iteration_count for r in refs), dt
+
+
 def bfgs_update(H, step_length, d, dg):
     """update_inverse_hessian! (legacy/DZOptimization.jl:864-889). H (F-order) and d are
     modified in place; returns the scratch vector t = H*dg."""

@@ -128,8 +128,9 @@ def test_streaming_kernels_keep_their_registers():
     """The single-pass step holds two sets of 2k history vectors in registers (502 of 512 VGPRs at
     k = 20, fp64).  A single spilled register costs far more than its own traffic: scratch loads
     share vmcnt with the global loads and retire in order, so waiting for one drains the next row's
-    prefetch.  Guard the fp64 instantiations (and the two-pass streaming kernels) against a
-    compiler or source change that tips them over."""
+    prefetch.  Guard every instantiation, fp32 included (its K = 20 form used to spill the fp64 copies
+    of the new pair), the two-pass streaming kernels and the batched step kernel against a compiler or
+    source change that tips them over."""
     import shutil
     import subprocess
     import tempfile
@@ -154,7 +155,7 @@ def test_streaming_kernels_keep_their_registers():
                 m = re.match(r"\s+\.(vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", line)
                 if m and name:
                     meta.setdefault(name, {})[m.group(1)] = int(m.group(2))
-    guarded = [n for n in meta if re.search(r"lbfgs_single_pass_kernelId|gram_pass_lanes_kernelId|combine_kernelId", n)]
-    assert len(guarded) >= 5, sorted(meta)[:20]
+    guarded = [n for n in meta if re.search(r"lbfgs_single_pass_kernelI[df]|gram_pass_lanes_kernelI[df]|combine_kernelI[df]|batch_step_kernelI[df]Li1", n)]
+    assert len(guarded) >= 12, sorted(meta)[:20]
     for n in guarded:
         assert meta[n].get("vgpr_spill_count", 0) == 0 and meta[n].get("private_segment_fixed_size", 0) == 0, (n, meta[n])

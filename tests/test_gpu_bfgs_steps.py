@@ -187,3 +187,65 @@ def test_each_batched_step_matches_per_instance_oracle_on_identical_state(n, B, 
             _check_step(one, refs[b], f_before[b], (n, it, b))
             types.add(refs[b].last_step_type)
     assert dzo.STEP_BFGS in types
+
+
+@pytest.mark.parametrize("case", ["quadratic", "rosen_l2", "rosen_box", "rosen_max_increases", "quadratic_all"])
+def test_batched_objectives_and_decorators_match_per_instance_oracle(case):
+    """Batched breadth: the dense quadratic with a shared A, the L2 / box-gradient / box-constraint
+    decorators (legacy/DZOptimization.jl:219-296) and QuadraticLineSearch.max_increases (:181-188),
+    each step from the oracle's state."""
+    n, B, steps = 64, 4, 14
+    kw, max_inc = {}, 0
+    if case.startswith("quadratic"):
+        A = orc.quadratic_matrix(n)
+        kind_o, kind_d, kw = orc.QUADRATIC, dzo.QUADRATIC, dict(A=A)
+        X0 = np.stack([orc.pcg_fill(n, 4 + b) - 0.5 for b in range(B)])
+    else:
+        kind_o, kind_d = orc.ROSENBROCK_CHAIN, dzo.ROSENBROCK_CHAIN
+        X0 = np.stack([orc.pcg_fill(n, 1000 + b) for b in range(B)])
+    if case == "rosen_l2":
+        kw.update(l2=0.05)
+    if case == "rosen_box":
+        kw.update(box_constraint=(0.05, 0.9), box_gradient=(0.05, 0.9))
+    if case == "quadratic_all":
+        kw.update(l2=0.01, box_constraint=(-0.4, 0.3), box_gradient=(-0.4, 0.3))
+    if case == "rosen_max_increases":
+        max_inc = 1
+    prob_d = dzo.Problem(kind_d, n, **kw)
+    batch = dzo.BatchedBFGS(prob_d, X0, 1.0)
+    refs = [orc.BFGS(orc.Problem(kind_o, n, **kw), X0[b].copy(), 1.0) for b in range(B)]
+    if max_inc:
+        batch.set_max_increases(max_inc)
+        for r in refs:
+            r.set_max_increases(max_inc)
+    for b in range(B):                                        # constructor: constraint on x0, f0, g0 with the decorators
+        assert np.array_equal(batch.current_point.to_host()[b], refs[b].current_point)
+        assert batch.current_objective_value.to_host()[b] == pytest.approx(refs[b].current_objective_value, rel=1e-12)
+        assert rel(batch.current_gradient.to_host()[b], refs[b].current_gradient) <= 1e-13
+    moved = 0
+    for it in range(steps):
+        st = [_oracle_state(r) for r in refs]
+        batch.install_state(x=np.stack([s["x"] for s in st]), g=np.stack([s["g"] for s in st]),
+                            H=np.stack([s["H"] for s in st]), d=np.stack([s["d"] for s in st]),
+                            f=[s["f"] for s in st], last_step_length=[s["last_step_length"] for s in st],
+                            iteration_count=[s["iteration_count"] for s in st],
+                            last_step_type=[s["last_step_type"] for s in st],
+                            has_terminated=[int(r.has_terminated) for r in refs],
+                            dx=np.stack([s["dx"] for s in st]), dg=np.stack([s["dg"] for s in st]))
+        f_before = [r.current_objective_value for r in refs]
+        batch.step(1, poll=False)
+        for r in refs:
+            r.step()
+        got = _batch_read(batch)
+        for b in range(B):
+            one = {k: (v[b] if isinstance(v, np.ndarray) else v) for k, v in got.items()}
+            one["has_terminated"] = bool(one["has_terminated"])
+            if np.linalg.norm(refs[b].current_gradient) <= 1e-13 * max(np.linalg.norm(st[b]["g"]), 1e-300):
+                continue                                      # converged to rounding level
+            _check_step(one, refs[b], f_before[b], (case, it, b))
+            moved += int(not refs[b].has_terminated)
+    assert moved >= steps                                     # the comparison really covered moving instances
+    if "box" in case or case == "quadratic_all":
+        lo, hi = kw["box_constraint"]
+        X = batch.current_point.to_host()
+        assert X.min() >= lo and X.max() <= hi
