@@ -359,6 +359,205 @@ void launch_bfgs_update(hipStream_t s, int64_t n, T *H, T lambda, T *d, const T 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Lower-triangle form of update_inverse_hessian! + the following mul! (step! path; even n with H of 128 MiB
+// or more by default).  H is symmetric bit for bit (the update expression :882-884 commutes in i and j), so the
+// step reads and writes its LOWER triangle only: 1.5 n^2 T per update instead of 3 n^2 T; the upper
+// triangle in memory is stale until somebody asks for H (dzo_bfgs_get_ptr mirrors it first).
+//
+// Tiling: a workgroup owns a panel of kTriPH rows x a window of kTriCW columns; a thread owns one row
+// pair (16-B accesses, coalesced down each column) and every second column of the window.  A symmetric
+// product u = H v splits into
+//     row part   u_i += H[i,j] v_j   (j <= i)   thread-local           -> rowpart[window][i]
+//     col part   u_j += H[i,j] v_i   (i >  j)   summed across the wave -> colpart[panel][j]
+// and a small second kernel adds, for every i, the windows left of the diagonal and the panels below it
+// in a fixed order.  Loads are unconditional (masked lanes read the first 16 bytes of H) and issued a
+// chunk of eight columns ahead -- see the batched kernel, dzo_batch.hip, for the reasons.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTriPH = 256;          // rows per panel  (= 2 * 128 row pairs)
+constexpr int kTriCW = 32;           // columns per window (16 per parity)
+constexpr int kTriUJ = 8;
+
+template <typename T> __device__ __forceinline__ void tri_load2(const T *p, T (&hv)[2]) {
+    if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+    else { const float2 q = *reinterpret_cast<const float2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+}
+template <typename T> __device__ __forceinline__ void tri_store2(T *p, const T (&hv)[2]) {
+    if constexpr (sizeof(T) == 8) { double2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<double2 *>(p) = q; }
+    else { float2 q; q.x = hv[0]; q.y = hv[1]; *reinterpret_cast<float2 *>(p) = q; }
+}
+
+// UPDATE = false: u = H v (v = delta_gradient, :875).  UPDATE = true: the rank-2 update of the triangle
+// (:878-886) and u = Hnew v (v = gradient, :958-960); `dp` is the UNSCALED direction, the scalars of
+// :873-876 are formed from the per-block partials the reduce kernel left behind.
+template <typename T, bool UPDATE>
+__global__ __launch_bounds__(kBlock) void tri_pass_kernel(int64_t n, T *__restrict__ H, const T *__restrict__ v,
+                                                          double *__restrict__ rowpart, double *__restrict__ colpart,
+                                                          const T *__restrict__ dp, const T *__restrict__ tvec,
+                                                          const double *__restrict__ part_ov, const double *__restrict__ part_vt,
+                                                          int nparts, T lambda, T *__restrict__ dummy) {
+    const int P = blockIdx.y, W = blockIdx.x;
+    if ((int64_t)W * kTriCW >= ((int64_t)P + 1) * kTriPH || (int64_t)W * kTriCW >= n) return;   // window right of the panel's diagonal
+    __shared__ double lds[kWaves];
+    __shared__ double wp[kWaves][kTriCW];
+    __shared__ double rp[kTriPH];
+    const int half = threadIdx.x / 128, lane_h = threadIdx.x % 128;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int64_t row = (int64_t)P * kTriPH + 2 * lane_h;
+    const int64_t c_first = (int64_t)W * kTriCW;
+    T delta = (T)0, inv = (T)1;
+    T di[2] = {(T)0, (T)0}, ti[2] = {(T)0, (T)0};
+    if constexpr (UPDATE) {
+        const T overlap = (T)reduce_partials_all(part_ov, nparts, lds);     // :873
+        const T dgt = (T)reduce_partials_all(part_vt, nparts, lds);
+        inv = (T)1 / overlap;                                               // :874
+        delta = lambda * overlap + dgt;                                     // :876
+        if (row < n) { di[0] = dp[row] * inv; di[1] = dp[row + 1] * inv; ti[0] = tvec[row]; ti[1] = tvec[row + 1]; }
+    }
+    const double v0 = row < n ? (double)v[row] : 0.0, v1 = row < n ? (double)v[row + 1] : 0.0;
+    double acc[2] = {0, 0};
+    auto issue = [&](int c0, T (&hv)[kTriUJ][2]) {
+#pragma unroll
+        for (int u = 0; u < kTriUJ; ++u) {
+            const int64_t j = c_first + half + 2 * (c0 + u);
+            const bool act = c0 + u < kTriCW / 2 && j < n && row < n && row + 1 >= j;
+            tri_load2<T>(act ? H + j * n + row : H, hv[u]);
+        }
+    };
+    auto chunk = [&](int c0, const T (&hv)[kTriUJ][2]) {
+        double col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < kTriUJ; ++u) {
+            const int64_t j = c_first + half + 2 * (c0 + u);
+            const bool inw = c0 + u < kTriCW / 2 && j < n;
+            const bool act = inw && row < n && row + 1 >= j;
+            const bool lo0 = act && row >= j;                              // (row == j - 1: an upper element, left alone)
+            const int64_t jc = inw ? j : 0;
+            const double vj = inw ? (double)v[jc] : 0.0;
+            T nv[2] = {hv[u][0], hv[u][1]};
+            if constexpr (UPDATE) {
+                const T sj = dp[jc] * inv, tj = tvec[jc];                  // :879-880
+                nv[0] = nv[0] + (delta * (di[0] * sj) - (ti[0] * sj + di[0] * tj));   // :882-884
+                nv[1] = nv[1] + (delta * (di[1] * sj) - (ti[1] * sj + di[1] * tj));
+                if (!lo0) nv[0] = hv[u][0];
+                tri_store2<T>(act ? H + j * n + row : dummy, nv);
+            }
+            const double h0 = lo0 ? (double)nv[0] : 0.0, h1 = act ? (double)nv[1] : 0.0;
+            acc[0] = __builtin_fma(h0, vj, acc[0]);
+            acc[1] = __builtin_fma(h1, vj, acc[1]);
+            const double m0 = row > j ? h0 : 0.0, m1 = row + 1 > j ? h1 : 0.0;   // strictly lower: the mirror part
+            col[u] = __builtin_fma(m0, v0, col[u]);
+            col[u] = __builtin_fma(m1, v1, col[u]);
+        }
+        const double tot = wave_sum8(col, ln);
+        const int cw = 2 * (c0 + wave_sum8_owner(ln)) + half;             // column within the window
+        if (ln < 8 && cw < kTriCW) wp[wv][cw] = tot;
+    };
+    {
+        T hvA[kTriUJ][2], hvB[kTriUJ][2];
+        issue(0, hvA);
+        issue(kTriUJ, hvB);
+        chunk(0, hvA);
+        chunk(kTriUJ, hvB);
+    }
+    // row part: the two column parities of a row pair; column part: the two waves of a parity
+    if (half == 1) { rp[2 * lane_h] = acc[0]; rp[2 * lane_h + 1] = acc[1]; }
+    __syncthreads();
+    if (half == 0 && row < n) {
+        double *dst = rowpart + (int64_t)W * n + row;
+        dst[0] = acc[0] + rp[2 * lane_h];
+        dst[1] = acc[1] + rp[2 * lane_h + 1];
+    }
+    if (threadIdx.x < kTriCW) {
+        const int cw = threadIdx.x, hw = cw & 1;                          // parity hw lives in waves 2 hw, 2 hw + 1
+        const int64_t j = c_first + cw;
+        if (j < n) colpart[(int64_t)P * n + j] = wp[2 * hw][cw] + wp[2 * hw + 1][cw];
+    }
+}
+
+// u_i = sum of the windows left of (and on) the diagonal + the panels on and below it, fixed order.  A
+// block owns kTriRI consecutive i; its 256 threads are kTriRG groups that each take every kTriRG-th window
+// (and panel), combined through LDS in group order.  With `dvec` (the symv of update_inverse_hessian!) the
+// block also leaves the partial sums of overlap = d.v (:873) and v.u (:876) for the update pass's prologue.
+constexpr int kTriRI = 32, kTriRG = kBlock / kTriRI;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void tri_reduce_kernel(int64_t n, const double *__restrict__ rowpart,
+                                                            const double *__restrict__ colpart, T *__restrict__ out,
+                                                            const T *__restrict__ dvec, const T *__restrict__ v,
+                                                            double *__restrict__ part_ov, double *__restrict__ part_vt) {
+    __shared__ double grp[kTriRG][kTriRI];
+    __shared__ double pr[2][kTriRI];
+    const int li = threadIdx.x % kTriRI, gq = threadIdx.x / kTriRI;
+    const int64_t i = (int64_t)blockIdx.x * kTriRI + li;
+    const int64_t np = (n + kTriPH - 1) / kTriPH;
+    double a = 0;
+    if (i < n) {
+        for (int64_t w = gq; w <= i / kTriCW; w += kTriRG) a += rowpart[w * n + i];
+        for (int64_t p = i / kTriPH + gq; p < np; p += kTriRG) a += colpart[p * n + i];
+    }
+    grp[gq][li] = a;
+    __syncthreads();
+    if (gq == 0) {
+        double u = 0;
+#pragma unroll
+        for (int q = 0; q < kTriRG; ++q) u += grp[q][li];
+        const T ui = (T)u;
+        double pov = 0, pvt = 0;
+        if (i < n) {
+            out[i] = ui;
+            if (dvec) { pov = (double)dvec[i] * (double)v[i]; pvt = (double)v[i] * (double)ui; }
+        }
+        pr[0][li] = pov; pr[1][li] = pvt;
+    }
+    __syncthreads();
+    if (dvec && threadIdx.x < 2) {
+        double r = 0;
+        for (int q = 0; q < kTriRI; ++q) r += pr[threadIdx.x][q];
+        (threadIdx.x == 0 ? part_ov : part_vt)[blockIdx.x] = r;
+    }
+}
+
+// upper triangle <- lower triangle, before the host (or a full-storage kernel) looks at H
+template <typename T>
+__global__ __launch_bounds__(kBlock) void tri_mirror_kernel(int64_t n, T *__restrict__ H) {
+    const int64_t total = n * n;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+        const int64_t col = e / n, row = e % n;
+        if (row < col) H[e] = H[row * n + col];
+    }
+}
+
+// update_inverse_hessian!(H, lambda, d, dg, scratch) + d_next = Hnew g on the lower triangle: four launches.
+// part: 2 * ceil(n / kTriRI) doubles; rowpart: ceil(n / kTriCW) * n doubles; colpart: ceil(n / kTriPH) * n.
+template <typename T>
+void launch_bfgs_update_tri(hipStream_t s, int64_t n, T *H, T lambda, const T *d, const T *dg, T *scratch, const T *g,
+                            T *d_next, double *part, double *rowpart, double *colpart, T *dummy) {
+    const dim3 grid((unsigned)((n + kTriCW - 1) / kTriCW), (unsigned)((n + kTriPH - 1) / kTriPH));
+    const int rblocks = (int)((n + kTriRI - 1) / kTriRI);
+    double *part_ov = part, *part_vt = part + rblocks;
+    {
+        DZO_TIMED("bfgs_symv", s);
+        hipLaunchKernelGGL((tri_pass_kernel<T, false>), grid, dim3(kBlock), 0, s, n, H, dg, rowpart, colpart, (const T *)nullptr,
+                           (const T *)nullptr, (const double *)nullptr, (const double *)nullptr, 0, (T)0, dummy);
+    }
+    {
+        DZO_TIMED("bfgs_tri_reduce", s);
+        hipLaunchKernelGGL(tri_reduce_kernel<T>, dim3(rblocks), dim3(kBlock), 0, s, n, (const double *)rowpart, (const double *)colpart,
+                           scratch, d, dg, part_ov, part_vt);
+    }
+    {
+        DZO_TIMED("bfgs_update", s);
+        hipLaunchKernelGGL((tri_pass_kernel<T, true>), grid, dim3(kBlock), 0, s, n, H, g, rowpart, colpart, d, (const T *)scratch,
+                           (const double *)part_ov, (const double *)part_vt, rblocks, lambda, dummy);
+    }
+    {
+        DZO_TIMED("bfgs_tri_reduce", s);
+        hipLaunchKernelGGL(tri_reduce_kernel<T>, dim3(rblocks), dim3(kBlock), 0, s, n, (const double *)rowpart, (const double *)colpart,
+                           d_next, (const T *)nullptr, (const T *)nullptr, (double *)nullptr, (double *)nullptr);
+    }
+}
+
 }  // namespace dzo
 
 struct dzo_bfgs_s {
@@ -392,6 +591,10 @@ struct dzo_bfgs_s {
     double df = 0;                              // GradientDescentOptimizer.delta_objective_value (:313)
     int64_t evals = 0;
     double *upd_part = nullptr;                 // device: 2*ceil(n/4) partials of the fused update scalars
+    bool tri = false;                           // step! keeps the LOWER triangle of H only (launch_bfgs_update_tri)
+    bool upper_stale = false;                   // ... and the upper one has not been mirrored since the last update
+    double *tri_rowpart = nullptr, *tri_colpart = nullptr;
+    void *tri_dummy = nullptr;
     double *ws = nullptr;                       // device: partials + scalars + flags
     double *host = nullptr;                     // pinned
     double *host_dev = nullptr;                 // the same buffer as the device sees it
@@ -830,11 +1033,23 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
     return DZO_OK;
 }
 
+// make the stored matrix whole again (upper <- lower) before anything reads it as a full matrix
+static int32_t bfgs_mirror(dzo_bfgs_s *o) {
+    if (!o->upper_stale) return DZO_OK;
+    DZO_TIMED("bfgs_mirror", o->stream);
+    const int grid = stream_grid(o->n * o->n, 4);
+    DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(tri_mirror_kernel<T>, dim3(grid), dim3(kBlock), 0, o->stream, o->n, (T *)o->H));
+    DZO_HIP(hipGetLastError());
+    o->upper_stale = false;
+    return DZO_OK;
+}
+
 static int32_t bfgs_identity(dzo_bfgs_s *o) {
     DZO_TIMED("bfgs_identity", o->stream);
     const int grid = stream_grid(o->n * o->n, 4);
     DZO_DISPATCH(o->dtype, hipLaunchKernelGGL(identity_kernel<T>, dim3(grid), dim3(kBlock), 0, o->stream, o->n, (T *)o->H));
     DZO_HIP(hipGetLastError());
+    o->upper_stale = false;                                      // (both triangles written)
     return DZO_OK;
 }
 
@@ -898,7 +1113,12 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
         o->iteration_count += 1;                                 // :940
         DZO_TRY(bfgs_move(o, t_b, o->d, o->best_grad[1]));       // :943-950
         // :953-960 update_inverse_hessian!(H, -t_b, d, dg, scratch) fused with d = H*g
-        if (o->n >= 65535LL * kColsPerBlock) {
+        if (o->tri) {
+            DZO_DISPATCH(dt, launch_bfgs_update_tri<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (const T *)o->d, (const T *)o->dg,
+                                                       (T *)o->scratch, (const T *)o->g, (T *)o->d_alt, o->upd_part, o->tri_rowpart,
+                                                       o->tri_colpart, (T *)o->tri_dummy));
+            o->upper_stale = true;
+        } else if (o->n >= 65535LL * kColsPerBlock) {
             DZO_DISPATCH(dt, launch_bfgs_update<T>(o->stream, o->n, (T *)o->H, (T)(-t_b), (T *)o->d, (const T *)o->dg,
                                                    (T *)o->scratch, (const T *)o->g, (T *)o->d_alt, o->scalars()));
         } else {
@@ -941,8 +1161,26 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
             return DZO_ERR_NOMEM;
         }
     }
+    {
+        // default: from H = 128 MiB up (config 2: n = 4096 fp64).  Measured on MI355X: n = 4096 (H fits the
+        // Infinity Cache) update + direction 68 us against 78 us for the full-storage kernels, the step rate
+        // the same; n = 8192 (512 MiB, HBM) 196 us against 332 us, step! 1446 against 1218 per second.
+        // Below that size the two extra launches cost more than the halved traffic saves.
+        const char *e = getenv("DZO_TUNE_BFGS_TRI_MIN_N");
+        const bool big = e ? o->n >= atoll(e) : (size_t)o->n * (size_t)o->n * es >= (128u << 20);
+        o->tri = !o->no_hessian && o->n % 2 == 0 && big && o->n < 65535LL * kTriCW;
+        if (o->tri) {
+            const size_t nw = (size_t)((o->n + kTriCW - 1) / kTriCW), npn = (size_t)((o->n + kTriPH - 1) / kTriPH);
+            if (hipMalloc((void **)&o->tri_rowpart, nw * (size_t)o->n * sizeof(double)) != hipSuccess ||
+                hipMalloc((void **)&o->tri_colpart, npn * (size_t)o->n * sizeof(double)) != hipSuccess ||
+                hipMalloc(&o->tri_dummy, 64) != hipSuccess) {
+                (void)hipGetLastError();
+                o->tri = false;                                  // not enough memory for the partial sums: full-storage kernels
+            }
+        }
+    }
     DZO_HIP(hipMalloc(&o->grad_pool, 24 * vbytes));
-    DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));
+    DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));   // (>= 2 ceil(n / kTriRI) too)
     DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 48)));
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 48)));
     DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 32, hipHostMallocMapped | hipHostMallocCoherent));
@@ -973,6 +1211,7 @@ static int32_t cast_async(hipStream_t s, int64_t n, int32_t src_dtype, const voi
 // BFGSOptimizer(::Type{T}, objective, gradient!, constraint!, opt)  legacy/DZOptimization.jl:819-862:
 // re-types a running optimizer; `o` already carries the new dtype and the new callbacks/problem.
 static int32_t bfgs_convert(dzo_bfgs_s *src, dzo_bfgs_s *o) {
+    DZO_TRY(bfgs_mirror(src));
     DZO_HIP(hipStreamSynchronize(src->stream));
     DZO_TRY(bfgs_alloc(o));
     hipStream_t s = o->stream;
@@ -1138,7 +1377,7 @@ int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
     if (!o) return DZO_OK;
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     void *ptrs[] = {o->x, o->g, o->dx, o->dg, o->d, o->d_alt, o->scratch, o->ref_point, o->scratch2, o->ref_point2, o->spec_buf[0], o->spec_buf[1], o->spec_buf[2],
-                    o->spec_buf[3], o->grad_pool, o->H, o->ws, o->upd_part};
+                    o->spec_buf[3], o->grad_pool, o->H, o->ws, o->upd_part, o->tri_rowpart, o->tri_colpart, o->tri_dummy};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
     problem_view_destroy(o->problem);
@@ -1333,6 +1572,7 @@ int32_t dzo_bfgs_set_i(dzo_bfgs_t o, int32_t what, int64_t value) {
 
 int32_t dzo_bfgs_get_ptr(dzo_bfgs_t o, int32_t what, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    if (what == 5) DZO_TRY(bfgs_mirror(o));                  // step! keeps the lower triangle only
     DZO_HIP(hipStreamSynchronize(o->stream));
     switch (what) {
     case 0: *ptr_dev = o->x; break;

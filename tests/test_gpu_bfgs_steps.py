@@ -97,6 +97,37 @@ def test_each_bfgs_step_matches_oracle_on_identical_state_quadratic(n, steps):
         orc.set_threads(1)
 
 
+@pytest.mark.parametrize("n,steps", [(2, 20), (16, 30), (200, 30), (514, 20), (1026, 8)])
+def test_lower_triangle_update_path_matches_oracle_per_step(n, steps, monkeypatch):
+    """The step!'s lower-triangle form of update_inverse_hessian! + mul! (default for even n >= 1024, forced
+    here at small and ragged sizes: n = 514 is two panels and a 17th window with two columns) from the
+    oracle's state each step; the matrix handed out is whole and exactly symmetric."""
+    monkeypatch.setenv("DZO_TUNE_BFGS_TRI_MIN_N", "2")
+    A = orc.quadratic_matrix(n)
+    x0 = orc.pcg_fill(n, 4) - 0.5
+    ref = orc.BFGS(orc.Problem(orc.QUADRATIC, n, A=A), x0, 1.0)
+    opt = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+    g0 = np.linalg.norm(ref.current_gradient)
+    done = 0
+    for it in range(steps):
+        if np.linalg.norm(ref.current_gradient) <= 1e-13 * g0 or ref.has_terminated:
+            break
+        opt.install_state(**_oracle_state(ref))
+        f_before = ref.current_objective_value
+        opt.step(); ref.step()
+        _check_step(_read(opt), ref, f_before, (n, it))
+        done += 1
+    assert done >= min(steps, n, 8)
+    # free run: two updates in a row without the host looking at H in between (the upper triangle stays stale)
+    opt2 = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A), None, dzo.DeviceArray.from_host(x0), 1.0)
+    ref2 = orc.BFGS(orc.Problem(orc.QUADRATIC, n, A=A), x0, 1.0)
+    for _ in range(min(6, n)):
+        opt2.step(); ref2.step()
+    H = opt2.approximate_inverse_hessian.to_host().reshape(n, n)
+    assert np.array_equal(H, H.T)
+    assert rel(H, np.ascontiguousarray(ref2.approximate_inverse_hessian)) <= 1e-7
+
+
 @pytest.mark.parametrize("n,steps", [(2, 60), (16, 60), (200, 40)])
 def test_each_bfgs_step_matches_oracle_on_identical_state_rosenbrock(n, steps):
     """Non-quadratic objective: the sequential (not side-by-side) line searches, gradient-descent
