@@ -339,6 +339,11 @@ def secondary_workload(args):
             if k in kern:
                 kern[k]["algorithmic_GBps"] = round(b / (kern[k]["avg_us"] * 1e-6) / 1e9, 1)
         dom = "bfgs_update"
+        # measured ceilings: the same read-only streaming kernel over a buffer the size of what a pass over H reads
+        # (Infinity-Cache resident) and over 4 GiB (HBM)
+        hbytes = n * n * 8 // (2 if tri else 1)
+        ceil_llc = dzo.calibrate_read_bandwidth(hbytes, 30)
+        ceil_hbm = dzo.calibrate_read_bandwidth(4 << 30, 3)
         out.update({"metric": "step!() calls/sec and achieved HBM GB/s, dense BFGS n=4096 fp64 (config 2)",
                     "value": round(world * args.steps / el, 3), "unit": "step!() calls/s",
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
@@ -354,6 +359,8 @@ def secondary_workload(args):
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(kern.get(dom, {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4),
                                  "traffic": None,
+                                 "measured_read_ceiling_GBps": {"resident_buffer_of_this_size": round(ceil_llc, 1), "hbm_4GiB": round(ceil_hbm, 1)},
+                                 "frac_of_measured_resident_ceiling": round(kern.get(dom, {}).get("algorithmic_GBps", 0) / max(ceil_llc, 1e-9), 4),
                                  "update_plus_direction_kernel_us": round(sum(kern[k]["avg_us"] * (2 if k == "bfgs_tri_reduce" else 1)
                                                                               for k in ("bfgs_symv", "bfgs_update", "bfgs_tri_reduce") if k in kern), 2),
                                  "note": ("step! reads and writes the lower triangle of H only (1.5 n^2 T per update + direction); " if tri else "")

@@ -27,7 +27,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdzo_hip.so")
+LIB_PATH = os.environ.get("DZO_LIB_PATH") or os.path.join(_HERE, "libdzo_hip.so")   # (override: A/B of two builds)
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 F32, F64 = 0, 1
@@ -127,6 +127,14 @@ def synchronize():
     _check(lib().dzo_synchronize())
 
 
+def calibrate_read_bandwidth(nbytes, repeats=20):
+    """GB/s of a plain streaming read over ``nbytes`` (Infinity-Cache resident up to ~200 MiB, HBM beyond)."""
+    _need_init()
+    r = C.c_double()
+    _check(lib().dzo_calibrate_read_bandwidth(int(nbytes), int(repeats), C.byref(r)))
+    return r.value
+
+
 # ------------------------------------------------------------------------------ ABI table
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 CONSTRAINT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
@@ -140,6 +148,7 @@ ABI = {
     "dzo_synchronize": [],
     "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_profile_count": [_P(_i32)],
     "dzo_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_dbl)],
+    "dzo_calibrate_read_bandwidth": [_i64, _i32, _P(_dbl)],
     "dzo_malloc": [_P(_vp), _i64], "dzo_free": [_vp], "dzo_memcpy_h2d": [_vp, _vp, _i64],
     "dzo_memcpy_d2h": [_vp, _vp, _i64], "dzo_memcpy_d2d": [_vp, _vp, _i64],
     "dzo_axpy": [_i64, _i32, _dbl, _vp, _vp], "dzo_axpby": [_i64, _i32, _dbl, _vp, _dbl, _vp],

@@ -38,6 +38,10 @@ struct SlotMap {
     uint8_t slot[kMaxHistory];
 };
 
+constexpr int kRowOwn = 62;                     // wave-row geometry of the single-pass kernel (see there)
+constexpr int kRowLead = (64 - kRowOwn) / 2;
+constexpr int kTileBytes = 64 * 16;             // one stream's share of a wave-row in the blocked ring
+
 }  // namespace dzo
 
 struct dzo_lbfgs_s {
@@ -109,11 +113,32 @@ struct dzo_lbfgs_s {
     // layout 1 (default): ONE slab, slots interleaved s_0 y_0 s_1 y_1 ... (Y = S + stride, pair
     // stride 2*stride): consecutive streams sit an odd number of KiB apart.  layout 0: two slabs.
     int64_t pair_stride = 0;        // elements between consecutive slots of the same history
-    template <typename T> T *s_slot(int slot) const { return (T *)S + (int64_t)slot * pair_stride; }
-    template <typename T> T *y_slot(int slot) const { return (T *)Y + (int64_t)slot * pair_stride; }
-    void *s_slot_v(int slot) const { return (char *)S + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype); }
-    void *y_slot_v(int slot) const { return (char *)Y + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype); }
-    void refresh_delta_ptrs() { core.dx = s_slot_v(spare()); core.dg = y_slot_v(spare()); }
+    // layout 2 (blocked, see "blocked history ring"): S is the ring, a slot's s / y stream starts at tile
+    // 2*slot / 2*slot + 1 of row 0, consecutive rows are rowbytes apart.  delta_point / delta_gradient are
+    // then contiguous vectors of their own (dx_lin / dg_lin): the two-pass step works on them and scatters
+    // them into the spare slot at the push; after a single-pass step (which writes the tiles directly) they
+    // are gathered back only when somebody asks.
+    bool blocked = false;
+    int64_t rowbytes = 0, ring_rows = 0;
+    void *dx_lin = nullptr, *dg_lin = nullptr;
+    bool lin_stale = false;         // dx_lin / dg_lin do not hold the newest pair (a single-pass step pushed it)
+    void *export_slab = nullptr;    // contiguous copies of S[i] / Y[i] handed out by get_ptr (2 m vectors, lazily)
+    template <typename T> T *s_slot(int slot) const {
+        return blocked ? (T *)((char *)S + (size_t)(2 * slot) * dzo::kTileBytes) : (T *)S + (int64_t)slot * pair_stride;
+    }
+    template <typename T> T *y_slot(int slot) const {
+        return blocked ? (T *)((char *)S + (size_t)(2 * slot + 1) * dzo::kTileBytes) : (T *)Y + (int64_t)slot * pair_stride;
+    }
+    void *s_slot_v(int slot) const {
+        return blocked ? (void *)((char *)S + (size_t)(2 * slot) * dzo::kTileBytes) : (void *)((char *)S + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype));
+    }
+    void *y_slot_v(int slot) const {
+        return blocked ? (void *)((char *)S + (size_t)(2 * slot + 1) * dzo::kTileBytes) : (void *)((char *)Y + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype));
+    }
+    void refresh_delta_ptrs() {
+        if (blocked) { core.dx = dx_lin; core.dg = dg_lin; }
+        else { core.dx = s_slot_v(spare()); core.dg = y_slot_v(spare()); }
+    }
 };
 
 namespace dzo {
@@ -133,6 +158,23 @@ template <typename T, bool VEC> struct Ld {
         if constexpr (VEC) store16(p, v); else p[0] = v[0];
     }
 };
+
+// ---------------------------------------------------------------------------- blocked history ring
+// When the optimizer is eligible for the single-pass step its (s, y) ring is stored TILE-MAJOR instead of
+// as 2(m+1) slabs: the unit is a wave-row of the single-pass kernel -- 62 owned 16-B vectors plus a copy of
+// the neighbouring vector on each side = one 1-KiB tile [halo | 62 | halo] per stream -- and the
+// 2(m+1) tiles of a row (s_0 y_0 s_1 y_1 ...) are adjacent.  A wave-row's 2k history loads are then one
+// contiguous run of aligned full lines (k = 20: 40 KiB) instead of 40 unaligned 992-byte pieces 80 MB
+// apart.  Vector v of a stream lives in row v / 62 at position v % 62 + 1; the first / last vector of a row
+// is duplicated at position 63 / 0 of the previous / next row.  The two-pass kernels address the same
+// layout through hist_ptr; contiguous views (S[i], Y[i], delta_point, delta_gradient, set_history) are
+// gathered / scattered on demand.
+template <bool BLK, typename T>
+__device__ __forceinline__ const T *hist_ptr(const T *base, int64_t vi, int64_t rowbytes) {
+    if constexpr (!BLK) return base + vi * Vec16<T>::N;
+    const uint32_t v = (uint32_t)vi, r = v / (uint32_t)kRowOwn, q = v - r * (uint32_t)kRowOwn + (uint32_t)kRowLead;
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (int64_t)r * rowbytes + (int64_t)q * 16);
+}
 
 // ============================================================================ CHAIN mode
 // One link of the two-loop recursion: out = post * fma(coef, v, in), with
@@ -277,6 +319,7 @@ template <typename T> struct GramParams {
     const T *s[kMaxHistory];    // logical pair -> slot base (wave-uniform index -> scalar loads)
     const T *y[kMaxHistory];
     double *partials;           // [kGramValues * k][gridDim.x]
+    int64_t rowbytes;           // blocked ring: bytes between consecutive wave-rows (BLK kernels only)
 };
 
 __device__ __forceinline__ void wave_sum5(const double (&t)[5], int lane, double (&tot)[5]) {
@@ -446,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p)
 // butterfly and added into lane i's accumulators for pair i, so a lane carries 5 fp64
 // accumulators whatever k is (k <= 64 = wave width), occupancy stays high, and no operand is
 // loaded twice.  VALU/LDS cost of the butterflies: ~15 % of the memory time at U = 4.
-template <typename T, bool VEC, int U>
+template <typename T, bool VEC, int U, bool BLK = false>
 __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
@@ -474,12 +517,12 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             if (ok[u]) {
                 if (p.fresh_plain) {
                     L::load(p.g + vi * N, gv[u]);
-                    L::load(sp + vi * N, spv[u]);
-                    L::load(yp + vi * N, ypv[u]);
+                    L::load(hist_ptr<BLK>(sp, vi, p.rowbytes), spv[u]);
+                    L::load(hist_ptr<BLK>(yp, vi, p.rowbytes), ypv[u]);
                 } else {
                     L::load_nt(p.g + vi * N, gv[u]);
-                    L::load_nt(sp + vi * N, spv[u]);
-                    L::load_nt(yp + vi * N, ypv[u]);
+                    L::load_nt(hist_ptr<BLK>(sp, vi, p.rowbytes), spv[u]);
+                    L::load_nt(hist_ptr<BLK>(yp, vi, p.rowbytes), ypv[u]);
                 }
             } else {
 #pragma unroll
@@ -497,8 +540,8 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             for (int u = 0; u < U; ++u) {
                 if (FULL || ok[u]) {
                     const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
-                    L::load_nt(si + vi * N, sv[u]);
-                    L::load_nt(yi + vi * N, yv[u]);
+                    L::load_nt(hist_ptr<BLK>(si, vi, p.rowbytes), sv[u]);
+                    L::load_nt(hist_ptr<BLK>(yi, vi, p.rowbytes), yv[u]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < N; ++j) { sv[u][j] = 0; yv[u][j] = 0; }
@@ -604,6 +647,7 @@ template <typename T> struct CombineParams {
     const double *alpha, *coef, *scale;
     const T *s[kMaxHistory];    // logical pair -> slot base
     const T *y[kMaxHistory];
+    int64_t rowbytes;           // blocked ring (BLK kernels only)
 };
 
 // d[e] = the reference's elementwise recurrence (:438-449) with the scalars already known:
@@ -612,7 +656,7 @@ template <typename T> struct CombineParams {
 // The 2k coefficients are staged once per block in LDS (wave-uniform broadcast reads), the
 // slot pointers come from the kernel-argument segment (scalar loads), and the history is
 // streamed with non-temporal 16-B loads, UI of them in flight per stream step.
-template <typename T, bool VEC, int U, bool NTS>
+template <typename T, bool VEC, int U, bool NTS, bool BLK = false>
 __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
@@ -643,8 +687,8 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (ok[u]) {
-                    if (p.fresh_plain && i == 0) L::load(yi + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
-                    else L::load_nt(yi + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                    if (p.fresh_plain && i == 0) L::load(hist_ptr<BLK>(yi, base + (int64_t)u * kBlock + threadIdx.x, p.rowbytes), v[u]);
+                    else L::load_nt(hist_ptr<BLK>(yi, base + (int64_t)u * kBlock + threadIdx.x, p.rowbytes), v[u]);
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -665,8 +709,8 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (ok[u]) {
-                    if (p.fresh_plain && i == 0) L::load(si + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
-                    else L::load_nt(si + (base + (int64_t)u * kBlock + threadIdx.x) * N, v[u]);
+                    if (p.fresh_plain && i == 0) L::load(hist_ptr<BLK>(si, base + (int64_t)u * kBlock + threadIdx.x, p.rowbytes), v[u]);
+                    else L::load_nt(hist_ptr<BLK>(si, base + (int64_t)u * kBlock + threadIdx.x, p.rowbytes), v[u]);
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -717,8 +761,6 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
 // each side.  62 uses the whole wave.  (56 owned vectors = seven whole 128-B lines per stream, so
 // that rows start on line boundaries, measured slower: 770 vs 757 us -- 11 % more rows and
 // redundant halo loads cost more than the partial first / last line of every row.)
-constexpr int kRowOwn = 62;
-constexpr int kRowLead = (64 - kRowOwn) / 2;
 constexpr int kFusedMaxK = 20;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
 
 template <typename T> struct FusedParams {
@@ -729,10 +771,14 @@ template <typename T> struct FusedParams {
     const T *x, *g;                            // current_point / current_gradient: READ ONLY in this pass
     T *x_out, *g_out;                          // the trial point and its gradient go to the twin buffers
     T *d;                                      // step_direction
-    T *s_new, *y_new;                          // delta_point / delta_gradient (spare slots)
     const double *alpha, *coef, *scale;
-    const T *s[kFusedMaxK];                    // logical pair -> slot base, newest first
-    const T *y[kFusedMaxK];
+    // blocked ring: ONE base pointer; the tile of stream q in wave-row r is at ring + r * rowbytes + off(q).
+    // Every address of a row is then (one scalar row base) + (a 32-bit uniform offset) + 16 * lane -- eighty
+    // separate stream pointers times a 64-bit row offset each do not fit the scalar register file.
+    T *ring;
+    uint32_t rowbytes;                         // bytes between consecutive wave-rows of the ring
+    uint32_t soff[kFusedMaxK];                 // logical pair -> byte offset of its s tile within a row (y tile: + kTileBytes)
+    uint32_t new_off;                          // s tile of the spare slot: delta_point / delta_gradient of this step
     double *gram_partials;                     // [kGramValues * k_next][gridDim.x], post-push order
     double *obj_partials;                      // [gridDim.x]
     int32_t *changed;
@@ -792,21 +838,36 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     // the next row's loads BEFORE this row's stores also keeps the store acknowledgements off the
     // critical path: vmcnt retires in issue order.  Measured at n = 1e7, k = 20: 845 us with one
     // register set refilled pair by pair during the dots, 537 us for the loads alone.
+    // History loads: row r of every stream is one aligned 1-KiB tile, the tiles of a row adjacent; lane l
+    // reads position l of the tile (position 0 / 63 hold the neighbouring rows' edge vectors).  The row base is
+    // wave-uniform: it goes into the scalar base address, the vector offset is the constant 16 * lane.
+    const uint32_t toff = (uint32_t)lane * 16u;
+    auto rowbase = [&](int64_t row) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)row);       // rows < 2^31 (n T < 4 GiB)
+        return reinterpret_cast<char *>(p.ring) + (uint64_t)r * p.rowbytes;
+    };
+    // (scalar row base) + (32-bit vector offset = tile offset + 16 * lane).  The empty asm keeps the tile offset
+    // opaque inside the loop: hoisted, the forty loop-invariant sums would each pin a VGPR.
+    auto tl = [&](char *rb, uint32_t uoff) {
+        asm volatile("" : "+s"(uoff));
+        return reinterpret_cast<const T *>(rb + (uint32_t)(uoff + toff));
+    };
     auto issue = [&](int64_t row, uint32_t boff, T (&sv)[K][N], T (&yv)[K][N], T (&xo)[N], T (&go)[N]) {
         load_xg(row, boff, xo, go);
+        char *rb = rowbase(row);
         if constexpr (PLAIN) {
 #pragma unroll
-            for (int i = 0; i < K; ++i) load16(at(p.y[i], boff), yv[i]);
+            for (int i = 0; i < K; ++i) load16(tl(rb, p.soff[i] + (uint32_t)kTileBytes), yv[i]);
 #pragma unroll
-            for (int i = K - 1; i >= 0; --i) load16(at(p.s[i], boff), sv[i]);
+            for (int i = K - 1; i >= 0; --i) load16(tl(rb, p.soff[i]), sv[i]);
             return;
         }
-        if (p.debug_skip & 16) { load16(at(p.y[0], boff), yv[0]); load16(at(p.s[0], boff), sv[0]); }
-        else { load16_nt(at(p.y[0], boff), yv[0]); load16_nt(at(p.s[0], boff), sv[0]); }
+        if (p.debug_skip & 16) { load16(tl(rb, p.soff[0] + (uint32_t)kTileBytes), yv[0]); load16(tl(rb, p.soff[0]), sv[0]); }
+        else { load16_nt(tl(rb, p.soff[0] + (uint32_t)kTileBytes), yv[0]); load16_nt(tl(rb, p.soff[0]), sv[0]); }
 #pragma unroll
-        for (int i = 1; i < K; ++i) load16_nt(at(p.y[i], boff), yv[i]);
+        for (int i = 1; i < K; ++i) load16_nt(tl(rb, p.soff[i] + (uint32_t)kTileBytes), yv[i]);
 #pragma unroll
-        for (int i = K - 1; i >= 1; --i) load16_nt(at(p.s[i], boff), sv[i]);
+        for (int i = K - 1; i >= 1; --i) load16_nt(tl(rb, p.soff[i]), sv[i]);
     };
     auto compute = [&](int64_t row, uint32_t boff, const T (&sv)[K][N], const T (&yv)[K][N], const T (&xo)[N], const T (&go)[N]) {
         const int64_t v = row * kOwn - kLead + lane;
@@ -859,8 +920,25 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             if (!(p.debug_skip & 128)) store16_nt(atw(p.d, boff), q);
             store16_nt(atw(p.x_out, boff), xn);
             store16_nt(atw(p.g_out, boff), gn);
-            if (!(p.debug_skip & 64)) store16_nt(atw(p.s_new, boff), sn);
-            if (!(p.debug_skip & 64)) store16_nt(atw(p.y_new, boff), yn);
+            // the new pair goes straight into its tiles; the first / last owned vector of the row is also
+            // the right / left halo copy of the neighbouring row's tile
+            char *st = rowbase(row) + p.new_off;
+            char *yt = st + kTileBytes;
+            if (!(p.debug_skip & 64)) {
+                store16_nt(reinterpret_cast<T *>(st + toff), sn);
+                store16_nt(reinterpret_cast<T *>(yt + toff), yn);
+            }
+            // (measured, n = 1e7 k = 20: the four one-lane halo stores cost 8 us of 690; the five output streams
+            // ~25 us each, twice their bytes at the read rate -- write/read turnarounds in the HBM stacks; plain
+            // instead of non-temporal stores are within the run-to-run noise inside step!)
+            if (lane == kLead && row > 0) {
+                store16(reinterpret_cast<T *>(st - (int64_t)p.rowbytes + 63 * 16), sn);
+                store16(reinterpret_cast<T *>(yt - (int64_t)p.rowbytes + 63 * 16), yn);
+            }
+            if (lane == kLead + kOwn - 1 && row + 1 < rows) {
+                store16(reinterpret_cast<T *>(st + p.rowbytes), sn);
+                store16(reinterpret_cast<T *>(yt + p.rowbytes), yn);
+            }
         }
         if (!owner) {
 #pragma unroll
@@ -954,6 +1032,34 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     block_raise_flag(diff, p.changed, &lds_flag);
     const double fo = block_sum(fobj, lds);
     if (threadIdx.x == 0) p.obj_partials[blockIdx.x] = fo;
+}
+
+// ---------------------------------------------------------------------------- blocked ring <-> contiguous vectors
+// One stream of the ring (all its tiles) from / to a contiguous vector of nvec 16-B vectors.  Thread = one
+// tile position; the halo positions 0 and 63 take the neighbouring rows' edge vectors.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ring_scatter_kernel(int64_t nvec, const T *__restrict__ lin, T *__restrict__ stream, int64_t rowbytes) {
+    constexpr int N = Vec16<T>::N;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = id >> 6;
+        const int pos = (int)(id & 63);
+        const int64_t v = row * kRowOwn - kRowLead + pos;
+        if (v < 0 || v >= nvec) continue;
+        T t[N];
+        load16(lin + v * N, t);
+        store16(reinterpret_cast<T *>(reinterpret_cast<char *>(stream) + row * rowbytes + pos * 16), t);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ring_gather_kernel(int64_t nvec, const T *__restrict__ stream, T *__restrict__ lin, int64_t rowbytes) {
+    constexpr int N = Vec16<T>::N;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBlock) {
+        T t[N];
+        load16(hist_ptr<true>(stream, v, rowbytes), t);
+        store16(lin + v * N, t);
+    }
 }
 
 // ============================================================================ post-gradient
@@ -1132,6 +1238,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     gp.sp = o->s_slot<T>(o->slot_of(pivot)); gp.yp = o->y_slot<T>(o->slot_of(pivot));
     for (int i = 0; i < k; ++i) { gp.s[i] = o->s_slot<T>(o->slot_of(i)); gp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     gp.partials = o->gram_partials;
+    gp.rowbytes = o->rowbytes;
     gp.peel = o->gram_peel;
     gp.fresh_plain = o->gram_fresh_plain;
     gp.pivot_first = (o->gram_skip0 && pivot == 0) ? 1 : 0;
@@ -1153,7 +1260,8 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
 #define GL(UU)                                                                                                  \
     do {                                                                                                        \
-        auto kern = vec ? gram_pass_lanes_kernel<T, true, UU> : gram_pass_lanes_kernel<T, false, UU>;           \
+        auto kern = o->blocked ? gram_pass_lanes_kernel<T, true, UU, true>                                      \
+                    : vec ? gram_pass_lanes_kernel<T, true, UU> : gram_pass_lanes_kernel<T, false, UU>;         \
         int64_t cap = o->gram_grid;                                                                             \
         if (o->gram_bpc <= 0) { const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern); if (res < cap) cap = res; } \
         if (blocks > cap) blocks = cap;                                                                         \
@@ -1226,6 +1334,7 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     cp.n = c.n; cp.g = (const T *)c.g; cp.d = (T *)o->d; cp.k = k;
     for (int i = 0; i < k; ++i) { cp.s[i] = o->s_slot<T>(o->slot_of(i)); cp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     cp.alpha = o->alpha; cp.coef = o->coef; cp.scale = o->scale;
+    cp.rowbytes = o->rowbytes;
     cp.fresh_plain = o->combine_fresh_plain;
     const bool vec = al16(c.g);
     int u = o->combine_u;
@@ -1236,7 +1345,8 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
         DZO_TIMED("lbfgs_combine", s);
 #define CB(UU)                                                                                                   \
     do {                                                                                                         \
-        auto kern = (vec && o->combine_nts) ? combine_kernel<T, true, UU, true>                                  \
+        auto kern = o->blocked ? combine_kernel<T, true, UU, true, true>                                         \
+                    : (vec && o->combine_nts) ? combine_kernel<T, true, UU, true>                                \
                     : vec ? combine_kernel<T, true, UU, false> : combine_kernel<T, false, UU, false>;            \
         const int bpc = o->combine_blocks_per_cu > 0 ? o->combine_blocks_per_cu : resident_blocks((const void *)kern); \
         const int64_t cap = (int64_t)ctx().cus * bpc;                                                            \
@@ -1266,7 +1376,7 @@ static int32_t lbfgs_direction(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
-static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done, bool rho_final = false);
+static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done, bool rho_final = false, bool tiles_written = false);
 
 static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
@@ -1336,9 +1446,79 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
     return lbfgs_rho_finish(o, grid, gate);
 }
 
-static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done, bool rho_final) {
+// ---------------------------------------------------------------------------- blocked ring, host side
+template <typename T> static void ring_scatter(dzo_lbfgs_s *o, const void *lin, void *stream) {
+    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int grid = stream_grid(o->ring_rows * 64, 1);
+    hipLaunchKernelGGL(ring_scatter_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)lin, (T *)stream, o->rowbytes);
+}
+template <typename T> static void ring_gather(dzo_lbfgs_s *o, const void *stream, void *lin) {
+    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int grid = stream_grid(nvec, 1);
+    hipLaunchKernelGGL(ring_gather_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)stream, (T *)lin, o->rowbytes);
+}
+
+// delta_point / delta_gradient as contiguous vectors (blocked ring: gathered from the newest pair when a
+// single-pass step pushed it without materialising them)
+static int32_t lbfgs_refresh_lin(dzo_lbfgs_s *o) {
+    if (!o->blocked || !o->lin_stale) return DZO_OK;
+    DZO_TIMED("lbfgs_ring_gather", o->core.stream);
+    DZO_DISPATCH(o->core.dtype, (ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin), ring_gather<T>(o, o->y_slot_v(o->newest), o->dg_lin)));
+    DZO_HIP(hipGetLastError());
+    o->lin_stale = false;
+    return DZO_OK;
+}
+
+// Leave the blocked layout for good (CHAIN mode walks the history as plain vectors): every live pair is
+// gathered into a slab ring, the blocked ring is freed.
+static int32_t lbfgs_unblock(dzo_lbfgs_s *o) {
+    if (!o->blocked) return DZO_OK;
+    OptCore &c = o->core;
+    DZO_TRY(lbfgs_refresh_lin(o));
+    const size_t es = dtype_size(c.dtype);
+    const int m1 = o->m + 1;
+    const size_t slab = (size_t)m1 * (size_t)o->stride * es;
+    void *ring = nullptr;
+    hipError_t e = hipMalloc(&ring, 2 * slab);
+    if (e != hipSuccess) { set_error("out of device memory converting the history ring (%zu bytes)", 2 * slab); return DZO_ERR_NOMEM; }
+    DZO_HIP(hipMemsetAsync(ring, 0, 2 * slab, c.stream));
+    void *Yb = (char *)ring + (size_t)o->stride * es;
+    const int64_t ps = 2 * o->stride;
+    for (int i = 0; i < o->k; ++i) {
+        const int slot = o->slot_of(i);
+        DZO_DISPATCH(c.dtype, (ring_gather<T>(o, o->s_slot_v(slot), (char *)ring + (size_t)slot * ps * es),
+                               ring_gather<T>(o, o->y_slot_v(slot), (char *)Yb + (size_t)slot * ps * es)));
+    }
+    DZO_HIP(hipGetLastError());
+    // the deltas of the last step live in the spare slots of a slab ring
+    const int sp = o->spare();
+    DZO_HIP(hipMemcpyAsync((char *)ring + (size_t)sp * ps * es, o->dx_lin, (size_t)c.n * es, hipMemcpyDeviceToDevice, c.stream));
+    DZO_HIP(hipMemcpyAsync((char *)Yb + (size_t)sp * ps * es, o->dg_lin, (size_t)c.n * es, hipMemcpyDeviceToDevice, c.stream));
+    DZO_HIP(hipStreamSynchronize(c.stream));
+    (void)hipFree(o->S);
+    o->S = ring; o->Y = Yb; o->interleaved = true; o->pair_stride = ps;
+    o->blocked = false;
+    // (after a push delta_point / delta_gradient are the newest pair; before the first step the zero-filled spare)
+    if (c.iteration_count > 0 && o->k > 0) { c.dx = o->s_slot_v(o->newest); c.dg = o->y_slot_v(o->newest); }
+    else o->refresh_delta_ptrs();
+    return DZO_OK;
+}
+
+static int32_t lbfgs_finish_push(dzo_lbfgs_s *o, int grid, bool rho_done, bool rho_final, bool tiles_written) {
     OptCore &c = o->core;
     const int sp = o->spare();
+    if (o->blocked) {
+        if (tiles_written) {
+            o->lin_stale = true;                          // (the single pass wrote the pair's tiles, not dx_lin / dg_lin)
+        } else {
+            // a two-pass step leaves delta_point / delta_gradient in the contiguous vectors: copy them into the
+            // spare slot's tiles (4 n T; only after a rejected first trial, with callbacks, ...)
+            DZO_TIMED("lbfgs_ring_scatter", c.stream);
+            DZO_DISPATCH(c.dtype, (ring_scatter<T>(o, o->dx_lin, o->s_slot_v(sp)), ring_scatter<T>(o, o->dg_lin, o->y_slot_v(sp))));
+            DZO_HIP(hipGetLastError());
+            o->lin_stale = false;
+        }
+    }
     if (o->reset_on_push) {                               // legacy :609  _history_count[] = 0
         o->k = 0;
         o->reset_on_push = false;
@@ -1509,7 +1689,15 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     if (c.is_stuck) {                                     // :474-476
         // delta_point holds x_old (:118, the first trial's backup); delta_gradient is still the
         // previous step's, which lives in the newest pair of the ring
-        if (o->k > 0) c.dg = o->y_slot_v(o->newest);
+        if (o->blocked) {
+            if (o->k > 0) {                               // (the search used dg_lin as its scratch)
+                DZO_DISPATCH(c.dtype, ring_gather<T>(o, o->y_slot_v(o->newest), o->dg_lin));
+                DZO_HIP(hipGetLastError());
+            }
+            o->lin_stale = false;
+        } else if (o->k > 0) {
+            c.dg = o->y_slot_v(o->newest);
+        }
         return DZO_OK;
     }
     int32_t done = -1;
@@ -1539,7 +1727,7 @@ static inline bool al16v(const void *p) { return (reinterpret_cast<uintptr_t>(p)
 // can this step run as one pass over the history?  (built-in chained Rosenbrock, plain options)
 static bool single_pass_ok(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
-    if (!o->single_pass || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
+    if (!o->single_pass || !o->blocked || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
     if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post) return false;
     if (c.iteration_count == 0 || o->k < 1 || o->k > kFusedMaxK) return false;
     const int vecn = 16 / (int)dtype_size(c.dtype);
@@ -1611,11 +1799,13 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     memset(&fp, 0, sizeof(fp));
     fp.n = c.n; fp.k = k; fp.k_next = k < o->m ? k + 1 : o->m; fp.t = (T)1;
     fp.x = (const T *)c.x; fp.g = (const T *)c.g; fp.x_out = (T *)o->x_twin; fp.g_out = (T *)o->g_twin;
-    fp.d = (T *)o->d; fp.s_new = (T *)c.dx; fp.y_new = (T *)c.dg;
+    fp.d = (T *)o->d;
+    fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
+    fp.new_off = (uint32_t)(2 * o->spare()) * (uint32_t)kTileBytes;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     for (int i = 0; i < kFusedMaxK; ++i) {                // entries >= k: any valid vector (zero coefficient)
         const int slot = o->slot_of(i < k ? i : 0);
-        fp.s[i] = o->s_slot<T>(slot); fp.y[i] = o->y_slot<T>(slot);
+        fp.soff[i] = (uint32_t)(2 * slot) * (uint32_t)kTileBytes;
     }
     fp.gram_partials = o->gram_partials;
     fp.obj_partials = c.problem->scratch;
@@ -1668,8 +1858,10 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
         c.is_stuck = true;
         // the fields as take_backtracking_step! leaves them: delta_point = x_old (:118), delta_gradient
         // still the previous step's (= the newest pair of the ring; the pass wrote only spare slots)
+        // (blocked ring: delta_gradient is gathered from the newest pair's tiles unless dg_lin still holds it)
+        if (o->lin_stale && o->k > 0) { ring_gather<T>(o, o->y_slot_v(o->newest), o->dg_lin); o->lin_stale = false; }
         DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));
-        if (o->k > 0) c.dg = o->y_slot_v(o->newest);
+        DZO_HIP(hipGetLastError());
         return DZO_OK;
     }
     c.last_trials = 1;
@@ -1677,7 +1869,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     if (status == 1) {                                    // :139-146 (f_new < f), and the kernel already did :478-480
         c.df = round_to_dtype(c.dtype, f_new - c.f);
         c.f = f_new;
-        DZO_TRY(lbfgs_finish_push(o, 0, true, true));     // rho of the new pair was set by the gated gram_finish
+        DZO_TRY(lbfgs_finish_push(o, 0, true, true, true));   // rho of the new pair was set by the gated gram_finish; the pass wrote its tiles
         o->spec_scalars = true;                           // alpha_sp / coef_sp / scale_sp hold the next step's scalars
         o->gram_ready = false;
         o->gram_stale = 0;
@@ -1737,6 +1929,8 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
 
 using namespace dzo;
 
+static thread_local bool tl_want_blocked = false;       // dzo_lbfgs_create_problem -> dzo_lbfgs_create
+
 // ============================================================================ C ABI
 extern "C" {
 
@@ -1773,7 +1967,22 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     e = hipMalloc((void **)&(ptr), (bytes));                                                       \
     if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     o->interleaved = tune("DZO_TUNE_INTERLEAVE", 1) != 0;
-    if (o->interleaved) {
+    {
+        // blocked (tile-major) ring: when the constructor knows that the single-pass step applies
+        const int vecn = 16 / (int)es;
+        o->blocked = tl_want_blocked && tune("DZO_TUNE_BLOCKED", 1) != 0 && tune("DZO_TUNE_SINGLE_PASS", 1) != 0 &&
+                     history_length <= kFusedMaxK && n % vecn == 0 && n >= 4 * vecn && (uint64_t)n * es < (1ull << 32);
+    }
+    if (o->blocked) {
+        const int64_t nvec = n / (16 / (int64_t)es);
+        o->ring_rows = (nvec + kRowOwn - 1) / kRowOwn;
+        o->rowbytes = (int64_t)2 * m1 * kTileBytes;
+        ALLOC(o->S, (size_t)o->ring_rows * (size_t)o->rowbytes);
+        o->Y = nullptr;
+        o->pair_stride = 0;
+        ALLOC(o->dx_lin, (size_t)o->stride * es);
+        ALLOC(o->dg_lin, (size_t)o->stride * es);
+    } else if (o->interleaved) {
         ALLOC(o->S, 2 * slab);
         o->Y = (char *)o->S + (size_t)o->stride * es;
         o->pair_stride = 2 * o->stride;
@@ -1826,7 +2035,11 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1);
     o->link_partials = base;
     // :366-374 zero-filled deltas: the whole ring starts zeroed
-    if (o->interleaved) {
+    if (o->blocked) {
+        DZO_HIP(hipMemsetAsync(o->S, 0, (size_t)o->ring_rows * (size_t)o->rowbytes, c.stream));
+        DZO_HIP(hipMemsetAsync(o->dx_lin, 0, (size_t)o->stride * es, c.stream));
+        DZO_HIP(hipMemsetAsync(o->dg_lin, 0, (size_t)o->stride * es, c.stream));
+    } else if (o->interleaved) {
         DZO_HIP(hipMemsetAsync(o->S, 0, 2 * slab, c.stream));
     } else {
         DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
@@ -1857,9 +2070,12 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     unsettled_remove(o);
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->S) (void)hipFree(o->S);
-    if (o->Y && !o->interleaved) (void)hipFree(o->Y);
+    if (o->Y && !o->interleaved && !o->blocked) (void)hipFree(o->Y);
     if (o->d_alloc) (void)hipFree(o->d_alloc);
     if (o->twin_slab) (void)hipFree(o->twin_slab);
+    if (o->dx_lin) (void)hipFree(o->dx_lin);
+    if (o->dg_lin) (void)hipFree(o->dg_lin);
+    if (o->export_slab) (void)hipFree(o->export_slab);
     if (o->xt) (void)hipFree(o->xt);
     if (o->gt) (void)hipFree(o->gt);
     if (o->gram_ticket) (void)hipFree(o->gram_ticket);
@@ -1897,7 +2113,11 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
     void *g = nullptr;
     DZO_HIP(hipMalloc(&g, (size_t)((problem->n + 63) / 64 * 64) * dtype_size(problem->dtype)));
     int32_t rc = dzo_problem_grad(problem, g, x_dev);     // :421
+    // the single-pass step will apply (built-in chained Rosenbrock, no decorators): tile-major history ring
+    tl_want_blocked = problem->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && problem->l2 == 0.0 && !problem->bg_on && !problem->cons_on &&
+                      (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
     if (rc == DZO_OK) rc = dzo_lbfgs_create(problem->n, history_length, problem->dtype, x_dev, g, f0, initial_step_length, out);
+    tl_want_blocked = false;
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
     rc = problem_view_create(problem, &(*out)->core.problem);    // private partial-sum workspace per optimizer
@@ -1931,6 +2151,7 @@ int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t o, int32_t mode) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(mode == DZO_TWOLOOP_CHAIN || mode == DZO_TWOLOOP_GRAM, DZO_ERR_INVALID, "bad two-loop mode %d", mode);
     DZO_TRY(lbfgs_flush_rho(o));
+    if (mode == DZO_TWOLOOP_CHAIN) DZO_TRY(lbfgs_unblock(o));   // the chain kernels walk the pairs as plain vectors
     if (mode == DZO_TWOLOOP_GRAM && o->mode != DZO_TWOLOOP_GRAM) o->gram_rebuild = true;
     o->mode = mode;
     return DZO_OK;
@@ -2061,6 +2282,24 @@ int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t o, int32_t is_stuck) {
 int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
     DZO_TRY(lbfgs_settle(o));                             // current_point / current_gradient ARE the caller's arrays again
+    if (what == 1 || what == 3) DZO_TRY(lbfgs_refresh_lin(o));   // blocked ring: delta_point / delta_gradient gathered on demand
+    if ((what == 5 || what == 6) && o->blocked) {
+        // S[i] / Y[i] of a blocked ring: a contiguous COPY of the pair's stream (read-only snapshot; use
+        // dzo_lbfgs_set_history to install pairs)
+        DZO_REQUIRE(idx >= 0 && idx < o->k, DZO_ERR_INVALID, "history index %d out of range [0,%d)", idx, o->k);
+        const size_t vb = (size_t)o->stride * dtype_size(o->core.dtype);
+        if (!o->export_slab) {
+            hipError_t e = hipMalloc(&o->export_slab, 2 * (size_t)o->m * vb);
+            if (e != hipSuccess) { set_error("out of device memory for the contiguous copies of the history (%zu bytes)", 2 * (size_t)o->m * vb); return DZO_ERR_NOMEM; }
+        }
+        void *dst = (char *)o->export_slab + ((what == 5 ? 0 : (size_t)o->m) + (size_t)idx) * vb;
+        const void *src = what == 5 ? o->s_slot_v(o->slot_of(idx)) : o->y_slot_v(o->slot_of(idx));
+        DZO_DISPATCH(o->core.dtype, ring_gather<T>(o, src, dst));
+        DZO_HIP(hipGetLastError());
+        DZO_HIP(hipStreamSynchronize(o->core.stream));
+        *ptr_dev = dst;
+        return DZO_OK;
+    }
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     switch (what) {
     case 0: *ptr_dev = o->core.x; break;
@@ -2117,13 +2356,20 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     double rho_host[kMaxHistory + 1] = {0};
     for (int i = 0; i < k; ++i) {
         const int slot = o->slot_of(i);
-        DZO_HIP(hipMemcpyAsync(o->s_slot_v(slot), (const char *)S_dev + (size_t)i * c.n * es, (size_t)c.n * es, hipMemcpyDeviceToDevice, s));
-        DZO_HIP(hipMemcpyAsync(o->y_slot_v(slot), (const char *)Y_dev + (size_t)i * c.n * es, (size_t)c.n * es, hipMemcpyDeviceToDevice, s));
+        const void *si = (const char *)S_dev + (size_t)i * c.n * es, *yi = (const char *)Y_dev + (size_t)i * c.n * es;
+        if (o->blocked) {
+            DZO_REQUIRE((((uintptr_t)si | (uintptr_t)yi) & 15u) == 0, DZO_ERR_INVALID, "history rows must be 16-byte aligned");
+            DZO_DISPATCH(c.dtype, (ring_scatter<T>(o, si, o->s_slot_v(slot)), ring_scatter<T>(o, yi, o->y_slot_v(slot))));
+            DZO_HIP(hipGetLastError());
+        } else {
+            DZO_HIP(hipMemcpyAsync(o->s_slot_v(slot), si, (size_t)c.n * es, hipMemcpyDeviceToDevice, s));
+            DZO_HIP(hipMemcpyAsync(o->y_slot_v(slot), yi, (size_t)c.n * es, hipMemcpyDeviceToDevice, s));
+        }
         if (rho_or_null) {
             rho_host[slot] = rho_or_null[i];
         } else {
             double r = 0;
-            DZO_TRY(dot_blocking(s, c.n, c.dtype, o->s_slot_v(slot), o->y_slot_v(slot), c.partials(), c.host, &r));
+            DZO_TRY(dot_blocking(s, c.n, c.dtype, si, yi, c.partials(), c.host, &r));
             rho_host[slot] = round_to_dtype(c.dtype, r);
         }
     }
@@ -2131,6 +2377,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_HIP(hipMemcpy(o->rho, rho_host, sizeof(double) * (o->m + 1), hipMemcpyHostToDevice));
     // the spare slots hold delta_point / delta_gradient: zero them like a fresh optimizer (:366-374)
     o->refresh_delta_ptrs();
+    o->lin_stale = false;
     DZO_HIP(hipMemset(c.dx, 0, (size_t)o->stride * es));
     DZO_HIP(hipMemset(c.dg, 0, (size_t)o->stride * es));
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams

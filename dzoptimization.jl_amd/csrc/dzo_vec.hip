@@ -166,6 +166,25 @@ __global__ __launch_bounds__(kBlock) void isequal_kernel(int64_t n, const T *__r
     block_raise_flag(diff, differs, &lds_flag);
 }
 
+// read-only streaming kernel of dzo_calibrate_read_bandwidth, shaped like the fastest reader of this library
+// (the single-pass L-BFGS step with its stores and dots switched off): a wave takes a 32-KiB chunk as 32
+// aligned 1-KiB tiles, lane l reads bytes [16 l, 16 l + 16) of every tile with non-temporal loads, all 32
+// in flight before the first use
+constexpr int kCalibTiles = 32;
+__global__ __launch_bounds__(kBlock, 2) void calib_read_kernel(const char *__restrict__ p, int64_t nchunks, double *__restrict__ sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0;
+    for (int64_t c = (int64_t)blockIdx.x * kWaves + wave; c < nchunks; c += (int64_t)gridDim.x * kWaves) {
+        const char *base = p + c * (kCalibTiles * 1024) + lane * 16;
+        double v[kCalibTiles][2];
+#pragma unroll
+        for (int u = 0; u < kCalibTiles; ++u) load16_nt(reinterpret_cast<const double *>(base + u * 1024), v[u]);
+#pragma unroll
+        for (int u = 0; u < kCalibTiles; ++u) a += v[u][0] + v[u][1];
+    }
+    if (a == 1.2345e300) sink[blockIdx.x] = a;                     // (keeps the loads alive)
+}
+
 // ---------------------------------------------------------------------------- launchers
 #define DZO_LAUNCH_VEC(kernel, T, vec_ok, grid, stream, ...)                              \
     do {                                                                                  \
@@ -369,6 +388,38 @@ int32_t dzo_scal_oop(int64_t n, int32_t dtype, void *dst_dev, double alpha, cons
     DZO_DISPATCH(dtype, launch_scal_oop<T>(ctx().stream, n, (T *)dst_dev, (T)alpha, (const T *)x_dev));
     DZO_HIP(hipGetLastError());
     DZO_HIP(hipStreamSynchronize(ctx().stream));
+    return DZO_OK;
+}
+
+// Calibration: GB/s of a plain read-only streaming kernel over `bytes` of zeroed device memory, re-read
+// `repeats` times (HIP events around all repeats, after one untimed pass).  A buffer that fits the 256 MiB
+// Infinity Cache gives the on-die ceiling the small dense configurations (config 2: H = 128 MiB) run
+// against; a few GiB give the HBM streaming ceiling ("calibrate on the box").
+int32_t dzo_calibrate_read_bandwidth(int64_t bytes, int32_t repeats, double *gbps) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(gbps && bytes >= kCalibTiles * 1024 && repeats >= 1, DZO_ERR_INVALID, "bad argument (at least 32 KiB, one repeat)");
+    void *buf = nullptr;
+    double *sink = nullptr;
+    hipError_t e = hipMalloc(&buf, (size_t)bytes);
+    if (e != hipSuccess) { set_error("out of device memory for a %lld-byte calibration buffer", (long long)bytes); return DZO_ERR_NOMEM; }
+    DZO_HIP(hipMalloc((void **)&sink, sizeof(double) * 4096));
+    hipStream_t s = ctx().stream;
+    DZO_HIP(hipMemsetAsync(buf, 0, (size_t)bytes, s));
+    const int64_t nchunks = bytes / (kCalibTiles * 1024);
+    int grid = (int)((nchunks + kWaves - 1) / kWaves);
+    if (grid > ctx().cus * 2) grid = ctx().cus * 2;
+    hipEvent_t a, b;
+    DZO_HIP(hipEventCreate(&a)); DZO_HIP(hipEventCreate(&b));
+    hipLaunchKernelGGL(calib_read_kernel, dim3(grid), dim3(kBlock), 0, s, (const char *)buf, nchunks, sink);
+    DZO_HIP(hipEventRecord(a, s));
+    for (int r = 0; r < repeats; ++r) hipLaunchKernelGGL(calib_read_kernel, dim3(grid), dim3(kBlock), 0, s, (const char *)buf, nchunks, sink);
+    DZO_HIP(hipEventRecord(b, s));
+    DZO_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    DZO_HIP(hipEventElapsedTime(&ms, a, b));
+    *gbps = (double)nchunks * (kCalibTiles * 1024.0) * repeats / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(buf); (void)hipFree(sink);
     return DZO_OK;
 }
 

@@ -109,6 +109,11 @@ int32_t dzo_profile_reset(void);
 int32_t dzo_profile_count(int32_t *count);
 int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launches, double *total_ms);
 
+/* Calibration (SURVEY.md 8(d) "calibrate on the box"): GB/s of a plain read-only streaming kernel over
+ * `bytes` of device memory re-read `repeats` times.  <= ~200 MiB stays in the Infinity Cache (the ceiling of
+ * config 2, H = 128 MiB); several GiB give the HBM streaming ceiling. */
+int32_t dzo_calibrate_read_bandwidth(int64_t bytes, int32_t repeats, double *gbps);
+
 /* ---------------------------------------------------------------------------------------
  * device memory (what `similar` / `copy` / `Array(x)` do for a GPU array type A)
  * ------------------------------------------------------------------------------------- */
@@ -237,7 +242,9 @@ int32_t dzo_lbfgs_step(dzo_lbfgs_t opt);
  *   accept         delta_f, f, delta_point = x - x_old (:142-145), K3
  *   reject         copy!(x, delta_point) (:151), K4
  *   pre_gradient   copy!(delta_gradient, g) (:478)
- *   post_gradient  delta_gradient = g - delta_gradient, ring push, rho, count (:480-507), K5+K6 */
+ *   post_gradient  delta_gradient = g - delta_gradient, ring push, rho, count (:480-507), K5+K6
+ * dzo_lbfgs_direction only enqueues its kernels on the optimizer's stream (like a KernelAbstractions
+ * launch); dzo_lbfgs_get_ptr(4) or dzo_synchronize waits for step_direction. */
 int32_t dzo_lbfgs_direction(dzo_lbfgs_t opt);
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t opt);
 int32_t dzo_lbfgs_trial(dzo_lbfgs_t opt, double step_size, int32_t *changed);
@@ -252,7 +259,14 @@ int32_t dzo_lbfgs_post_gradient(dzo_lbfgs_t opt);
  * get_s:   0 current_objective_value  1 delta_objective_value
  * get_ptr: 0 current_point  1 delta_point  2 current_gradient  3 delta_gradient
  *          4 step_direction  5 delta_point_history[idx]  6 delta_gradient_history[idx]
- *          (idx 0 = newest, the reference's index 1) */
+ *          (idx 0 = newest, the reference's index 1)
+ * Validity: 0 and 2 are the arrays the constructor was given (aliased, :393) and stay valid for the
+ * optimizer's life; a get_ptr / dzo_synchronize / dzo_memcpy_* call settles the live copy into them.
+ * 1, 3 and 4 are valid until the next step.  5 and 6: an optimizer made by dzo_lbfgs_create_problem on
+ * the built-in chained Rosenbrock with history_length <= 20 keeps its pairs tile-major in HBM
+ * ("blocked ring"); for it 5 / 6 return a contiguous COPY of the pair, valid until the next
+ * step -- read-only; install pairs with dzo_lbfgs_set_history.  Every other optimizer returns the live
+ * vectors of the ring. */
 int32_t dzo_lbfgs_get_i(dzo_lbfgs_t opt, int32_t what, int64_t *value);
 int32_t dzo_lbfgs_get_s(dzo_lbfgs_t opt, int32_t what, double *value);
 int32_t dzo_lbfgs_set_s(dzo_lbfgs_t opt, int32_t what, double value);
@@ -292,12 +306,14 @@ int32_t dzo_adgd_set_callbacks(dzo_adgd_t opt, dzo_constraint_fn constraint,
                                dzo_objective_fn objective, dzo_gradient_fn gradient, void *ctx);
 int32_t dzo_adgd_step(dzo_adgd_t opt);
 /* With the built-in chained Rosenbrock objective step! is ONE pass over x and g (first trial, objective,
- * gradient, both deltas and the two norms the next step's :292-294 need); after a rejected trial the
- * pass is repeated at half the step from the backups it wrote (:151-152).
+ * gradient, both deltas and the two norms the next step's :292-294 need) that reads x and g and writes
+ * the trial point and its gradient into twin buffers (6 n T of traffic); after a rejected trial the pass
+ * is repeated at half the step from the untouched x and g (:151-152).
  * get_i: 0 is_stuck 1 iteration_count 2 n 3 fused steps 4 of them after a rejected first trial;
  * get_s: 0 f 1 delta_f 2 current_step_size 3 previous_step_size;
- * get_ptr: 0 x 1 delta_point 2 g 3 delta_gradient (the optimizer then assumes the caller may have
- * written through the pointer and re-reads what it had cached about that array) */
+ * get_ptr: 0 x 1 delta_point 2 g 3 delta_gradient.  0 and 2 are the constructor's arrays (aliased, :261)
+ * for the optimizer's life: get_ptr / dzo_synchronize / dzo_memcpy_* settle the live copy into them.
+ * 1 and 3 are valid until the next step (delta_gradient alternates between two buffers). */
 int32_t dzo_adgd_get_i(dzo_adgd_t opt, int32_t what, int64_t *value);
 int32_t dzo_adgd_get_s(dzo_adgd_t opt, int32_t what, double *value);
 int32_t dzo_adgd_get_ptr(dzo_adgd_t opt, int32_t what, void **ptr_dev);

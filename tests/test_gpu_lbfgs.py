@@ -814,8 +814,8 @@ def test_single_pass_rejected_first_trials_follow_the_reference_loop():
 
 
 def test_history_longer_than_the_single_pass_limit_switches_paths_cleanly():
-    """m = 24 > 20: the single-pass step serves the first 20 steps of the history fill, then the
-    two-pass kernels take over (the dots handed over by the last single pass included)."""
+    """m = 24 > 20: the tile-major ring and the single-pass step are chosen at construction and only
+    for m <= 20, so this optimizer runs the two-pass kernels throughout -- same steps as the oracle."""
     n, m = 1000, 24
     opt, ref, _ = _gpu_and_oracle(n, m)
     for it in range(40):
@@ -823,7 +823,7 @@ def test_history_longer_than_the_single_pass_limit_switches_paths_cleanly():
         if it < 12:
             assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
             assert opt.last_trials == ref.last_trials
-    assert 15 <= opt.single_pass_steps <= 21 and opt.history_count == m
+    assert opt.single_pass_steps == 0 and opt.history_count == m
     # per-step parity from synced state on both sides of the switch
     opt2, ref2, _ = _gpu_and_oracle(n, m)
     for it in range(30):
@@ -869,3 +869,62 @@ def test_single_pass_twin_buffers_keep_the_callers_array_aliased(n, m, dtype, mo
         assert runs[0][3] >= K - 2 and runs[1][3] == 0
         assert runs[0][2] == runs[1][2]
         assert rel(runs[0][0].astype(np.float64), runs[1][0].astype(np.float64)) <= tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m", [(16, 3), (2 * 62 * 3 + 12, 5), (100_004, 20)])
+def test_blocked_ring_hands_out_the_pairs_as_plain_vectors(n, m, dtype):
+    """Optimizers on the built-in chained Rosenbrock keep their (s, y) pairs tile-major (rows of 62 vectors
+    plus a halo vector either side, DESIGN.md "blocked ring").  The reference's fields stay what they are
+    (src/DZOptimization.jl:366-374): delta_point_history[i] / delta_gradient_history[i] are the deltas of
+    step count-i, delta_point / delta_gradient the newest of them; set_history round-trips bit for bit;
+    switching to the chain kernels converts the ring without changing a bit of it."""
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    prob = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype)
+
+    def run():
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        xs, gs = [x0.copy()], [prob.grad(x0)]
+        for it in range(m + 4):
+            opt.step()
+            if opt.is_stuck:
+                break
+            xs.append(opt.current_point.to_host()); gs.append(opt.current_gradient.to_host())
+        return opt, xs, gs
+
+    opt, xs, gs = run()
+    steps = len(xs) - 1
+    assert steps >= 3 and opt.single_pass_steps >= 1
+    k = opt.history_count
+    assert k == min(steps, m)
+
+    def check(o):
+        S = [h.to_host() for h in o.delta_point_history]
+        Y = [h.to_host() for h in o.delta_gradient_history]
+        for i in range(k):
+            assert np.array_equal(S[i], xs[steps - i] - xs[steps - i - 1]), i
+            assert np.array_equal(Y[i], gs[steps - i] - gs[steps - i - 1]), i
+        return S, Y
+
+    S, Y = check(opt)
+    if not opt.is_stuck:
+        assert np.array_equal(opt.delta_point.to_host(), S[0]) and np.array_equal(opt.delta_gradient.to_host(), Y[0])
+    # round trip through set_history (row 0 = newest, as get_ptr's idx)
+    opt.set_history(np.stack(S), np.stack(Y), opt.rho_history.copy(), iteration_count=opt.iteration_count)
+    check(opt)
+    opt.compute_step_direction()
+    d_gram = opt.step_direction.to_host()
+    opt.set_two_loop_mode(dzo.TWOLOOP_CHAIN)                  # leaves the tile-major layout
+    check(opt)
+    opt.compute_step_direction()
+    tol = 1e-11 if dtype == np.float64 else 2e-4
+    assert rel(opt.step_direction.to_host(), d_gram) <= tol
+    # the same run, converted right after its last step: deltas and pairs survive the conversion
+    opt2, xs2, _ = run()
+    assert len(xs2) == len(xs) and np.array_equal(xs2[-1], xs[-1])
+    opt2.set_two_loop_mode(dzo.TWOLOOP_CHAIN)
+    check(opt2)
+    if not opt2.is_stuck:
+        assert np.array_equal(opt2.delta_point.to_host(), S[0]) and np.array_equal(opt2.delta_gradient.to_host(), Y[0])
+    opt2.step()
+    assert opt2.iteration_count == steps + 1 or opt2.is_stuck
