@@ -717,6 +717,9 @@ class AdGDOptimizer(_OptBase):
     previous_step_size = property(lambda s: s._s(3))
     fused_steps = property(lambda s: s._i(3))
     fused_rejections = property(lambda s: s._i(4))
+    pipelined_passes = property(lambda s: s._i(5))     # passes adopted that were enqueued before the previous decision was seen
+    pipeline_discards = property(lambda s: s._i(6))    # passes in flight dropped (a pointer was handed out, an option changed)
+    pipeline_corrections = property(lambda s: s._i(7)) # adopted passes whose device-side step size differed from the host's evaluation
 
 
 class BFGSOptimizer(_OptBase):

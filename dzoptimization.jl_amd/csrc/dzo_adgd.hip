@@ -5,19 +5,40 @@
 #include "dzo_problems.h"
 #include "dzo_rosen.h"
 
+namespace dzo {
+// Device-side twin of the step's scalar state: what the NEXT pass needs when it is enqueued before the host has
+// seen the outcome of this one (see "pipelined step" below).  Written by adgd_seed_kernel (from the host's values)
+// and advanced by adgd_decide_kernel.
+struct AdgdDev {
+    double t;                        // step size of the next pass (first trial or halved retry)
+    double f_cur;                    // current_objective_value
+    double prev, cur;                // previous_step_size / current_step_size as step! leaves them (:298-299)
+    int32_t sel;                     // the pass reads point / gradient buffer sel and writes buffer (sel + 1) % 3
+    int32_t halvings;
+    int32_t stuck;                   // the search ended (unchanged point, halving limit): later passes do nothing
+    int32_t seq;                     // passes decided so far
+};
+}  // namespace dzo
+
 struct dzo_adgd_s {
     dzo::OptCore core;
     double current_step_size = 0;    // :195
     double previous_step_size = 0;   // :196
-    void *dx_buf = nullptr, *dg_buf = nullptr, *dg_alt = nullptr;
-    // fused step (built-in chained Rosenbrock): one pass does :301 (first trial), :306-308 and the
-    // two sums of squares that :292 / :294 of the NEXT step need.  The pass never writes x or g: the
-    // trial point and its gradient go to TWIN buffers, which swap roles with x / g when the trial is
-    // accepted (no backups, nothing to restore after a rejected trial, no boundary snapshots).  x_user /
-    // g_user are the arrays the optimizer aliases (:253-254 of the reference constructor); they are
-    // settled whenever the host looks (get_ptr, dzo_synchronize, dzo_memcpy_*, destroy).
+    void *dx_buf = nullptr, *dg_buf = nullptr;
+    // fused step (built-in chained Rosenbrock): one pass does :301 (first trial), :307 and the two sums of
+    // squares that :292 / :294 of the NEXT step need -- 2 reads + 2 writes per element.  The pass never writes
+    // x or g: point and gradient live in THREE buffer pairs used in rotation (0 = the arrays the optimizer
+    // aliases, :253-254 of the reference constructor); a pass reads pair `cur` and writes pair cur + 1, an
+    // accepted trial makes that the current pair.  Nothing has to be backed up or restored (:118, :151), and
+    // delta_point = x - x_old (:145), delta_gradient = g - g_old (:306, :308) are not written by the pass at all:
+    // both operands stay intact in pairs cur and cur - 1 (the pass in flight writes pair cur + 1), so the two
+    // vectors are formed when somebody asks for them (get_ptr, or a step on the generic kernels).  The caller's
+    // arrays are settled whenever the host looks (get_ptr, dzo_synchronize, dzo_memcpy_*, destroy).
     bool fused = true;               // DZO_TUNE_ADGD_FUSED=0 forces the generic kernel sequence
-    void *twin = nullptr, *x_twin = nullptr, *g_twin = nullptr;
+    void *twin = nullptr;
+    void *xbuf[3] = {nullptr, nullptr, nullptr}, *gbuf[3] = {nullptr, nullptr, nullptr};
+    int cur = 0;                     // core.x == xbuf[cur], core.g == gbuf[cur]
+    bool dx_lazy = false, dg_lazy = false;   // delta_point / delta_gradient = pair cur - pair (cur + 2) % 3, not formed yet
     void *x_user = nullptr, *g_user = nullptr;
     bool unsettled = false;
     int device = 0;
@@ -25,6 +46,21 @@ struct dzo_adgd_s {
     bool norms_ready = false;        // |delta_point|^2, |delta_gradient|^2 of the last step are in norm2[]
     double norm2[2] = {0, 0};
     int64_t fused_steps = 0, fused_rejections = 0;
+    // Pipelined step: behind every pass + decision the NEXT pass is enqueued at once, reading its step size and
+    // buffer roles from `dev` (the decision kernel runs the recurrence of :285-299 / the halving of :152 on the
+    // device), so the GPU never waits for the host's round trip.  Between two step! calls exactly one pass is in
+    // flight and it writes only buffers the current state does not live in: a getter that hands out a pointer or
+    // a changed option just drains the stream and the next pass starts from the host's state.  The host evaluates
+    // the same recurrence and checks the value the device used (spec_corrected counts disagreements: none, both
+    // sides evaluate the same IEEE expressions).
+    bool pipeline = true;            // DZO_TUNE_ADGD_PIPELINE=0: one host round trip per pass
+    dzo::AdgdDev *dev = nullptr;
+    double *slots = nullptr, *slots_dev = nullptr;   // pinned: 2 x 8 doubles, outcome of the last two decisions
+    hipEvent_t decided[2] = {nullptr, nullptr};
+    bool spec_pending = false;       // a pass + decision is enqueued whose outcome the host has not consumed
+    int spec_slot = 0;
+    int32_t seq = 0;                 // decisions enqueued so far (mod 2 = slot of the next one)
+    int64_t spec_adopted = 0, spec_discarded = 0, spec_corrected = 0;
 };
 
 namespace dzo {
@@ -39,14 +75,14 @@ namespace dzo {
 //   delta_point = x_new - x_old                       :145
 //   delta_gradient = g_new - g_old                    :306, :308
 //   partial sums of |delta_point|^2, |delta_gradient|^2   (:292, :294 of the next step)
-// 2 reads + 4 writes per element instead of the 16 element passes of the separate kernels.
+// 2 reads + 2 writes per element (the deltas enter the two sums only; the vectors are formed on demand from the
+// buffer pairs, see dzo_adgd_s) instead of the 16 element passes of the separate kernels.
 constexpr int kAdgdOwn = 62;
 
 template <typename T> struct AdgdFusedParams {
     int64_t n;
-    T t;                                       // -step size
-    const T *x, *g;                            // read only
-    T *x_out, *g_out, *dx, *dg;
+    const AdgdDev *st;                         // step size, which buffer pair holds the current state
+    T *x0, *g0, *x1, *g1, *x2, *g2;            // the three pairs
     double *partials;                          // [3][gridDim.x]: objective, |dx|^2, |dg|^2
     int32_t *changed;
 };
@@ -65,6 +101,13 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
     const bool halo_lane = lane == 0 || lane == 63;
     double fobj = 0, sdx = 0, sdg = 0;
     bool diff = false;
+    if (p.st->stuck) return;                                                 // (uniform: the search is over, nothing to do)
+    const T t = (T)(-p.st->t);
+    const int sel = p.st->sel;
+    const T *__restrict__ xin = sel == 0 ? p.x0 : (sel == 1 ? p.x1 : p.x2);
+    const T *__restrict__ gin = sel == 0 ? p.g0 : (sel == 1 ? p.g1 : p.g2);
+    T *__restrict__ xout = sel == 0 ? p.x1 : (sel == 1 ? p.x2 : p.x0);
+    T *__restrict__ gout = sel == 0 ? p.g1 : (sel == 1 ? p.g2 : p.g0);
     for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < rows; row += (int64_t)gridDim.x * kWaves) {
         const int64_t v = row * kAdgdOwn - 1 + lane;
         const bool valid = v >= 0 && v < nvec;
@@ -72,12 +115,12 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
         const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);          // clamped: the value is never used
         const int64_t e0 = v * N;
         T xo[N], go[N];
-        load16(p.x + vc * N, xo);                                            // halo lanes read their neighbours directly
-        load16(p.g + vc * N, go);
+        load16(xin + vc * N, xo);                                            // halo lanes read their neighbours directly
+        load16(gin + vc * N, go);
         T xn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            xn[j] = dfma(p.t, go[j], xo[j]);                               // :124
+            xn[j] = dfma(t, go[j], xo[j]);                                   // :124
             diff |= owner && !is_equal(xn[j], xo[j]);                      // :128
         }
         const T xprev = __shfl_up(xn[N - 1], 1, 64);
@@ -97,10 +140,8 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
             }
         }
         if (owner) {
-            store16_nt(p.x_out + v * N, xn);
-            store16_nt(p.g_out + v * N, gn);
-            store16_nt(p.dx + v * N, sn);
-            store16_nt(p.dg + v * N, yn);
+            store16_nt(xout + v * N, xn);
+            store16_nt(gout + v * N, gn);
         }
     }
     block_raise_flag(diff, p.changed, &lds_flag);
@@ -114,12 +155,22 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
     }
 }
 
-// fixed-order sums of the three partial arrays, the :128 / :139 decision, everything the host needs
-// straight into its pinned mirror: {f_new, -, -, status, changed, |dx|^2, |dg|^2}
+// host state -> device state (a pass that is not the continuation of the passes in flight)
+__global__ void adgd_seed_kernel(AdgdDev *st, AdgdDev v) { *st = v; }
+
+// Fixed-order sums of the three partial arrays, the :128 / :139 decision, the outcome into the host's pinned slot
+// {sum f, t used, roles used, status, changed, |dx|^2, |dg|^2, seq} -- and the state of the NEXT pass: after an
+// accepted trial the step-size recurrence of :285-299 (expression by expression as adgd_step evaluates it on
+// the host, which checks the value before it adopts the pass), after a rejected one half the step (:152).
 __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__restrict__ partials, int grid,
-                                                             int32_t *__restrict__ changed, double f_cur, int to_f32,
-                                                             double *__restrict__ host_out) {
+                                                             int32_t *__restrict__ changed, AdgdDev *__restrict__ st, int to_f32,
+                                                             double inv_sqrt_two, int64_t max_halvings,
+                                                             double *__restrict__ slot) {
     __shared__ double lds[kWaves];
+    if (st->stuck) {                                                         // (uniform)
+        if (threadIdx.x == 0) { reinterpret_cast<int32_t *>(slot + 3)[0] = 3; slot[7] = (double)st->seq; st->seq += 1; __threadfence_system(); }
+        return;
+    }
     double v[3];
     for (int c = 0; c < 3; ++c) {
         double a = 0;
@@ -127,18 +178,49 @@ __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__res
         v[c] = block_sum(a, lds);
     }
     if (threadIdx.x == 0) {
-        double f_new = v[0];
-        if (to_f32) f_new = (double)(float)f_new;
+        auto rnd = [&](double x) { return to_f32 ? (double)(float)x : x; };
+        auto root = [&](double x) { return to_f32 ? (double)sqrtf((float)x) : sqrt(x); };
+        const double f_new = rnd(v[0]);
         const int32_t ch = *changed;
-        int32_t st = 0;
-        if (ch == 0) st = 2;
-        else if (f_new < f_cur) st = 1;
+        int32_t status = 0;
+        if (ch == 0) status = 2;
+        else if (f_new < st->f_cur) status = 1;
         *changed = 0;
-        host_out[0] = v[0];
-        host_out[5] = v[1];
-        host_out[6] = v[2];
-        reinterpret_cast<int32_t *>(host_out + 3)[0] = st;
-        reinterpret_cast<int32_t *>(host_out + 4)[0] = ch;
+        slot[0] = v[0];
+        slot[1] = st->t;
+        slot[2] = (double)st->sel;
+        slot[5] = v[1];
+        slot[6] = v[2];
+        slot[7] = (double)st->seq;
+        reinterpret_cast<int32_t *>(slot + 3)[0] = status;
+        reinterpret_cast<int32_t *>(slot + 4)[0] = ch;
+        st->seq += 1;
+        if (status == 1) {
+            const double previous = st->prev, current = st->cur;             // :285-286 of the next step!
+            double next = current;                                           // :287
+            if (previous != 0.0) {                                           // (:289 asserts it; the host raises the error)
+                const double theta = rnd(current / previous);                // :290
+                next = rnd(next * root(1.0 + theta));                        // :291
+                const double dgn = root(v[2]);                               // :292
+                if (dgn != 0.0) {                                            // :293
+                    const double inv_L = rnd(root(v[1]) / dgn);              // :294
+                    const double cap = rnd(inv_sqrt_two * inv_L);
+                    next = next < cap ? next : cap;                          // :295
+                }
+            } else {
+                st->stuck = 1;
+            }
+            st->prev = current; st->cur = next; st->t = next;                // :298-299, :301
+            st->f_cur = f_new;
+            st->sel = (st->sel + 1) % 3;
+            st->halvings = 0;
+        } else if (status == 0) {
+            st->t = rnd(st->t * 0.5);                                        // :152
+            st->halvings += 1;
+            if (max_halvings > 0 && st->halvings >= max_halvings) st->stuck = 1;
+        } else {
+            st->stuck = 1;
+        }
         __threadfence_system();
     }
 }
@@ -146,23 +228,48 @@ __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__res
 static int32_t adgd_settle_entry(void *h);
 
 static void adgd_mark_unsettled(dzo_adgd_s *o) {
-    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user;
+    const bool dirty = o->cur != 0;
     if (dirty && !o->unsettled) { unsettled_add(o, adgd_settle_entry); o->unsettled = true; }
     if (!dirty && o->unsettled) { unsettled_remove(o); o->unsettled = false; }
+}
+
+// Drop the pass in flight (if any): it wrote only buffers the current state does not live in, so waiting for it
+// is all there is to do; the next pass starts from the host's state again.
+static int32_t adgd_cancel_pipeline(dzo_adgd_s *o) {
+    if (!o->spec_pending) return DZO_OK;
+    DZO_HIP(hipStreamSynchronize(o->core.stream));
+    o->spec_pending = false;
+    o->spec_discarded += 1;
+    o->core.flag_armed = true;                                               // (every decision re-arms the flag)
+    return DZO_OK;
+}
+
+// delta_point / delta_gradient as vectors (after steps on the fused pass they exist only as pair cur - pair cur-1)
+static int32_t adgd_materialize_deltas(dzo_adgd_s *o) {
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    OptCore &c = o->core;
+    if (!o->dx_lazy && !o->dg_lazy) return DZO_OK;
+    DZO_TRY(adgd_cancel_pipeline(o));
+    const int prev = (o->cur + 2) % 3;
+    // fma(-1, old, new) = new - old, rounded once: the value of :145 / :308
+    if (o->dx_lazy) DZO_DISPATCH(c.dtype, launch_axpy_oop<T>(c.stream, c.n, (T *)o->dx_buf, (T)-1, (const T *)o->xbuf[prev], (const T *)o->xbuf[o->cur]));
+    if (o->dg_lazy) DZO_DISPATCH(c.dtype, launch_axpy_oop<T>(c.stream, c.n, (T *)o->dg_buf, (T)-1, (const T *)o->gbuf[prev], (const T *)o->gbuf[o->cur]));
+    DZO_HIP(hipGetLastError());
+    o->dx_lazy = o->dg_lazy = false;
+    return DZO_OK;
 }
 
 // current_point / current_gradient back into the arrays the optimizer aliases
 static int32_t adgd_settle(dzo_adgd_s *o) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
-    const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
-    if (c.x != o->x_user) {
+    DZO_TRY(adgd_cancel_pipeline(o));
+    if (o->cur != 0) {
+        DZO_TRY(adgd_materialize_deltas(o));                                 // (pair 0 may be the old point the deltas are formed from)
+        const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
         DZO_HIP(hipMemcpyAsync(o->x_user, c.x, bytes, hipMemcpyDeviceToDevice, c.stream));
-        o->x_twin = c.x; c.x = o->x_user;
-    }
-    if (c.g != o->g_user) {
         DZO_HIP(hipMemcpyAsync(o->g_user, c.g, bytes, hipMemcpyDeviceToDevice, c.stream));
-        o->g_twin = c.g; c.g = o->g_user;
+        o->cur = 0; c.x = o->x_user; c.g = o->g_user;
     }
     adgd_mark_unsettled(o);
     return DZO_OK;
@@ -176,8 +283,8 @@ static int32_t adgd_settle_entry(void *h) {
     return DZO_OK;
 }
 
-// Eligibility of the one-pass step, INCLUDING its buffers (the twins of x and g, the second
-// delta_gradient buffer): they are allocated here, before step! changes anything, and a failed
+// Eligibility of the one-pass step, INCLUDING its buffers (two more point / gradient pairs, the device
+// state and the pinned outcome slots): they are allocated here, before step! changes anything, and a failed
 // allocation only switches the optimizer to the generic kernel sequence (which needs no extra memory)
 // instead of failing the step.
 static bool adgd_fused_ok(dzo_adgd_s *o) {
@@ -190,13 +297,17 @@ static bool adgd_fused_ok(dzo_adgd_s *o) {
     if (!o->twin) {
         const size_t padded = (size_t)((c.n + 63) / 64 * 64) * es;
         const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;             // an odd number of KiB apart
-        if (hipMalloc(&o->twin, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->twin = nullptr; o->fused = false; return false; }
-        o->x_twin = (char *)o->twin + 5 * 1024;
-        o->g_twin = (char *)o->x_twin + slot;
+        if (hipMalloc(&o->twin, 4 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->twin = nullptr; o->fused = false; return false; }
+        char *b = (char *)o->twin + 5 * 1024;
+        o->xbuf[0] = o->x_user; o->gbuf[0] = o->g_user;
+        o->xbuf[1] = b; o->gbuf[1] = b + slot; o->xbuf[2] = b + 2 * slot; o->gbuf[2] = b + 3 * slot;
     }
-    if (!o->dg_alt) {
-        const size_t bytes = (size_t)((c.n + 63) / 64 * 64) * es;
-        if (hipMalloc(&o->dg_alt, bytes) != hipSuccess) { (void)hipGetLastError(); o->dg_alt = nullptr; o->fused = false; return false; }
+    if (!o->dev) {
+        bool ok = hipMalloc((void **)&o->dev, sizeof(AdgdDev)) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&o->slots, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+        ok = ok && hipHostGetDevicePointer((void **)&o->slots_dev, o->slots, 0) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&o->decided[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); o->fused = false; return false; }
     }
     return true;
 }
@@ -213,60 +324,110 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
     AdgdFusedParams<T> fp;
     fp.n = c.n;
-    fp.x = (const T *)c.x; fp.g = (const T *)c.g; fp.x_out = (T *)o->x_twin; fp.g_out = (T *)o->g_twin;
-    // delta_gradient is written into the OTHER of two buffers and the pointers swap when the step is
-    // accepted: a step that ends stuck leaves the previous step's delta_gradient untouched, as
-    // take_backtracking_step! does (:128-130 returns before anything but delta_point was written)
-    void *dg_new = (c.dg == o->dg_buf) ? o->dg_alt : o->dg_buf;
-    fp.dx = (T *)c.dx; fp.dg = (T *)dg_new;
+    fp.st = o->dev;
+    fp.x0 = (T *)o->xbuf[0]; fp.g0 = (T *)o->gbuf[0]; fp.x1 = (T *)o->xbuf[1]; fp.g1 = (T *)o->gbuf[1];
+    fp.x2 = (T *)o->xbuf[2]; fp.g2 = (T *)o->gbuf[2];
     fp.partials = c.partials();
     fp.changed = c.flag();
     int64_t blocks = (rows + kWaves - 1) / kWaves;
     if (blocks > 1024) blocks = 1024;                                        // 3 x 1024 partials fit the workspace
     const int grid = (int)(blocks < 1 ? 1 : blocks);
-    if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
-    c.flag_armed = false;
+    const double inv_sqrt_two = c.dtype == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);
+    auto roles = [&]() { return o->cur; };                                   // the pair a pass from the CURRENT state reads
+    auto enqueue = [&](bool retry) -> int32_t {                              // one pass + its decision, outcome into slot seq & 1
+        const int slot = o->seq & 1;
+        {
+            DZO_TIMED(retry ? "adgd_fused_retry" : "adgd_fused_step", s);
+            hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
+        }
+        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), o->dev,
+                           c.dtype == DZO_F32 ? 1 : 0, inv_sqrt_two, (int64_t)c.max_halvings, o->slots_dev + 8 * slot);
+        DZO_HIP(hipGetLastError());
+        DZO_HIP(hipEventRecord(o->decided[slot], s));
+        o->seq += 1;
+        return DZO_OK;
+    };
     auto give_up = [&]() -> int32_t {                                        // :118 delta_point holds x_old when the search gives up
-        DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));
+        DZO_TRY(adgd_cancel_pipeline(o));                                    // (delta_gradient stays the previous step's: :128-130 returns
+        DZO_HIP(hipMemcpyAsync(o->dx_buf, c.x, (size_t)c.n * sizeof(T), hipMemcpyDeviceToDevice, s));   // before anything else is written)
+        o->dx_lazy = false;
         return DZO_OK;
     };
     *done = true;
     c.last_trials = 0;
     int64_t halvings = 0;
     double t = step;
-    for (bool first = true;; first = false) {                                // :121
-        fp.t = (T)(-t);
-        {
-            DZO_TIMED(first ? "adgd_fused_step" : "adgd_fused_retry", s);
-            hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
+    for (bool first = true;;) {                                              // :121
+        // a decided pass for this trial: the one already in flight, or a fresh one from the host's state
+        const bool in_flight = o->spec_pending;
+        int slot;
+        if (in_flight) {
+            slot = o->spec_slot;
+            o->spec_pending = false;
+        } else {
+            if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
+            AdgdDev v;
+            v.t = t; v.f_cur = c.f; v.prev = o->previous_step_size; v.cur = o->current_step_size;
+            v.sel = roles();
+            v.halvings = (int32_t)halvings; v.stuck = 0; v.seq = o->seq;
+            hipLaunchKernelGGL(adgd_seed_kernel, dim3(1), dim3(1), 0, s, o->dev, v);
+            slot = o->seq & 1;
+            DZO_TRY(enqueue(!first));
         }
-        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), c.f,
-                           c.dtype == DZO_F32 ? 1 : 0, c.host_dev);
         c.flag_armed = true;
-        DZO_HIP(hipGetLastError());
-        DZO_HIP(hipStreamSynchronize(s));
-        const int32_t st = reinterpret_cast<const int32_t *>(c.host + 3)[0];
-        if (st == 2) {                                                       // :128-130 (x_new == x_old bit for bit)
+        const int32_t my_seq = o->seq - 1;
+        if (o->pipeline) {                                                   // the pass after this one, whatever this one's outcome
+            o->spec_slot = o->seq & 1;
+            DZO_TRY(enqueue(false));
+            o->spec_pending = true;
+        }
+        DZO_HIP(hipEventSynchronize(o->decided[slot]));
+        const double *out = o->slots + 8 * slot;
+        if (in_flight) {
+            const int32_t st = reinterpret_cast<const int32_t *>(out + 3)[0];
+            if (st == 3) {                                                   // the device had closed the search: nothing ran
+                DZO_TRY(adgd_cancel_pipeline(o));
+                continue;                                                    // the same trial again, from the host's state
+            }
+            // The pass continued the device's own chain: it must be decision number my_seq with the buffer roles
+            // the host derives from its pointers (anything else is a bug, and the pass after it may already have
+            // written over the current state: stop).
+            DZO_REQUIRE((int32_t)out[7] == my_seq && (int)out[2] == roles(), DZO_ERR_STATE,
+                        "AdGD pipeline out of step with the host (decision %d / %d, buffer pair %d / %d)", (int)out[7], (int)my_seq, (int)out[2], roles());
+            // Its step size comes from the device-side evaluation of :285-299 / :152 -- the same IEEE expressions
+            // the host evaluates, so the two agree bit for bit; if they ever do not, the pass that ran is still a
+            // valid step! with the device's value, which then is the optimizer's step size.
+            if (out[1] != t) {
+                o->spec_corrected += 1;
+                t = out[1];
+                if (first) o->current_step_size = t;
+            }
+            o->spec_adopted += 1;
+        }
+        const int32_t status = reinterpret_cast<const int32_t *>(out + 3)[0];
+        if (status == 2) {                                                   // :128-130 (x_new == x_old bit for bit)
             DZO_TRY(give_up());
             c.is_stuck = true;
             return DZO_OK;
         }
+        DZO_REQUIRE(status == 0 || status == 1, DZO_ERR_STATE, "AdGD pass reported status %d", status);
         c.last_trials += 1;
-        if (st == 1) {                                                       // :139
-            const double f_new = round_to_dtype(c.dtype, c.host[0]);
+        if (status == 1) {                                                   // :139
+            const double f_new = round_to_dtype(c.dtype, out[0]);
             c.df = round_to_dtype(c.dtype, f_new - c.f);                     // :142-143
             c.f = f_new;                                                     // :144
-            o->norm2[0] = c.host[5]; o->norm2[1] = c.host[6];
+            o->norm2[0] = out[5]; o->norm2[1] = out[6];
             o->norms_ready = true;
-            c.dg = dg_new;                                                   // (the previous delta_gradient buffer is the next step's target)
-            std::swap(c.x, o->x_twin);                                       // the trial point and its gradient are the current ones now
-            std::swap(c.g, o->g_twin);
+            o->cur = (o->cur + 1) % 3;                                       // the trial point and its gradient are the current ones now
+            c.x = o->xbuf[o->cur]; c.g = o->gbuf[o->cur];
+            o->dx_lazy = o->dg_lazy = true;                                  // = pair cur - pair cur-1 (:145, :308), formed on demand
             adgd_mark_unsettled(o);
             o->fused_steps += 1;
             if (!first) o->fused_rejections += 1;
             return DZO_OK;
         }
         t = round_to_dtype(c.dtype, t * 0.5);                                // :152
+        first = false;
         if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
             DZO_TRY(give_up());
             c.is_stuck = true;
@@ -294,6 +455,7 @@ static int32_t adgd_step(dzo_adgd_s *o) {
     }
     const int32_t dt = c.dtype;
     const bool fused_ok = adgd_fused_ok(o);                          // (may allocate; before any state changes)
+    if (!fused_ok) DZO_TRY(adgd_cancel_pipeline(o));
     const double half = 0.5;
     const double inv_sqrt_two = dt == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);   // :283
     const double previous = o->previous_step_size;                   // :285
@@ -328,6 +490,7 @@ static int32_t adgd_step(dzo_adgd_s *o) {
             return DZO_OK;
         }
     }
+    DZO_TRY(adgd_materialize_deltas(o));                             // (the generic kernels work on the vectors)
     DZO_TRY(core_backtracking_step(c, -next, c.g));                  // :301
     if (c.is_stuck) return DZO_OK;                                   // :302-304
     DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(dt), hipMemcpyDeviceToDevice, c.stream));  // :306
@@ -373,6 +536,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     const double s0 = c.is_stuck ? 0.0 : round_to_dtype(dtype, initial_step_length / gnorm);  // :232-233
     o->current_step_size = s0; o->previous_step_size = s0;         // :241
     o->fused = getenv("DZO_TUNE_ADGD_FUSED") ? atoi(getenv("DZO_TUNE_ADGD_FUSED")) != 0 : true;
+    o->pipeline = getenv("DZO_TUNE_ADGD_PIPELINE") ? atoi(getenv("DZO_TUNE_ADGD_PIPELINE")) != 0 : true;
     *out = o;
     return DZO_OK;
 }
@@ -403,8 +567,10 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->dx_buf) (void)hipFree(o->dx_buf);
     if (o->dg_buf) (void)hipFree(o->dg_buf);
-    if (o->dg_alt) (void)hipFree(o->dg_alt);
     if (o->twin) (void)hipFree(o->twin);
+    if (o->dev) (void)hipFree(o->dev);
+    if (o->slots) (void)hipHostFree(o->slots);
+    for (int i = 0; i < 2; ++i) if (o->decided[i]) (void)hipEventDestroy(o->decided[i]);
     core_free(o->core);
     delete o;
     return DZO_OK;
@@ -413,6 +579,11 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
 int32_t dzo_adgd_set_callbacks(dzo_adgd_t o, dzo_constraint_fn constraint, dzo_objective_fn objective,
                                dzo_gradient_fn gradient, void *cb_ctx) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    {
+        DeviceScope scope(o->device);
+        std::lock_guard<std::recursive_mutex> lk(o->mu);
+        DZO_TRY(adgd_cancel_pipeline(o));
+    }
     o->core.constraint = constraint; o->core.objective = objective; o->core.gradient = gradient;
     o->core.cb_ctx = cb_ctx;
     return DZO_OK;
@@ -431,6 +602,9 @@ int32_t dzo_adgd_get_i(dzo_adgd_t o, int32_t what, int64_t *value) {
     case 2: *value = o->core.n; break;
     case 3: *value = o->fused_steps; break;
     case 4: *value = o->fused_rejections; break;
+    case 5: *value = o->spec_adopted; break;
+    case 6: *value = o->spec_discarded; break;
+    case 7: *value = o->spec_corrected; break;
     default: set_error("dzo_adgd_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;
@@ -450,6 +624,8 @@ int32_t dzo_adgd_get_s(dzo_adgd_t o, int32_t what, double *value) {
 
 int32_t dzo_adgd_get_ptr(dzo_adgd_t o, int32_t what, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
+    if (what == 1 || what == 3) DZO_TRY(adgd_materialize_deltas(o)); // after one-pass steps the two vectors are formed here
     DZO_TRY(adgd_settle(o));                                         // current_point / current_gradient ARE the caller's arrays again
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     // the caller may write through the pointer: do not trust what the fused step cached about it

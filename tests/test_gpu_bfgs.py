@@ -500,3 +500,40 @@ def test_bfgs_reset_restores_identity_and_gradient_direction():
     f = opt.current_objective_value
     opt.step()
     assert opt.current_objective_value < f
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,step0", [(4100, 0.1), (100_000, 0.1), (4100, 200.0)])
+def test_adgd_pipelined_passes_are_the_same_steps(n, step0, dtype, monkeypatch):
+    """Behind every AdGD pass the next one is enqueued before the host has seen the decision; its step size comes
+    from the device-side twin of the recurrence (src/DZOptimization.jl:285-299) or of the halving (:152).  The
+    host adopts such a pass only when the device used exactly the host's own value, so a pipelined run must be
+    the run with one host round trip per pass (DZO_TUNE_ADGD_PIPELINE=0), bit for bit -- scalars included --
+    and the passes must really have been adopted; handing out a pointer in between drops the pass in flight
+    and changes nothing either."""
+    K = 30
+    x0 = orc.rosenbrock_chain_x0(n).astype(dtype)
+    runs = {}
+    for mode in ("1", "0", "peek"):
+        monkeypatch.setenv("DZO_TUNE_ADGD_PIPELINE", "0" if mode == "0" else "1")
+        opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
+        scal = []
+        for it in range(K):
+            opt.step()
+            scal.append((opt.current_objective_value, opt.current_step_size, opt.previous_step_size, opt.iteration_count, opt.is_stuck))
+            if mode == "peek" and it % 3 == 1:
+                opt.current_point.to_host()                               # get_ptr: the pass in flight is dropped
+        runs[mode] = (scal, opt.current_point.to_host(), opt.current_gradient.to_host(), opt.delta_point.to_host(),
+                      opt.delta_gradient.to_host(), opt.fused_steps, opt.fused_rejections, opt.pipelined_passes, opt.pipeline_discards)
+        assert opt.pipeline_corrections == 0
+    a, b, c = runs["1"], runs["0"], runs["peek"]
+    for other in (b, c):
+        assert a[0] == other[0]
+        for i in (1, 2, 3, 4):
+            assert np.array_equal(a[i], other[i])
+        assert a[5:7] == other[5:7]
+    its = a[0][-1][3]                                       # (fp32 may end stuck before K steps)
+    assert a[5] == its and its >= 10
+    assert b[7] == 0 and b[8] == 0
+    assert a[7] >= its - 2 and a[8] <= 2                    # every pass but the very first was already in flight
+    assert c[8] >= min(its, K) // 3 - 1 and c[7] >= 1
