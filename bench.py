@@ -408,6 +408,7 @@ def secondary_workload(args):
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
                     "config": {"workload": f"batched BFGS, {B} instances/GPU x n={n}, chained Rosenbrock, fp64 (BASELINE configs[4])",
                                "instances_per_gpu": B, "instances_total": B * world, "active_at_end": batch.count_active(),
+                               "rccl_world_size": comm.nranks if comm is not None else None,
                                "parallelism": (f"instances sharded by rank (block partition), world size {world}; the only collective is "
                                                f"the convergence flag: {'dzo_bfgs_batch_all_done (RCCL behind the C ABI)' if comm is not None else flag.transport}, "
                                                f"{polls} polls in the timed region"),
@@ -695,6 +696,7 @@ def main():
                    "parallelism": (f"1 optimizer instance per GPU (replicas), world size {world}; convergence flag: "
                                    f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",
+                   "rccl_world_size": comm.nranks if comm is not None else None,
                    "objective_evals_per_step": round(trials / args.steps, 3), "any_stuck": any_stuck,
                    "f_start": f_start, "f_end": opt.current_objective_value, "device": info["name"]},
         "roofline": roofline, "kernels": kernels,
