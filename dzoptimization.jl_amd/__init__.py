@@ -636,6 +636,7 @@ class LBFGSOptimizer(_OptBase):
     last_step_kind = property(lambda s: s._i(10))
     single_pass_steps = property(lambda s: s._i(11))          # informational
     single_pass_rejections = property(lambda s: s._i(12))
+    single_pass_retries = property(lambda s: s._i(13))    # rejected first trials continued by a second pass at t/2
 
     def compute_step_direction(self, sync=True):
         """``compute_lbfgs_step_direction!`` (:430-451).  ``sync=False`` only enqueues the kernels (the

@@ -102,7 +102,7 @@ struct dzo_lbfgs_s {
     void *x_user = nullptr, *g_user = nullptr;
     bool unsettled = false;         // registered in the list that dzo_synchronize / dzo_memcpy_* settle
     std::recursive_mutex mu;        // a step vs a settle coming from another host thread (recursive: a callback may call a getter)
-    int64_t single_pass_steps = 0, single_pass_rejections = 0;
+    int64_t single_pass_steps = 0, single_pass_rejections = 0, single_pass_retries = 0;
     bool fused_post = true;         // use the problem's fused accept+gradient+delta kernel when it has one
     bool combine_nts = true;        // non-temporal stores for d in the combine pass
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 0, gram_bpc = 0;   // tuning knobs (DZO_TUNE_* env, dev only)
@@ -373,13 +373,9 @@ struct GramFinishParams {
 // a fixed order (value-major layout -> contiguous reads).
 // The last block (index nvals) optionally finishes the pending rho = delta_point.delta_gradient
 // of the pair pushed by the previous step (:505), saving that step a launch of its own.
-__global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
-                                                             double *__restrict__ vals, int nvals,
-                                                             const double *__restrict__ rho_partials, int rho_count,
-                                                             double *__restrict__ rho_dst, int rho_to_f32,
-                                                             const int32_t *__restrict__ gate = nullptr) {
-    __shared__ double lds[kWaves];
-    if (gate && *gate != 1) return;            // speculative launch: only after an accepted trial
+__device__ __forceinline__ void gram_reduce_body(const double *__restrict__ partials, int grid, double *__restrict__ vals, int nvals,
+                                                 const double *__restrict__ rho_partials, int rho_count,
+                                                 double *__restrict__ rho_dst, int rho_to_f32, double *lds) {
     if ((int)blockIdx.x == nvals) {
         const double r = reduce_partials_all(rho_partials, rho_count, lds);
         if (threadIdx.x == 0) rho_dst[0] = rho_to_f32 ? (double)(float)r : r;
@@ -397,6 +393,25 @@ __global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__res
     if (threadIdx.x == 0) vals[blockIdx.x] = r;
 }
 
+__global__ __launch_bounds__(kBlock) void gram_reduce_kernel(const double *__restrict__ partials, int grid,
+                                                             double *__restrict__ vals, int nvals,
+                                                             const double *__restrict__ rho_partials, int rho_count,
+                                                             double *__restrict__ rho_dst, int rho_to_f32,
+                                                             const int32_t *__restrict__ gate = nullptr) {
+    __shared__ double lds[kWaves];
+    if (gate && *gate != 1) return;            // speculative launch: only after an accepted trial
+    gram_reduce_body(partials, grid, vals, nvals, rho_partials, rho_count, rho_dst, rho_to_f32, lds);
+}
+
+// The reduction behind a single-pass step, with the step's :128 / :139 decision as one more block (index nvals):
+// one launch instead of two between the pass and gram_finish.  The sums are formed whatever the decision will be
+// (they are scratch); gram_finish, the next launch, is the one that is gated on the status this launch publishes.
+__global__ __launch_bounds__(kBlock) void gram_reduce_decide_kernel(const double *__restrict__ partials, int grid,
+                                                                    double *__restrict__ vals, int nvals, DecideArgs dec) {
+    __shared__ double lds[kWaves];
+    if ((int)blockIdx.x == nvals) { decide_body(dec, lds); return; }
+    gram_reduce_body(partials, grid, vals, nvals, nullptr, 0, nullptr, 0, lds);
+}
 // (1) refresh of the pivot row/column of the slot-indexed Gram caches from the reduced values,
 // (2) the two-loop recursion on SCALARS by one wave, lane i owning pair i:
 //     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
@@ -767,7 +782,8 @@ template <typename T> struct FusedParams {
     int64_t n;
     int k;                                     // pairs read (history before the push)
     int k_next;                                // pairs after the push = min(k + 1, m)
-    T t;                                       // first trial step size (1)
+    T t;                                       // trial step size (1; 1/2 when the pass is re-run after a rejected first trial)
+    T t_half;                                  // t/2 (rounded): the objective there rides along, obj_partials[gridDim.x + b]
     const T *x, *g;                            // current_point / current_gradient: READ ONLY in this pass
     T *x_out, *g_out;                          // the trial point and its gradient go to the twin buffers
     T *d;                                      // step_direction
@@ -812,7 +828,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     double acc[kGramValues];
 #pragma unroll
     for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
-    double fobj = 0;
+    double fobj = 0, fobj_h = 0;
     bool diff = false;
 
     // Lanes beyond either end of x read a clamped (valid) address: their values only ever act as
@@ -900,6 +916,19 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
         for (int j = 0; j < N; ++j) {
             xn[j] = dfma(p.t, q[j], xo[j]);
             diff |= owner && !is_equal(xn[j], xo[j]);
+        }
+        // ---- the objective at HALF the step rides along (:152's next candidate): if this trial is rejected the
+        //      host knows at once whether t/2 will be accepted, and then re-runs this pass with t/2
+        {
+            T xh[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) xh[j] = dfma(p.t_half, q[j], xo[j]);
+            const T xhnext = __shfl_down(xh[0], 1, 64);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
+                if (owner && e0 + j + 1 < p.n) fobj_h += rosen_term<T>(xh[j], xq);
+            }
         }
         // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
         const T xprev = __shfl_up(xn[N - 1], 1, 64);
@@ -1031,7 +1060,8 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     }
     block_raise_flag(diff, p.changed, &lds_flag);
     const double fo = block_sum(fobj, lds);
-    if (threadIdx.x == 0) p.obj_partials[blockIdx.x] = fo;
+    const double fh = block_sum(fobj_h, lds);
+    if (threadIdx.x == 0) { p.obj_partials[blockIdx.x] = fo; p.obj_partials[gridDim.x + blockIdx.x] = fh; }
 }
 
 // ---------------------------------------------------------------------------- blocked ring <-> contiguous vectors
@@ -1655,7 +1685,7 @@ static int32_t lbfgs_wolfe_search(dzo_lbfgs_s *o, bool *accepted) {
 }
 
 // one line search along o->d followed, when it succeeds, by the post-gradient phase and the push
-static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected = false) {
+static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
     OptCore &c = o->core;
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
     o->scalars_ready = false; o->gram_ready = false;      // x, g and the history are about to change
@@ -1681,7 +1711,7 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, bool first_trial_rejected =
     c.defer_delta = fused;
     c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
     c.speculative_self = o;
-    int32_t rc = core_backtracking_step(c, 1.0, o->d, first_trial_rejected);    // :473
+    int32_t rc = core_backtracking_step(c, 1.0, o->d, trials_rejected);    // :473
     const bool speculated = c.speculative_tail != nullptr;
     c.defer_delta = false;
     c.speculative_tail = nullptr;
@@ -1824,36 +1854,45 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
     if (blocks > 2 * kMaxPartialBlocks) blocks = 2 * kMaxPartialBlocks;      // objective partials live in the problem scratch
     const int grid = (int)(blocks < 1 ? 1 : blocks);
+    // The pass runs at t = 1 and, when that trial is rejected while the objective at t/2 (which rode along) is a
+    // decrease, once more at t = 1/2 -- the loop of take_backtracking_step! (:121-152) on the same kernel, x and g
+    // untouched in between.  Deeper halvings continue on the cheap trial kernels.
+    const bool retry_pass = tune("DZO_TUNE_SP_RETRY", 1) != 0;
+    double t = 1.0;
+    for (int attempt = 0;; ++attempt) {
+    fp.t = (T)t; fp.t_half = (T)round_to_dtype(c.dtype, t * 0.5);
     if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
     c.flag_armed = false;
     {
-        DZO_TIMED("lbfgs_single_pass", s);
+        DZO_TIMED(attempt == 0 ? "lbfgs_single_pass" : "lbfgs_single_pass_retry", s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
     }
-    launch_decide(c, fp.obj_partials, grid, 1.0);        // :128 / :139 on the device, outcome to pinned host memory
-    DZO_HIP(hipGetLastError());
-    DZO_HIP(hipEventRecord(c.decided, s));
     {
-        // Enqueued BEFORE the host knows the outcome, gated on the device-side decision: the scalar
-        // part of the NEXT two-loop (reduce + recurrence) on the post-push history, so the GPU has
-        // work while the host round-trips and the next step starts with its scalars ready.
+        // :128 / :139 on the device (outcome to pinned host memory) as one block of the launch that also sums the
+        // Gram partials; then, enqueued BEFORE the host knows the outcome and gated on that decision, the scalar
+        // part of the NEXT two-loop (recurrence on the post-push history), so the GPU has work while the host
+        // round-trips and the next step starts with its scalars ready.
         const int sv_newest = o->newest, sv_k = o->k;
         o->newest = o->spare(); o->k = fp.k_next;         // as lbfgs_finish_push will leave them
         double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
         {
             DZO_TIMED("lbfgs_gram_reduce", s);
-            hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * o->k), dim3(kBlock), 0, s, o->gram_partials, grid, vals,
-                               kGramValues * o->k, (const double *)nullptr, 0, (double *)nullptr, 0, (const int32_t *)c.status());
+            const int nvals = kGramValues * o->k;
+            DecideArgs da = decide_args(c, fp.obj_partials, grid, 1.0);
+            da.partials2 = fp.obj_partials + grid;        // f(x + t/2 d)
+            hipLaunchKernelGGL(gram_reduce_decide_kernel, dim3(nvals + 1), dim3(kBlock), 0, s, (const double *)o->gram_partials, grid, vals,
+                               nvals, da);
+            c.flag_armed = true;
         }
+        DZO_HIP(hipGetLastError());
         int32_t rc = gram_finish_launch(o, 0, true, vals, true, c.status());
         o->newest = sv_newest; o->k = sv_k;
         DZO_TRY(rc);
     }
-    DZO_HIP(hipEventSynchronize(c.decided));
+    DZO_TRY(core_wait_decision(c));
     // the host follows the DEVICE's decision (the gated kernels already acted on it): 0 reject, 1 accept, 2 stuck
     const int32_t status = reinterpret_cast<int32_t *>(c.host + 3)[0];
-    c.last_trials = 0;
-    o->single_pass_steps += 1;
+    if (attempt == 0) { c.last_trials = 0; o->single_pass_steps += 1; }
     if (status == 2) {                                    // :128-131 (x_new == x_old everywhere; x and g were never written)
         c.is_stuck = true;
         // the fields as take_backtracking_step! leaves them: delta_point = x_old (:118), delta_gradient
@@ -1864,7 +1903,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
         DZO_HIP(hipGetLastError());
         return DZO_OK;
     }
-    c.last_trials = 1;
+    c.last_trials += 1;
     const double f_new = round_to_dtype(c.dtype, c.host[0]);
     if (status == 1) {                                    // :139-146 (f_new < f), and the kernel already did :478-480
         c.df = round_to_dtype(c.dtype, f_new - c.f);
@@ -1879,10 +1918,19 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
         lbfgs_mark_unsettled(o);
         return DZO_OK;
     }
-    // rejected: x and g are untouched, so the reference's loop simply continues at its first halving on
-    // the two-pass kernels (whose first trial saves x_old in delta_point, :118)
-    o->single_pass_rejections += 1;
-    return lbfgs_search_and_post(o, true);
+    // rejected: x and g are untouched
+    if (attempt == 0) o->single_pass_rejections += 1;
+    const double f_half = round_to_dtype(c.dtype, c.host[1]);
+    if (attempt == 0 && retry_pass && f_half < c.f) {     // :152, and the trial at t/2 will pass :139
+        t = round_to_dtype(c.dtype, t * 0.5);
+        o->single_pass_retries += 1;
+        continue;
+    }
+    // the reference's loop continues on the two-pass kernels (whose first trial saves x_old in delta_point, :118):
+    // after this trial, and after the one at t/2 as well when its objective is already known to be no decrease
+    if (attempt == 0 && retry_pass) { c.last_trials += 1; return lbfgs_search_and_post(o, 2); }
+    return lbfgs_search_and_post(o, attempt + 1);
+    }
 }
 
 static int32_t lbfgs_step(dzo_lbfgs_s *o) {
@@ -2234,6 +2282,7 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 10: *value = o->last_step_kind; break;
     case 11: *value = o->single_pass_steps; break;
     case 12: *value = o->single_pass_rejections; break;
+    case 13: *value = o->single_pass_retries; break;
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;

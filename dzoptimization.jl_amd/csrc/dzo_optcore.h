@@ -33,6 +33,7 @@ struct OptCore {
     double *host = nullptr;       // pinned host mirror of result[8]
     double *host_dev = nullptr;   // the same buffer as the device sees it (decide_kernel writes the outcome there)
     bool flag_armed = false;      // flag() is known to be zero (decide_kernel resets it after reading)
+    double ticket = 0;            // number of the last decision launched; decide_kernel writes it to host[7] after the outcome
     int64_t max_halvings = 4096;  // build-added escape from the NaN loop
     int64_t last_trials = 0;
     bool search_open = false;     // begin_search called, first trial not yet taken
@@ -73,7 +74,61 @@ int32_t core_objective(OptCore &c, double *f_new);
 int32_t core_constraint(OptCore &c, bool *feasible);
 int32_t core_gradient(OptCore &c);
 // take_backtracking_step!(opt, step_size, dir)  :107-154
-int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, bool first_trial_rejected = false);
+int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, int trials_rejected = 0);
 void launch_decide(OptCore &c, const double *partials, int64_t count, double scale);
+int32_t core_wait_decision(OptCore &c);
+
+// The decision of take_backtracking_step! (:128, :139) as kernel arguments, so that it can also run as one more
+// block of another launch (the Gram reduction behind the single-pass step).
+struct DecideArgs {
+    double *result;            // [0] receives f_new
+    const double *partials;    // objective partials to sum in fixed order (nullptr: result[0] already holds f_new)
+    const double *partials2;   // optional second set (the objective at half the step, carried by the single pass): host_out[1]
+    int64_t count;
+    double scale;
+    int32_t *changed;
+    double f_cur;
+    int to_f32;
+    int32_t *status;
+    double *host_out;          // pinned host mirror: [0] f_new, [3] status, [4] changed, [7] ticket
+    double ticket;
+};
+DecideArgs decide_args(OptCore &c, const double *partials, int64_t count, double scale);   // (takes the next ticket)
+
+__device__ __forceinline__ void decide_body(const DecideArgs &a, double *lds) {
+    double f_new;
+    if (a.partials) {
+        double v = 0;
+        for (int64_t i = threadIdx.x; i < a.count; i += kBlock) v += a.partials[i];
+        f_new = a.scale * block_sum(v, lds);
+        if (threadIdx.x == 0) a.result[0] = f_new;
+    } else {
+        f_new = a.result[0];
+    }
+    double f_second = 0;
+    if (a.partials2) {
+        double v = 0;
+        for (int64_t i = threadIdx.x; i < a.count; i += kBlock) v += a.partials2[i];
+        f_second = a.scale * block_sum(v, lds);
+    }
+    if (threadIdx.x == 0) {
+        const double f_raw = f_new;
+        if (a.to_f32) f_new = (double)(float)f_new;
+        const int32_t ch = *a.changed;
+        int32_t st = 0;
+        if (ch == 0) st = 2;                                     // :128 isequal -> stuck
+        else if (f_new < a.f_cur) st = 1;                        // :139 strict decrease
+        *a.status = st;
+        *a.changed = 0;                                          // armed for the next trial (saves a memset launch)
+        // outcome straight into the pinned host mirror: no D->H blit kernel on the critical path
+        a.host_out[0] = f_raw;
+        a.host_out[1] = f_second;
+        reinterpret_cast<int32_t *>(a.host_out + 3)[0] = st;
+        reinterpret_cast<int32_t *>(a.host_out + 4)[0] = ch;
+        __threadfence_system();
+        a.host_out[7] = a.ticket;                                // the host spins on this word (core_wait_decision)
+        __threadfence_system();
+    }
+}
 
 }  // namespace dzo

@@ -8,6 +8,8 @@
 
 #include "dzo_optcore.h"
 
+#include <atomic>
+
 namespace dzo {
 
 template <typename T, bool VEC, bool FIRST>
@@ -64,42 +66,49 @@ __global__ __launch_bounds__(kBlock) void trial_kernel(int64_t n, T *x, T *__res
 // accepted-step tail speculatively instead of idling the GPU across a host round trip.  When
 // `partials` is given the kernel also performs the objective's final fixed-order sum (one launch
 // fewer per trial) and publishes f_new in result[0].
-__global__ __launch_bounds__(kBlock) void decide_kernel(double *__restrict__ result, const double *__restrict__ partials,
-                                                        int64_t count, double scale,
-                                                        int32_t *__restrict__ changed, double f_cur, int to_f32,
-                                                        int32_t *__restrict__ status, double *__restrict__ host_out) {
+__global__ __launch_bounds__(kBlock) void decide_kernel(DecideArgs a) {
     __shared__ double lds[kWaves];
-    double f_new;
-    if (partials) {
-        double v = 0;
-        for (int64_t i = threadIdx.x; i < count; i += kBlock) v += partials[i];
-        f_new = scale * block_sum(v, lds);
-        if (threadIdx.x == 0) result[0] = f_new;
-    } else {
-        f_new = result[0];
-    }
-    if (threadIdx.x == 0) {
-        const double f_raw = f_new;
-        if (to_f32) f_new = (double)(float)f_new;
-        const int32_t ch = *changed;
-        int32_t st = 0;
-        if (ch == 0) st = 2;                                     // :128 isequal -> stuck
-        else if (f_new < f_cur) st = 1;                          // :139 strict decrease
-        *status = st;
-        *changed = 0;                                            // armed for the next trial (saves a memset launch)
-        // outcome straight into the pinned host mirror: no D->H blit kernel on the critical path
-        host_out[0] = f_raw;
-        reinterpret_cast<int32_t *>(host_out + 3)[0] = st;
-        reinterpret_cast<int32_t *>(host_out + 4)[0] = ch;
-        __threadfence_system();
-    }
+    decide_body(a, lds);
+}
+
+DecideArgs decide_args(OptCore &c, const double *partials, int64_t count, double scale) {
+    c.ticket += 1.0;
+    DecideArgs a;
+    a.result = c.result(); a.partials = partials; a.partials2 = nullptr; a.count = count; a.scale = scale;
+    a.changed = c.flag(); a.f_cur = c.f; a.to_f32 = c.dtype == DZO_F32 ? 1 : 0;
+    a.status = c.status(); a.host_out = c.host_dev; a.ticket = c.ticket;
+    return a;
 }
 
 // device-side :128 / :139 decision; with `partials` it also finishes the objective's sum
 void launch_decide(OptCore &c, const double *partials, int64_t count, double scale) {
-    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kBlock), 0, c.stream, c.result(), partials, count, scale,
-                       c.flag(), c.f, c.dtype == DZO_F32 ? 1 : 0, c.status(), c.host_dev);
+    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kBlock), 0, c.stream, decide_args(c, partials, count, scale));
     c.flag_armed = true;
+}
+
+// Wait for the outcome of the last launch_decide.  The decision kernel writes straight into pinned host memory
+// and stamps it with a ticket, so the host spins on that word: no event record between the decision and the gated
+// kernels behind it (a barrier packet, ~5 us on the stream) and no wake-up through the runtime's signal wait.
+// Every few thousand spins the stream is queried so that a failed launch cannot hang the caller.
+int32_t core_wait_decision(OptCore &c) {
+    static const bool poll = getenv("DZO_TUNE_POLL") ? atoi(getenv("DZO_TUNE_POLL")) != 0 : true;
+    if (!poll) { DZO_HIP(hipStreamSynchronize(c.stream)); return DZO_OK; }
+    volatile const double *h = c.host;
+    for (uint64_t spins = 1;; ++spins) {
+        if (h[7] == c.ticket) break;
+        if ((spins & 0xFFFF) == 0) {
+            hipError_t e = hipStreamQuery(c.stream);
+            if (e == hipSuccess) {                                   // everything ran: the ticket must be there
+                if (h[7] == c.ticket) break;
+                set_error("the decision kernel finished without publishing its outcome");
+                return DZO_ERR_HIP;
+            }
+            if (e != hipErrorNotReady) { DZO_HIP(e); }
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return DZO_OK;
 }
 
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -122,6 +131,7 @@ int32_t core_alloc(OptCore &c) {
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     DZO_HIP(hipHostMalloc((void **)&c.host, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent));
     DZO_HIP(hipHostGetDevicePointer((void **)&c.host_dev, c.host, 0));
+    for (int i = 0; i < 8; ++i) c.host[i] = 0;
     DZO_HIP(hipEventCreateWithFlags(&c.decided, hipEventDisableTiming));
     return DZO_OK;
 }
@@ -177,9 +187,8 @@ int32_t core_trial(OptCore &c, double t, const void *dir, bool fuse_objective, i
         }
         launch_decide(c, partials, count, scale);
         DZO_HIP(hipGetLastError());
-        DZO_HIP(hipEventRecord(c.decided, s));
         DZO_TRY(c.speculative_tail(c.speculative_self, c.status()));   // gated kernels, enqueued blind
-        DZO_HIP(hipEventSynchronize(c.decided));
+        DZO_TRY(core_wait_decision(c));
     } else {
         if (fused) DZO_TRY(problem_eval_async(c.problem, s, c.x, c.result()));
         // one D->H copy brings back {f_new, misc, status, flag}
@@ -239,22 +248,24 @@ int32_t core_gradient(OptCore &c) {
     return problem_grad_async(c.problem, c.stream, c.g, c.x);
 }
 
-int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, bool first_trial_rejected) {
+int32_t core_backtracking_step(OptCore &c, double step_size, const void *dir, int trials_rejected) {
     DZO_REQUIRE(c.has_objective(), DZO_ERR_STATE, "step! needs an objective (callbacks or built-in problem)");
     int64_t halvings = 0;
-    if (!first_trial_rejected) {
+    if (trials_rejected <= 0) {
         DZO_TRY(core_begin_search(c));                           // :118
     } else {
-        // the caller already evaluated x_old + step_size*dir OUT OF PLACE (x still holds x_old) and found
-        // no decrease: continue the loop at its first halving (:151-152); the next trial is the first
-        // one that writes x, so it is the one that saves x_old in delta_point (:118)
+        // the caller already evaluated x_old + step_size*dir (and step_size/2, ...) OUT OF PLACE (x still holds
+        // x_old) and found no decrease: continue the loop after those halvings (:151-152); the next trial is the
+        // first one that writes x, so it is the one that saves x_old in delta_point (:118)
         c.search_open = true;
-        c.last_trials = 1;
-        step_size = round_to_dtype(c.dtype, step_size * 0.5);
-        if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
-            DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));   // :118
-            c.is_stuck = true;
-            return DZO_OK;
+        c.last_trials = trials_rejected;
+        for (int r = 0; r < trials_rejected; ++r) {
+            step_size = round_to_dtype(c.dtype, step_size * 0.5);
+            if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
+                DZO_HIP(hipMemcpyAsync(c.dx, c.x, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));   // :118
+                c.is_stuck = true;
+                return DZO_OK;
+            }
         }
     }
     for (;;) {                                                   // :121

@@ -794,9 +794,10 @@ def test_single_pass_free_run_matches_two_pass_free_run(monkeypatch):
 
 
 def test_single_pass_rejected_first_trials_follow_the_reference_loop():
-    """When the single pass's t = 1 trial is rejected, x and g come back from the backups and the
-    halving loop continues on the two-pass kernels (one or more further trials); every such step
-    must still reproduce the oracle's step from the same state."""
+    """When the single pass's t = 1 trial is rejected, x and g are untouched and the halving loop continues:
+    with the same pass at t = 1/2 when the objective there (which rode along) is a decrease, on the trial
+    kernels otherwise (one or more further trials); every such step must still reproduce the oracle's step
+    from the same state."""
     n, m = 250, 3
     opt, ref, _ = _gpu_and_oracle(n, m)
     seen = set()
@@ -811,6 +812,9 @@ def test_single_pass_rejected_first_trials_follow_the_reference_loop():
         assert np.allclose(opt.rho_history, ref.rho_history, rtol=1e-9)
     assert opt.single_pass_steps >= 55
     assert opt.single_pass_rejections >= 3 and {1, 2}.issubset(seen)
+    # a rejected first trial whose t/2 objective (carried by the pass) is a decrease is continued by the same pass
+    # at t/2; deeper halvings go to the trial kernels
+    assert 1 <= opt.single_pass_retries <= opt.single_pass_rejections
 
 
 def test_history_longer_than_the_single_pass_limit_switches_paths_cleanly():
