@@ -66,6 +66,11 @@ struct Context {
 // with dzo_init (or entered through a DeviceScope), the first initialised device otherwise.
 Context &ctx();
 int32_t require_init();
+// Spin until the pinned host word `*word` holds `ticket` (a kernel on `s` writes it after its results, behind a
+// system-scope fence).  Cheaper than hipStreamSynchronize / an event: no barrier packet on the stream, no wake-up
+// through the runtime's signal wait.  The stream is queried every 64 Ki spins so that a failed launch cannot hang
+// the caller.  DZO_TUNE_POLL=0: hipStreamSynchronize instead.
+int32_t wait_ticket(hipStream_t s, const double *word, double ticket);
 constexpr int kMaxDevices = 32;
 
 // Enter `device` for the lifetime of the scope (HIP's current device of this thread and the

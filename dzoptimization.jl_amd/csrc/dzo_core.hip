@@ -4,6 +4,8 @@
 
 #include "dzo_common.h"
 
+#include <atomic>
+
 namespace dzo {
 
 static thread_local char g_error[512] = "";
@@ -43,6 +45,27 @@ DeviceScope::~DeviceScope() {
     tl_device = prev_ctx;
     int cur = -1;
     if (prev_hip >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev_hip) (void)hipSetDevice(prev_hip);
+}
+
+int32_t wait_ticket(hipStream_t s, const double *word, double ticket) {
+    static const bool poll = getenv("DZO_TUNE_POLL") ? atoi(getenv("DZO_TUNE_POLL")) != 0 : true;
+    if (!poll) { DZO_HIP(hipStreamSynchronize(s)); return DZO_OK; }
+    volatile const double *h = word;
+    for (uint64_t spins = 1;; ++spins) {
+        if (*h == ticket) break;
+        if ((spins & 0xFFFF) == 0) {
+            hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) {                                   // everything ran: the ticket must be there
+                if (*h == ticket) break;
+                set_error("a kernel finished without publishing its results to the host");
+                return DZO_ERR_HIP;
+            }
+            if (e != hipErrorNotReady) { DZO_HIP(e); }
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return DZO_OK;
 }
 
 int32_t require_init() {

@@ -90,26 +90,7 @@ void launch_decide(OptCore &c, const double *partials, int64_t count, double sca
 // and stamps it with a ticket, so the host spins on that word: no event record between the decision and the gated
 // kernels behind it (a barrier packet, ~5 us on the stream) and no wake-up through the runtime's signal wait.
 // Every few thousand spins the stream is queried so that a failed launch cannot hang the caller.
-int32_t core_wait_decision(OptCore &c) {
-    static const bool poll = getenv("DZO_TUNE_POLL") ? atoi(getenv("DZO_TUNE_POLL")) != 0 : true;
-    if (!poll) { DZO_HIP(hipStreamSynchronize(c.stream)); return DZO_OK; }
-    volatile const double *h = c.host;
-    for (uint64_t spins = 1;; ++spins) {
-        if (h[7] == c.ticket) break;
-        if ((spins & 0xFFFF) == 0) {
-            hipError_t e = hipStreamQuery(c.stream);
-            if (e == hipSuccess) {                                   // everything ran: the ticket must be there
-                if (h[7] == c.ticket) break;
-                set_error("the decision kernel finished without publishing its outcome");
-                return DZO_ERR_HIP;
-            }
-            if (e != hipErrorNotReady) { DZO_HIP(e); }
-        }
-        __builtin_ia32_pause();
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return DZO_OK;
-}
+int32_t core_wait_decision(OptCore &c) { return wait_ticket(c.stream, c.host + 7, c.ticket); }
 
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

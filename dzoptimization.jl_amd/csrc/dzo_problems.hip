@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
 // values to out[0..5], flags {changed, nonzero, differs from ref} of request q to the int32 view of
 // out[8..] at 3q; flags re-armed
 __global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__restrict__ partials, int64_t count, double scale,
-                                                             double *__restrict__ out, int32_t *__restrict__ flags) {
+                                                             double *__restrict__ out, int32_t *__restrict__ flags, double ticket) {
     __shared__ double lds[kWaves];
     double v[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = threadIdx.x; i < count; i += kBlock) {
@@ -438,6 +438,8 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__res
         for (int r = 0; r < 6; ++r) out[r] = scale * sres[r];
         int32_t *ho = reinterpret_cast<int32_t *>(out + 8);
         for (int q = 0; q < 18; ++q) { ho[q] = flags[q]; flags[q] = 0; }
+        __threadfence_system();
+        out[20] = ticket;                                        // the host spins on this word (wait_ticket)
         __threadfence_system();
     }
 }
@@ -749,7 +751,7 @@ bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const voi
 // Up to three step sizes along each of two directions in one pass over A.  req[side] describes the
 // requests (inactive ones are skipped); values and flags land in result_dev (>= 17 doubles, may be
 // pinned host memory): values [0..5], int32 flags from [8].  `flags`: 18 zeroed int32 on the device.
-bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev) {
+bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev, double ticket) {
     if (!p || p->kind != DZO_PROBLEM_QUADRATIC || p->l2 != 0.0 || p->cons_on) return false;
     const int64_t n = p->n;
     if (p->scratch_doubles < 6 * n) return false;
@@ -773,7 +775,7 @@ bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const Ph
                            p->scratch, flags);
     };
     if (p->dtype == DZO_F64) launch(double{}); else launch(float{});
-    hipLaunchKernelGGL(finish_phi6_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags);
+    hipLaunchKernelGGL(finish_phi6_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags, ticket);
     return true;
 }
 
