@@ -116,7 +116,7 @@ def _barrier(world):
 
 def _kernel_bytes(name, n, k, esize):
     """ALGORITHMIC bytes per launch (DESIGN.md section d)."""
-    if name == "lbfgs_single_pass":
+    if name in ("lbfgs_single_pass", "lbfgs_single_pass_retry"):
         # one sweep per accepted step: reads s_i, y_i (2k), g, x; writes d, the trial point and its gradient
         # (twin buffers: no backups of x_old / g_old), delta_point, delta_gradient (5)
         return (2 * k + 7) * n * esize
@@ -677,9 +677,11 @@ def main():
                                           "command (separate runs, gfx950 x2 read correction), not measured in this process")
             if "lbfgs_single_pass" in table:
                 roofline["single_pass"] = {"launches": table["lbfgs_single_pass"][0],
+                                           "retry_passes": table.get("lbfgs_single_pass_retry", (0, 0))[0],
                                            "fallback_gram_passes": table.get("lbfgs_gram_pass", (0, 0))[0],
-                                           "note": "first trial rejected -> the step finishes on the two-pass kernels and the "
-                                                   "next step needs a Gram pass"}
+                                           "note": "first trial rejected: the pass runs once more at t/2 when the objective there "
+                                                   "(carried by the pass) is a decrease; otherwise the step finishes on the trial "
+                                                   "kernels and the next step needs a Gram pass"}
             if two_pass is not None:
                 roofline["two_pass"] = two_pass
 
@@ -691,8 +693,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])",
                    "n": n, "m": m, "history_full": k == m,
-                   "two_loop": ("single_pass (one sweep over the history per accepted step; gram + combine after a "
-                                "rejected first trial)" if "lbfgs_single_pass" in table else args.mode),
+                   "two_loop": ("single_pass (one sweep over the history per trial of a step; gram + combine only after "
+                                "a step that needed t <= 1/4)" if "lbfgs_single_pass" in table else args.mode),
                    "parallelism": (f"1 optimizer instance per GPU (replicas), world size {world}; convergence flag: "
                                    f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",
