@@ -217,7 +217,8 @@ int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
  * dzo_lbfgs_get_i fields 8 / 9 / 10: history resets, descent-check replacements, kind of the
  * last step (0 quasi-Newton, 1 replaced by the descent check, 2 fallback); fields 11 / 12: steps
  * taken as one sweep over the history (single-pass step) and how many of those had their first
- * trial rejected (informational);
+ * trial rejected; field 13: how many of the rejected ones were continued by the same pass at
+ * t/2 (informational);
  * dzo_lbfgs_get_s field 2: last_step_length. */
 int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t opt, int32_t descent_check, int32_t steepest_descent_fallback);
 
@@ -309,7 +310,11 @@ int32_t dzo_adgd_step(dzo_adgd_t opt);
  * gradient, both deltas and the two norms the next step's :292-294 need) that reads x and g and writes
  * the trial point and its gradient into twin buffers (6 n T of traffic); after a rejected trial the pass
  * is repeated at half the step from the untouched x and g (:151-152).
- * get_i: 0 is_stuck 1 iteration_count 2 n 3 fused steps 4 of them after a rejected first trial;
+ * get_i: 0 is_stuck 1 iteration_count 2 n 3 fused steps 4 of them after a rejected first trial
+ *        5 passes that were already in flight when their step! was called (the next pass is enqueued behind
+ *        every decision, its step size from the device-side evaluation of :285-299 / :152)
+ *        6 passes in flight that were dropped (a pointer was handed out, an option changed)
+ *        7 adopted passes whose device-side step size differed from the host's evaluation (expected 0);
  * get_s: 0 f 1 delta_f 2 current_step_size 3 previous_step_size;
  * get_ptr: 0 x 1 delta_point 2 g 3 delta_gradient.  0 and 2 are the constructor's arrays (aliased, :261)
  * for the optimizer's life: get_ptr / dzo_synchronize / dzo_memcpy_* settle the live copy into them.
