@@ -108,8 +108,9 @@ struct dzo_lbfgs_s {
     int gram_u = 4, combine_u = 4, combine_blocks_per_cu = 0, gram_bpc = 0;   // tuning knobs (DZO_TUNE_* env, dev only)
 
     int device = 0;                 // the GPU this optimizer lives on
-    int slot_of(int i) const { return ((newest - i) % (m + 1) + (m + 1)) % (m + 1); }
-    int spare() const { return (newest + 1) % (m + 1); }
+    int32_t nslots = 0;             // ring slots: m + 1 (pairs + the spare); m + 2 for a blocked ring (it may hold m + 1 POINTS + the spare)
+    int slot_of(int i) const { return ((newest - i) % nslots + nslots) % nslots; }
+    int spare() const { return (newest + 1) % nslots; }
     // layout 1 (default): ONE slab, slots interleaved s_0 y_0 s_1 y_1 ... (Y = S + stride, pair
     // stride 2*stride): consecutive streams sit an odd number of KiB apart.  layout 0: two slabs.
     int64_t pair_stride = 0;        // elements between consecutive slots of the same history
@@ -123,6 +124,13 @@ struct dzo_lbfgs_s {
     void *dx_lin = nullptr, *dg_lin = nullptr;
     bool lin_stale = false;         // dx_lin / dg_lin do not hold the newest pair (a single-pass step pushed it)
     void *export_slab = nullptr;    // contiguous copies of S[i] / Y[i] handed out by get_ptr (2 m vectors, lazily)
+    // Point ring (see lbfgs_point_pass_kernel): the blocked ring holds the last k + 1 points / gradients, slot_of(j)
+    // = point j (0 = current), pair i = point i - point i+1.  Every trial of every step is one pass; the caller's
+    // arrays (core.x / core.g stay x_user / g_user) are gathered from point 0 when the host looks.  Anything else
+    // (installed pairs, options, the split entry points, CHAIN mode) first turns the ring into the pair ring in
+    // place (lbfgs_leave_points) and continues on the kernels above.
+    bool points = false;
+    bool xg_lin_stale = false;      // point 0 is newer than the contiguous x_user / g_user
     template <typename T> T *s_slot(int slot) const {
         return blocked ? (T *)((char *)S + (size_t)(2 * slot) * dzo::kTileBytes) : (T *)S + (int64_t)slot * pair_stride;
     }
@@ -793,7 +801,8 @@ template <typename T> struct FusedParams {
     // separate stream pointers times a 64-bit row offset each do not fit the scalar register file.
     T *ring;
     uint32_t rowbytes;                         // bytes between consecutive wave-rows of the ring
-    uint32_t soff[kFusedMaxK];                 // logical pair -> byte offset of its s tile within a row (y tile: + kTileBytes)
+    uint32_t soff[kFusedMaxK + 1];             // logical pair -> byte offset of its s tile within a row (y tile: + kTileBytes);
+                                               // point ring: logical POINT j (0 = current) -> its x tile (gradient tile: + kTileBytes)
     uint32_t new_off;                          // s tile of the spare slot: delta_point / delta_gradient of this step
     double *gram_partials;                     // [kGramValues * k_next][gridDim.x], post-push order
     double *obj_partials;                      // [gridDim.x]
@@ -1064,6 +1073,268 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
     if (threadIdx.x == 0) { p.obj_partials[blockIdx.x] = fo; p.obj_partials[gridDim.x + blockIdx.x] = fh; }
 }
 
+// ---------------------------------------------------------------------------- point ring
+// The same pass over a ring that holds the last k + 1 POINTS and GRADIENTS instead of their differences: point 0
+// is current_point / current_gradient, pair i is formed in registers as s_i = X_i - X_{i+1}, y_i = G_i - G_{i+1}
+// (one subtraction per use: exactly the value the reference stored as delta_point / delta_gradient, :145, :480).
+// The trial point and its gradient ARE the new ring entries, so the pass writes three streams (d, X, G) instead
+// of five (d, x, g, delta_point, delta_gradient) and reads the same 2k + 2.  x and g are never written in place
+// (the spare slot takes the trial), so a rejected trial just runs the pass again with a smaller t.
+// FIRST: the first step! walks along the step_direction the constructor left (d0 = -(step / |g|) g, :386-387 -- a
+// public field the caller may have changed): d is read instead of formed and not written back.
+template <typename T, int K, bool FIRST = false>
+__global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams<T> p) {
+    constexpr int N = Vec16<T>::N;
+    constexpr int kOwn = kRowOwn, kLead = kRowLead;
+    __shared__ T a_s[kFusedMaxK], c_s[kFusedMaxK];
+    __shared__ double wacc[kWaves][kFusedMaxK + 1][kGramValues];
+    __shared__ double lds[kWaves];
+    __shared__ int lds_flag;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int k = p.k, kn = p.k_next;          // k <= K
+    // pairs i >= k get a zero coefficient, and the host points the table entries of the points beyond k at point
+    // k, so that those pairs are X_k - X_k = 0: every load below is unconditional straight-line code
+    if (threadIdx.x < K) {
+        a_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.alpha[threadIdx.x]) : (T)0;
+        c_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.coef[threadIdx.x]) : (T)0;
+    }
+    __syncthreads();
+    const bool scaled = k > 0;
+    const T scale = scaled ? (T)p.scale[0] : (T)1;
+    const int64_t nvec = p.n / N;
+    const int64_t rows = (nvec + kOwn - 1) / kOwn;
+    const int64_t stride = (int64_t)gridDim.x * kWaves;
+    double acc[kGramValues];
+#pragma unroll
+    for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
+    double fobj = 0, fobj_h = 0;
+    bool diff = false;
+    auto byte_offset = [&](int64_t row) -> uint32_t {           // of the lane's vector in the contiguous d
+        const int64_t v = row * kOwn - kLead + lane;
+        const int64_t vc = v < 0 ? 0 : (v >= nvec ? nvec - 1 : v);
+        return (uint32_t)(vc * (int64_t)sizeof(T) * N);
+    };
+    auto atw = [](T *base, uint32_t boff) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff); };
+    const uint32_t toff = (uint32_t)lane * 16u;
+    auto rowbase = [&](int64_t row) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)row);       // rows < 2^31 (n T < 4 GiB)
+        return reinterpret_cast<char *>(p.ring) + (uint64_t)r * p.rowbytes;
+    };
+    auto tl = [&](char *rb, uint32_t uoff) {
+        asm volatile("" : "+s"(uoff));                           // (see lbfgs_single_pass_kernel)
+        return reinterpret_cast<const T *>(rb + (uint32_t)(uoff + toff));
+    };
+    // K + 1 points and K + 1 gradients of a row; two register sets (as lbfgs_single_pass_kernel)
+    auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N]) {
+        char *rb = rowbase(row);
+#pragma unroll
+        for (int j = 0; j <= K; ++j) load16_nt(tl(rb, p.soff[j] + (uint32_t)kTileBytes), gv[j]);
+#pragma unroll
+        for (int j = K; j >= 0; --j) load16_nt(tl(rb, p.soff[j]), xv[j]);
+    };
+    auto compute = [&](int64_t row, uint32_t boff, const T (&xv)[K + 1][N], const T (&gv)[K + 1][N]) {
+        const int64_t v = row * kOwn - kLead + lane;
+        const bool valid = v >= 0 && v < nvec;
+        const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
+        const int64_t e0 = v * N;
+        // ---- d = the reference's elementwise recurrence (:438-449)
+        T q[N];
+        if constexpr (FIRST) {
+            load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(p.d) + boff), q);   // (halo lanes: their neighbours' d)
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) q[j] = gv[0][j];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const T a = a_s[i];
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[j] = dfma(a, gv[i][j] - gv[i + 1][j], q[j]);
+            }
+            if (scaled) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[j] = scale * q[j];
+            }
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) {
+                const T c = c_s[i];
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[j] = dfma(c, xv[i][j] - xv[i + 1][j], q[j]);
+            }
+        }
+        // ---- trial point (:124), change flag (:128)
+        T xn[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            xn[j] = dfma(p.t, q[j], xv[0][j]);
+            diff |= owner && !is_equal(xn[j], xv[0][j]);
+        }
+        // ---- the objective at HALF the step rides along (:152's next candidate)
+        {
+            T xh[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) xh[j] = dfma(p.t_half, q[j], xv[0][j]);
+            const T xhnext = __shfl_down(xh[0], 1, 64);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
+                if (owner && e0 + j + 1 < p.n) fobj_h += rosen_term<T>(xh[j], xq);
+            }
+        }
+        // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
+        const T xprev = __shfl_up(xn[N - 1], 1, 64);
+        const T xnext = __shfl_down(xn[0], 1, 64);
+        T gn[N], sn[N], yn[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T xp = j > 0 ? xn[(j + N - 1) % N] : xprev;
+            const T xq = j + 1 < N ? xn[(j + 1) % N] : xnext;
+            gn[j] = rosen_grad_elem<T>(e0 + j, p.n, xp, xn[j], xq);
+            sn[j] = xn[j] - xv[0][j];                               // :145
+            yn[j] = gn[j] - gv[0][j];                               // :478-480
+            if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
+        }
+        if (owner && !(p.debug_skip & 2)) {
+            if constexpr (!FIRST) store16_nt(atw(p.d, boff), q);
+            // the trial point and its gradient go straight into the spare slot's tiles; the first / last owned
+            // vector of the row is also the right / left halo copy of the neighbouring row's tile
+            char *xt = rowbase(row) + p.new_off;
+            char *gt = xt + kTileBytes;
+            store16_nt(reinterpret_cast<T *>(xt + toff), xn);
+            store16_nt(reinterpret_cast<T *>(gt + toff), gn);
+            if (lane == kLead && row > 0) {
+                store16(reinterpret_cast<T *>(xt - (int64_t)p.rowbytes + 63 * 16), xn);
+                store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gn);
+            }
+            if (lane == kLead + kOwn - 1 && row + 1 < rows) {
+                store16(reinterpret_cast<T *>(xt + p.rowbytes), xn);
+                store16(reinterpret_cast<T *>(gt + p.rowbytes), gn);
+            }
+        }
+        if (!owner) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { gn[j] = (T)0; sn[j] = (T)0; yn[j] = (T)0; }   // halos add nothing to the dots
+        }
+        // ---- dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1)
+        {
+            double t5[kGramValues] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double sx = (double)sn[j], yx = (double)yn[j], gx = (double)gn[j];
+                t5[0] = __builtin_fma(sx, gx, t5[0]);
+                t5[1] = __builtin_fma(yx, gx, t5[1]);
+                t5[2] = __builtin_fma(yx, yx, t5[2]);
+                t5[3] = __builtin_fma(yx, sx, t5[3]);
+                t5[4] = __builtin_fma(sx, yx, t5[4]);
+            }
+            double tot[kGramValues];
+            wave_sum5(t5, lane, tot);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if (i + 1 < kn && !(p.debug_skip & 1)) {
+                double t5[kGramValues] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    // the pair is formed again here rather than kept from the combine chains above: 2K difference
+                    // vectors held across the stencil would not fit the register file (the empty asm keeps the
+                    // compiler from merging the two subtractions)
+                    T xa = xv[i][j], ga = gv[i][j];
+                    asm volatile("" : "+v"(xa), "+v"(ga));
+                    const double sx = (double)(xa - xv[i + 1][j]), yx = (double)(ga - gv[i + 1][j]);
+                    T gq = gn[j], yq = yn[j], sq = sn[j];
+                    if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(gq), "+v"(yq), "+v"(sq));   // (see lbfgs_single_pass_kernel)
+                    t5[0] = __builtin_fma(sx, (double)gq, t5[0]);
+                    t5[1] = __builtin_fma(yx, (double)gq, t5[1]);
+                    t5[2] = __builtin_fma(yx, (double)yq, t5[2]);
+                    t5[3] = __builtin_fma(yx, (double)sq, t5[3]);
+                    t5[4] = __builtin_fma(sx, (double)yq, t5[4]);
+                }
+                double tot[kGramValues];
+                wave_sum5(t5, lane, tot);
+                if (lane == i + 1) {
+#pragma unroll
+                    for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
+                }
+            }
+        }
+    };
+    T xA[K + 1][N], gA[K + 1][N];
+    T xB[K + 1][N], gB[K + 1][N];
+    int64_t row = (int64_t)blockIdx.x * kWaves + wave;
+    auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };
+    uint32_t boff = byte_offset(in_range(row));
+    issue(in_range(row), xA, gA);
+    while (row < rows) {
+        int64_t nrow = row + stride;
+        uint32_t nboff = byte_offset(in_range(nrow));
+        issue(in_range(nrow), xB, gB);
+        compute(row, boff, xA, gA);
+        row = nrow; boff = nboff;
+        if (row >= rows) break;
+        nrow = row + stride;
+        nboff = byte_offset(in_range(nrow));
+        issue(in_range(nrow), xA, gA);
+        compute(row, boff, xB, gB);
+        row = nrow; boff = nboff;
+    }
+    if (lane < kn) {
+#pragma unroll
+        for (int c = 0; c < kGramValues; ++c) wacc[wave][lane][c] = acc[c];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < kn) {
+#pragma unroll
+        for (int c = 0; c < kGramValues; ++c) {
+            const double r = (wacc[0][lane][c] + wacc[1][lane][c]) + (wacc[2][lane][c] + wacc[3][lane][c]);
+            p.gram_partials[(int64_t)(lane * kGramValues + c) * gridDim.x + blockIdx.x] = r;
+        }
+    }
+    block_raise_flag(diff, p.changed, &lds_flag);
+    const double fo = block_sum(fobj, lds);
+    const double fh = block_sum(fobj_h, lds);
+    if (threadIdx.x == 0) { p.obj_partials[blockIdx.x] = fo; p.obj_partials[gridDim.x + blockIdx.x] = fh; }
+}
+
+// ring streams elementwise, tile positions included (the halo copies transform like their originals):
+// a <- a - b (point ring -> pair ring, in place)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ring_diff_kernel(int64_t rows, T *__restrict__ a, const T *__restrict__ b, int64_t rowbytes) {
+    constexpr int N = Vec16<T>::N;
+    for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = id >> 6;
+        const int pos = (int)(id & 63);
+        T *pa = reinterpret_cast<T *>(reinterpret_cast<char *>(a) + row * rowbytes + pos * 16);
+        const T *pb = reinterpret_cast<const T *>(reinterpret_cast<const char *>(b) + row * rowbytes + pos * 16);
+        T va[N], vb[N];
+        load16(pa, va); load16(pb, vb);
+#pragma unroll
+        for (int j = 0; j < N; ++j) va[j] = va[j] - vb[j];
+        store16(pa, va);
+    }
+}
+
+// contiguous vector <- stream a - stream b (delta_point / a pair of the point ring as a plain vector)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ring_gather_diff_kernel(int64_t nvec, const T *__restrict__ a, const T *__restrict__ b,
+                                                                  T *__restrict__ lin, int64_t rowbytes) {
+    constexpr int N = Vec16<T>::N;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = v / kRowOwn;
+        const int pos = (int)(v - row * kRowOwn) + kRowLead;
+        T va[N], vb[N];
+        load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(a) + row * rowbytes + pos * 16), va);
+        load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(b) + row * rowbytes + pos * 16), vb);
+#pragma unroll
+        for (int j = 0; j < N; ++j) va[j] = va[j] - vb[j];
+        store16(lin + v * N, va);
+    }
+}
+
 // ---------------------------------------------------------------------------- blocked ring <-> contiguous vectors
 // One stream of the ring (all its tiles) from / to a contiguous vector of nvec 16-B vectors.  Thread = one
 // tile position; the halo positions 0 and 63 take the neighbouring rows' edge vectors.
@@ -1237,7 +1508,7 @@ static GramFinishParams gram_finish_params(dzo_lbfgs_s *o, int pivot, bool recur
                                            const int32_t *gate) {
     GramFinishParams fp;
     fp.gate = gate;
-    fp.k = o->k; fp.m1 = o->m + 1; fp.pivot = pivot; fp.grid = 0; fp.do_recurrence = recurrence ? 1 : 0;
+    fp.k = o->k; fp.m1 = o->nslots; fp.pivot = pivot; fp.grid = 0; fp.do_recurrence = recurrence ? 1 : 0;
     fp.map = make_map(o); fp.partials = vals; fp.rho = o->rho;
     fp.rho_from_vals = rho_from_vals ? 1 : 0; fp.rho_to_f32 = o->core.dtype == DZO_F32 ? 1 : 0;
     fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
@@ -1488,10 +1759,40 @@ template <typename T> static void ring_gather(dzo_lbfgs_s *o, const void *stream
     hipLaunchKernelGGL(ring_gather_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)stream, (T *)lin, o->rowbytes);
 }
 
+template <typename T> static void ring_gather_diff(dzo_lbfgs_s *o, const void *a, const void *b, void *lin) {
+    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int grid = stream_grid(nvec, 1);
+    hipLaunchKernelGGL(ring_gather_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)a, (const T *)b, (T *)lin, o->rowbytes);
+}
+template <typename T> static void ring_diff(dzo_lbfgs_s *o, void *a, const void *b) {
+    const int grid = stream_grid(o->ring_rows * 64, 1);
+    hipLaunchKernelGGL(ring_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->ring_rows, (T *)a, (const T *)b, o->rowbytes);
+}
+
+// point ring: current_point / current_gradient into the caller's arrays (the optimizer aliases them, :393)
+static int32_t lbfgs_points_settle(dzo_lbfgs_s *o) {
+    if (!o->points || !o->xg_lin_stale) return DZO_OK;
+    DZO_TIMED("lbfgs_ring_gather", o->core.stream);
+    DZO_DISPATCH(o->core.dtype, (ring_gather<T>(o, o->s_slot_v(o->newest), o->x_user), ring_gather<T>(o, o->y_slot_v(o->newest), o->g_user)));
+    DZO_HIP(hipGetLastError());
+    o->xg_lin_stale = false;
+    return DZO_OK;
+}
+
 // delta_point / delta_gradient as contiguous vectors (blocked ring: gathered from the newest pair when a
 // single-pass step pushed it without materialising them)
 static int32_t lbfgs_refresh_lin(dzo_lbfgs_s *o) {
     if (!o->blocked || !o->lin_stale) return DZO_OK;
+    if (o->points) {                                      // pair 0 = point 0 - point 1
+        if (o->k < 1) { o->lin_stale = false; return DZO_OK; }
+        DZO_TIMED("lbfgs_ring_gather", o->core.stream);
+        const int a = o->slot_of(0), b = o->slot_of(1);
+        DZO_DISPATCH(o->core.dtype, (ring_gather_diff<T>(o, o->s_slot_v(a), o->s_slot_v(b), o->dx_lin),
+                                     ring_gather_diff<T>(o, o->y_slot_v(a), o->y_slot_v(b), o->dg_lin)));
+        DZO_HIP(hipGetLastError());
+        o->lin_stale = false;
+        return DZO_OK;
+    }
     DZO_TIMED("lbfgs_ring_gather", o->core.stream);
     DZO_DISPATCH(o->core.dtype, (ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin), ring_gather<T>(o, o->y_slot_v(o->newest), o->dg_lin)));
     DZO_HIP(hipGetLastError());
@@ -1499,14 +1800,43 @@ static int32_t lbfgs_refresh_lin(dzo_lbfgs_s *o) {
     return DZO_OK;
 }
 
+static void lbfgs_mark_unsettled(dzo_lbfgs_s *o);
+
+// Point ring -> pair ring, in place: the caller's arrays receive point 0, then slot_of(i) <- point i - point i+1
+// from the newest pair to the oldest (each subtraction reads two slots no earlier one has touched).  The pair
+// ring keeps slots, rho, Gram caches and the scalars computed behind the last decision: the pairs are the same
+// numbers.  One way only (pairs cannot be turned back into points).
+static int32_t lbfgs_leave_points(dzo_lbfgs_s *o) {
+    if (!o->points) return DZO_OK;
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    OptCore &c = o->core;
+    DZO_TRY(lbfgs_points_settle(o));
+    DZO_TRY(lbfgs_refresh_lin(o));                        // delta_point / delta_gradient while the points still exist
+    {
+        DZO_TIMED("lbfgs_ring_to_pairs", c.stream);
+        for (int i = 0; i < o->k; ++i) {
+            const int a = o->slot_of(i), b = o->slot_of(i + 1);
+            DZO_DISPATCH(c.dtype, (ring_diff<T>(o, o->s_slot_v(a), o->s_slot_v(b)), ring_diff<T>(o, o->y_slot_v(a), o->y_slot_v(b))));
+        }
+        if (o->k == 0) {                                  // an empty pair ring is a zeroed one (:366-374)
+            DZO_HIP(hipMemsetAsync(o->S, 0, (size_t)o->ring_rows * (size_t)o->rowbytes, c.stream));
+        }
+        DZO_HIP(hipGetLastError());
+    }
+    o->points = false;
+    lbfgs_mark_unsettled(o);
+    return DZO_OK;
+}
+
 // Leave the blocked layout for good (CHAIN mode walks the history as plain vectors): every live pair is
 // gathered into a slab ring, the blocked ring is freed.
 static int32_t lbfgs_unblock(dzo_lbfgs_s *o) {
     if (!o->blocked) return DZO_OK;
+    DZO_TRY(lbfgs_leave_points(o));
     OptCore &c = o->core;
     DZO_TRY(lbfgs_refresh_lin(o));
     const size_t es = dtype_size(c.dtype);
-    const int m1 = o->m + 1;
+    const int m1 = o->nslots;                               // (the slab ring keeps the slot numbering)
     const size_t slab = (size_t)m1 * (size_t)o->stride * es;
     void *ring = nullptr;
     hipError_t e = hipMalloc(&ring, 2 * slab);
@@ -1779,11 +2109,22 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
     return true;
 }
 
+// the point ring serves exactly the optimizers the single-pass step serves (and, unlike it, the first step)
+static bool points_ok(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    if (!o->points || !o->single_pass || !o->blocked || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
+    if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post || !c.problem) return false;
+    if (c.problem->kind != DZO_PROBLEM_ROSENBROCK_CHAIN || c.problem->l2 != 0.0 || c.problem->bg_on || c.problem->cons_on) return false;
+    if (o->k > kFusedMaxK || !al16v(o->d)) return false;
+    if (o->k > 0 && !o->spec_scalars) return false;       // (the scalars come from the previous pass; anything else goes through Gram passes)
+    return true;
+}
+
 // ---- aliasing of the caller's arrays (:393, :395) with twin buffers
 static int32_t lbfgs_settle_entry(void *h);
 
 static void lbfgs_mark_unsettled(dzo_lbfgs_s *o) {
-    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user;
+    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user || (o->points && o->xg_lin_stale);
     if (dirty && !o->unsettled) { unsettled_add(o, lbfgs_settle_entry); o->unsettled = true; }
     if (!dirty && o->unsettled) { unsettled_remove(o); o->unsettled = false; }
 }
@@ -1793,6 +2134,11 @@ static void lbfgs_mark_unsettled(dzo_lbfgs_s *o) {
 static int32_t lbfgs_settle(dzo_lbfgs_s *o) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
+    if (o->points) {
+        DZO_TRY(lbfgs_points_settle(o));
+        lbfgs_mark_unsettled(o);
+        return DZO_OK;
+    }
     const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
     if (c.x != o->x_user) {
         DZO_HIP(hipMemcpyAsync(o->x_user, c.x, bytes, hipMemcpyDeviceToDevice, c.stream));
@@ -1852,7 +2198,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
     if (blocks > res) blocks = res;
     if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
-    if (blocks > 2 * kMaxPartialBlocks) blocks = 2 * kMaxPartialBlocks;      // objective partials live in the problem scratch
+    if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;              // two objective partials per block in the problem scratch
     const int grid = (int)(blocks < 1 ? 1 : blocks);
     // The pass runs at t = 1 and, when that trial is rejected while the objective at t/2 (which rode along) is a
     // decrease, once more at t = 1/2 -- the loop of take_backtracking_step! (:121-152) on the same kernel, x and g
@@ -1933,6 +2279,128 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     }
 }
 
+// step! on the point ring: every trial of the step is one lbfgs_point_pass_kernel launch (t = 1, then the halvings
+// of :152 -- skipping a t/2 whose objective, carried by the previous pass, is already known to be no decrease),
+// x and g (= point 0) untouched until a trial is accepted, which makes the spare slot point 0.
+template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    constexpr int N = Vec16<T>::N;
+    const int k = o->k;
+    const int64_t nvec = c.n / N;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    if (k > 0) {
+        DZO_TRY(gram_scalars<T>(o));                      // alpha / coef / scale of THIS step (computed behind the last decision)
+        o->scalars_ready = false;
+    }                                                     // (:463: the first step walks along the step_direction the constructor left)
+    FusedParams<T> fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.n = c.n; fp.k = k; fp.k_next = k < o->m ? k + 1 : o->m;
+    fp.d = (T *)o->d;
+    fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
+    fp.new_off = (uint32_t)(2 * o->spare()) * (uint32_t)kTileBytes;
+    fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
+    for (int j = 0; j <= kFusedMaxK; ++j)                 // points beyond k: point k again (those pairs are zero)
+        fp.soff[j] = (uint32_t)(2 * o->slot_of(j < k ? j : k)) * (uint32_t)kTileBytes;
+    fp.gram_partials = o->gram_partials;
+    fp.obj_partials = c.problem->scratch;
+    fp.changed = c.flag();
+    fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
+    void (*kern)(FusedParams<T>) = k == 0 ? lbfgs_point_pass_kernel<T, 8, true>
+                                   : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
+                                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
+                                   : lbfgs_point_pass_kernel<T, 20>;
+    int64_t blocks = (rows + kWaves - 1) / kWaves;
+    const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
+    if (blocks > res) blocks = res;
+    if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
+    if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;             // two objective partials per block in the problem scratch
+    const int grid = (int)(blocks < 1 ? 1 : blocks);
+    c.last_trials = 0;
+    o->single_pass_steps += 1;
+    int64_t halvings = 0;
+    double t = 1.0;
+    for (int attempt = 0;; ++attempt) {
+        fp.t = (T)t; fp.t_half = (T)round_to_dtype(c.dtype, t * 0.5);
+        if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
+        c.flag_armed = false;
+        {
+            DZO_TIMED(attempt == 0 ? "lbfgs_single_pass" : "lbfgs_single_pass_retry", s);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
+        }
+        {
+            // decision + Gram reduction in one launch, then the gated recurrence for the next step (as
+            // lbfgs_step_single_pass)
+            const int sv_newest = o->newest, sv_k = o->k;
+            o->newest = o->spare(); o->k = fp.k_next;
+            double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
+            {
+                DZO_TIMED("lbfgs_gram_reduce", s);
+                const int nvals = kGramValues * o->k;
+                DecideArgs da = decide_args(c, fp.obj_partials, grid, 1.0);
+                da.partials2 = fp.obj_partials + grid;    // f(x + t/2 d)
+                hipLaunchKernelGGL(gram_reduce_decide_kernel, dim3(nvals + 1), dim3(kBlock), 0, s, (const double *)o->gram_partials, grid, vals,
+                                   nvals, da);
+                c.flag_armed = true;
+            }
+            DZO_HIP(hipGetLastError());
+            int32_t rc = gram_finish_launch(o, 0, true, vals, true, c.status());
+            o->newest = sv_newest; o->k = sv_k;
+            DZO_TRY(rc);
+        }
+        DZO_TRY(core_wait_decision(c));
+        const int32_t status = reinterpret_cast<int32_t *>(c.host + 3)[0];
+        if (status == 2) {                                // :128-131 (x_new == x_old everywhere)
+            c.is_stuck = true;
+            // delta_point = x_old (:118), delta_gradient still the previous step's
+            if (o->k > 0) {
+                ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
+            }
+            ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin);
+            DZO_HIP(hipGetLastError());
+            o->lin_stale = false;
+            return DZO_OK;
+        }
+        c.last_trials += 1;
+        const double f_new = round_to_dtype(c.dtype, c.host[0]);
+        if (status == 1) {                                // :139-146, and the pass already did :478-480
+            c.df = round_to_dtype(c.dtype, f_new - c.f);
+            c.f = f_new;
+            DZO_TRY(lbfgs_finish_push(o, 0, true, true, true));   // rho by the gated gram_finish; the pass wrote the new point's tiles
+            o->spec_scalars = true;
+            o->gram_ready = false;
+            o->gram_stale = 0;
+            o->xg_lin_stale = true;
+            lbfgs_mark_unsettled(o);
+            return DZO_OK;
+        }
+        // rejected (:151-152)
+        if (attempt == 0) o->single_pass_rejections += 1;
+        else o->single_pass_retries += 0;
+        auto halve = [&]() -> bool {                      // false: the halving limit ended the search
+            t = round_to_dtype(c.dtype, t * 0.5);
+            return !(c.max_halvings > 0 && ++halvings >= c.max_halvings);
+        };
+        bool go_on = halve();
+        const double f_half = round_to_dtype(c.dtype, c.host[1]);
+        if (go_on && !(f_half < c.f)) {                   // the trial at t/2 would fail :139 as well: count it and move on
+            // (its change flag: x + (t/2) d == x only when x + t d == x, which the pass has just ruled out, up to the
+            // last halvings before the limit -- there the next pass reports status 2 itself)
+            c.last_trials += 1;
+            go_on = halve();
+        }
+        if (!go_on) {                                     // build-added escape from the NaN loop
+            c.is_stuck = true;
+            ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin);
+            if (o->k > 0) ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
+            DZO_HIP(hipGetLastError());
+            o->lin_stale = false;
+            return DZO_OK;
+        }
+        o->single_pass_retries += 1;
+    }
+}
+
 static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (c.is_stuck) return DZO_OK;                        // :456-458
@@ -1945,6 +2413,10 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     }
     bool quasi = false;
     o->last_step_kind = 0;
+    if (o->points) {
+        if (points_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_points<T>(o)); }
+        DZO_TRY(lbfgs_leave_points(o));                   // an option the passes do not serve: continue on the pair ring
+    }
     if (single_pass_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_single_pass<T>(o)); }
     if (c.iteration_count > 0) {
         DZO_TRY(lbfgs_direction(o));                      // :463-471
@@ -2008,19 +2480,20 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->last_step_length = round_to_dtype(dtype, initial_step_length);   // as legacy BFGS :779
     int32_t rc = core_alloc(c);
     if (rc != DZO_OK) { delete o; return rc; }
-    const int m1 = o->m + 1;
-    const size_t slab = (size_t)m1 * (size_t)o->stride * es;
-    hipError_t e;
-#define ALLOC(ptr, bytes)                                                                          \
-    e = hipMalloc((void **)&(ptr), (bytes));                                                       \
-    if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
-    o->interleaved = tune("DZO_TUNE_INTERLEAVE", 1) != 0;
     {
         // blocked (tile-major) ring: when the constructor knows that the single-pass step applies
         const int vecn = 16 / (int)es;
         o->blocked = tl_want_blocked && tune("DZO_TUNE_BLOCKED", 1) != 0 && tune("DZO_TUNE_SINGLE_PASS", 1) != 0 &&
                      history_length <= kFusedMaxK && n % vecn == 0 && n >= 4 * vecn && (uint64_t)n * es < (1ull << 32);
     }
+    o->nslots = o->m + (o->blocked ? 2 : 1);
+    const int m1 = o->nslots;
+    const size_t slab = (size_t)m1 * (size_t)o->stride * es;
+    hipError_t e;
+#define ALLOC(ptr, bytes)                                                                          \
+    e = hipMalloc((void **)&(ptr), (bytes));                                                       \
+    if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    o->interleaved = tune("DZO_TUNE_INTERLEAVE", 1) != 0;
     if (o->blocked) {
         const int64_t nvec = n / (16 / (int64_t)es);
         o->ring_rows = (nvec + kRowOwn - 1) / kRowOwn;
@@ -2093,8 +2566,14 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
         DZO_HIP(hipMemsetAsync(o->Y, 0, slab, c.stream));
     }
-    o->k = 0; o->newest = o->m;   // spare() == 0
+    o->k = 0; o->newest = o->nslots - 1;   // spare() == 0
     o->refresh_delta_ptrs();
+    if (o->blocked && tune("DZO_TUNE_POINT_RING", 1) != 0) {
+        // point ring: the start point and its gradient are point 0
+        o->points = true;
+        DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
+        DZO_HIP(hipGetLastError());
+    }
     // :381-388
     double gnorm = 0;
     rc = dot_blocking(c.stream, n, dtype, g_dev, g_dev, c.partials(), c.host, &gnorm);
@@ -2219,6 +2698,7 @@ int32_t dzo_lbfgs_step(dzo_lbfgs_t o) {
 int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     std::lock_guard<std::recursive_mutex> lk(o->mu);
+    DZO_TRY(lbfgs_leave_points(o));                       // the standalone two-loop works on the pair ring
     // returns after the enqueue (include/dzo.h, asynchrony): step_direction is complete once a getter
     // (dzo_lbfgs_get_ptr ...) or dzo_synchronize has returned, or for work enqueued on the handle's stream
     return lbfgs_direction(o);
@@ -2226,6 +2706,7 @@ int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DZO_TRY(lbfgs_leave_points(o));                       // the host-driven step works on the contiguous arrays and the pair ring
     DZO_TRY(lbfgs_flush_rho(o));                          // a host-driven step follows: settle what the single pass deferred
     o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false;
     o->refresh_delta_ptrs();
@@ -2283,6 +2764,7 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 11: *value = o->single_pass_steps; break;
     case 12: *value = o->single_pass_rejections; break;
     case 13: *value = o->single_pass_retries; break;
+    case 14: *value = o->points ? 2 : (o->blocked ? 1 : 0); break;   // history layout: 0 slabs, 1 tile-major pairs, 2 tile-major points
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;
@@ -2343,7 +2825,12 @@ int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_d
         }
         void *dst = (char *)o->export_slab + ((what == 5 ? 0 : (size_t)o->m) + (size_t)idx) * vb;
         const void *src = what == 5 ? o->s_slot_v(o->slot_of(idx)) : o->y_slot_v(o->slot_of(idx));
-        DZO_DISPATCH(o->core.dtype, ring_gather<T>(o, src, dst));
+        if (o->points) {                                  // pair idx = point idx - point idx+1
+            const void *older = what == 5 ? o->s_slot_v(o->slot_of(idx + 1)) : o->y_slot_v(o->slot_of(idx + 1));
+            DZO_DISPATCH(o->core.dtype, ring_gather_diff<T>(o, src, older, dst));
+        } else {
+            DZO_DISPATCH(o->core.dtype, ring_gather<T>(o, src, dst));
+        }
         DZO_HIP(hipGetLastError());
         DZO_HIP(hipStreamSynchronize(o->core.stream));
         *ptr_dev = dst;
@@ -2372,8 +2859,8 @@ int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t 
     if (!out) return DZO_OK;
     DZO_TRY(lbfgs_flush_rho(o));
     DZO_HIP(hipStreamSynchronize(o->core.stream));
-    double tmp[kMaxHistory + 1];
-    DZO_HIP(hipMemcpy(tmp, o->rho, sizeof(double) * (o->m + 1), hipMemcpyDeviceToHost));
+    double tmp[kMaxHistory + 2];
+    DZO_HIP(hipMemcpy(tmp, o->rho, sizeof(double) * o->nslots, hipMemcpyDeviceToHost));
     for (int i = 0; i < o->k && i < capacity; ++i) out[i] = tmp[o->slot_of(i)];
     return DZO_OK;
 }
@@ -2394,6 +2881,11 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
+    if (o->points) {                                     // installed PAIRS: the ring is a pair ring from here on
+        DZO_TRY(lbfgs_points_settle(o));
+        o->points = false;
+        lbfgs_mark_unsettled(o);
+    }
     o->rho_pending = false;                              // the whole history (and its rho) is replaced
     o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false;
     OptCore &c = o->core;
@@ -2401,8 +2893,8 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     const size_t es = dtype_size(c.dtype);
     // pair i -> slot (k-1-i): newest = k-1 (or m when empty)
     o->k = k; o->n_alpha = k;
-    o->newest = k > 0 ? k - 1 : o->m;
-    double rho_host[kMaxHistory + 1] = {0};
+    o->newest = k > 0 ? k - 1 : o->nslots - 1;
+    double rho_host[kMaxHistory + 2] = {0};
     for (int i = 0; i < k; ++i) {
         const int slot = o->slot_of(i);
         const void *si = (const char *)S_dev + (size_t)i * c.n * es, *yi = (const char *)Y_dev + (size_t)i * c.n * es;
@@ -2423,7 +2915,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
         }
     }
     DZO_HIP(hipStreamSynchronize(s));
-    DZO_HIP(hipMemcpy(o->rho, rho_host, sizeof(double) * (o->m + 1), hipMemcpyHostToDevice));
+    DZO_HIP(hipMemcpy(o->rho, rho_host, sizeof(double) * o->nslots, hipMemcpyHostToDevice));
     // the spare slots hold delta_point / delta_gradient: zero them like a fresh optimizer (:366-374)
     o->refresh_delta_ptrs();
     o->lin_stale = false;

@@ -1033,6 +1033,8 @@ int64_t FN(orc_lbfgs_get_i)(const FN(orc_lbfgs) *o, int what) {
 T FN(orc_lbfgs_get_s)(const FN(orc_lbfgs) *o, int what) {
     return what == 0 ? o->f : what == 1 ? o->df : o->last_step_length;
 }
+/* test infrastructure: install f (and clear the stuck flag) when a test makes the oracle follow another optimizer's state */
+void FN(orc_lbfgs_set_f)(FN(orc_lbfgs) *o, T f, int32_t is_stuck) { o->f = f; o->is_stuck = is_stuck; }
 void FN(orc_lbfgs_set_safeguards)(FN(orc_lbfgs) *o, int32_t descent_check, int32_t sd_fallback) {
     o->descent_check = descent_check; o->sd_fallback = sd_fallback;
 }

@@ -102,6 +102,7 @@ def _declare(L):
         f("orc_lbfgs_step", None, [vp])
         f("orc_lbfgs_get_i", i64, [vp, C.c_int])
         f("orc_lbfgs_get_s", ct, [vp, C.c_int])
+        f("orc_lbfgs_set_f", None, [vp, ct, i32])
         f("orc_lbfgs_get_v", vp, [vp, C.c_int, C.c_int])
         f("orc_lbfgs_set_max_halvings", None, [vp, i64])
         f("orc_lbfgs_set_history", None, [vp, i32, vp, vp, vp, i64])
@@ -330,6 +331,13 @@ class LBFGS:
 
     def set_max_halvings(self, v):
         getattr(lib(), "orc_lbfgs_set_max_halvings" + self.suf)(self.h, v)
+
+    def install_state(self, x, g, f, S, Y, rho, iteration_count):
+        """Follow another optimizer: its point, gradient, objective value and (s, y) history become this one's."""
+        self.current_point[:] = x
+        self.current_gradient[:] = g
+        getattr(lib(), "orc_lbfgs_set_f" + self.suf)(self.h, f, 0)
+        self.set_history(S, Y, rho, iteration_count)
 
     # optional safeguards (off = the live reference), SURVEY.md 8(f) rows 2 and 4
     def set_safeguards(self, descent_check=False, steepest_descent_fallback=False):

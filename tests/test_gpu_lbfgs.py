@@ -932,3 +932,82 @@ def test_blocked_ring_hands_out_the_pairs_as_plain_vectors(n, m, dtype):
         assert np.array_equal(opt2.delta_point.to_host(), S[0]) and np.array_equal(opt2.delta_gradient.to_host(), Y[0])
     opt2.step()
     assert opt2.iteration_count == steps + 1 or opt2.is_stuck
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,step0", [(16, 3, 1.0), (2 * 62 * 3 + 12, 5, 1.0), (4100, 20, 1.0), (100_004, 7, 1.0), (4100, 6, 300.0)])
+def test_point_ring_steps_match_the_oracle_from_the_same_state(n, m, step0, dtype):
+    """The default optimizer on the built-in chained Rosenbrock keeps the last k + 1 POINTS and GRADIENTS tile-major
+    (ring_layout == 2) and forms the pairs in registers; every trial of a step, the first step included, is one pass.
+    The GPU optimizer runs free here (nothing is installed into it: that would turn its ring into the pair ring) and
+    the ORACLE follows: before every step it is given the GPU's point, gradient, objective value and history -- read
+    through the public getters, which gather them without leaving the point layout -- and both take the step.
+    step0 = 300 makes first trials fail (several halvings, all on the same pass)."""
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)                    # the device sums in fp64
+    try:
+        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0, m)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), step0, m)
+        assert opt.ring_layout == 2
+        tol_d = TOL_DIRECTION if dtype == np.float64 else 2e-4
+        tol_x = 1e-12 if dtype == np.float64 else 1e-6
+        seen = set()
+        for it in range(3 * m + 12):
+            k = opt.history_count
+            S = np.stack([h.to_host() for h in opt.delta_point_history]) if k else np.zeros((0, n), dtype)
+            Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n), dtype)
+            x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
+            if it > 0:
+                assert np.array_equal(S[0], x - x_prev) and np.array_equal(Y[0], g - g_prev)      # pair 0 = point 0 - point 1
+                assert np.array_equal(opt.delta_point.to_host(), S[0]) and np.array_equal(opt.delta_gradient.to_host(), Y[0])
+            ref.install_state(x, g, opt.current_objective_value, S, Y, opt.rho_history[:k], opt.iteration_count)
+            x_prev, g_prev = x, g
+            opt.step(); ref.step()
+            assert opt.ring_layout == 2
+            assert opt.is_stuck == ref.is_stuck, it
+            if ref.is_stuck:
+                break
+            assert opt.iteration_count == ref.iteration_count and opt.last_trials == ref.last_trials, it
+            seen.add(opt.last_trials)
+            assert rel(opt.step_direction.to_host(), ref.step_direction) <= tol_d, it
+            assert rel(opt.current_point.to_host(), ref.current_point) <= tol_x, it
+            assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-12 if dtype == np.float64 else 1e-5)
+        assert opt.single_pass_steps == opt.iteration_count + (1 if opt.is_stuck else 0) or opt.is_stuck
+        if step0 > 1.0:
+            assert max(seen) >= 3                         # deep halvings happened, on passes
+    finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+
+
+def test_point_ring_turns_into_the_pair_ring_without_changing_a_bit(monkeypatch):
+    """Anything the passes do not serve (installed pairs, an option, the split entry points) turns the point ring
+    into the pair ring in place; the run then continues on the pair kernels exactly as an optimizer that never was
+    a point ring would from the same state."""
+    n, m = 4100, 6
+    x0 = orc.rosenbrock_chain_x0(n)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    for _ in range(m + 3):
+        opt.step()
+    assert opt.ring_layout == 2
+    x, g, f = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value
+    S = np.stack([h.to_host() for h in opt.delta_point_history]); Y = np.stack([h.to_host() for h in opt.delta_gradient_history])
+    rho, its = opt.rho_history.copy(), opt.iteration_count
+    opt.set_safeguards(descent_check=True)                # not served by the passes
+    opt.step()
+    assert opt.ring_layout == 1
+    # the same step from the same state on an optimizer that starts as a pair ring
+    monkeypatch.setenv("DZO_TUNE_POINT_RING", "0")
+    b = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    assert b.ring_layout == 1
+    b.current_point.upload(x); b.current_gradient.upload(g); b.set_objective_value(f)
+    b.set_history(S, Y, rho, iteration_count=its)
+    b.set_safeguards(descent_check=True)
+    b.step()
+    assert opt.last_trials == b.last_trials
+    assert rel(opt.step_direction.to_host(), b.step_direction.to_host()) <= 1e-11
+    assert rel(opt.current_point.to_host(), b.current_point.to_host()) <= 1e-13
+    k = opt.history_count
+    for i in range(1, k):                                 # the converted pairs are the pairs the point ring handed out
+        assert np.array_equal(opt.delta_point_history[i].to_host(), S[i - 1])
+        assert np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i - 1])
