@@ -114,11 +114,15 @@ def _barrier(world):
     torch.cuda.synchronize()
 
 
-def _kernel_bytes(name, n, k, esize):
+def _kernel_bytes(name, n, k, esize, layout=1):
     """ALGORITHMIC bytes per launch (DESIGN.md section d)."""
     if name in ("lbfgs_single_pass", "lbfgs_single_pass_retry"):
-        # one sweep per accepted step: reads s_i, y_i (2k), g, x; writes d, the trial point and its gradient
-        # (twin buffers: no backups of x_old / g_old), delta_point, delta_gradient (5)
+        if layout == 2:
+            # point ring: reads the k + 1 points and k + 1 gradients (2k + 2), writes the trial point and its gradient
+            # into the spare slot (2); step_direction is formed on demand, the pairs in registers
+            return (2 * k + 4) * n * esize
+        # pair ring: reads s_i, y_i (2k), g, x; writes d, the trial point and its gradient (twin buffers), delta_point,
+        # delta_gradient (5)
         return (2 * k + 7) * n * esize
     if name == "lbfgs_gram_pass":
         return (2 * k + 1) * n * esize           # each s_i, y_i once, g once
@@ -653,7 +657,7 @@ def main():
     kernels = {}
     for name, (launches, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
         avg_us = 1e3 * ms / launches
-        b = _kernel_bytes(name, n, k, esize)
+        b = _kernel_bytes(name, n, k, esize, opt.ring_layout)
         kernels[name] = {"launches": launches, "avg_us": round(avg_us, 2),
                          "algorithmic_GBps": None if b is None else round(b / (avg_us * 1e-6) / 1e9, 1)}
     roofline = None
@@ -670,7 +674,7 @@ def main():
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize),
+                        "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize, opt.ring_layout),
                         "avg_launch_us": kernels[dom]["avg_us"]}
             roofline["traffic_source"] = (None if traffic is None else
                                           "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -693,8 +697,11 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])",
                    "n": n, "m": m, "history_full": k == m,
-                   "two_loop": ("single_pass (one sweep over the history per trial of a step; gram + combine only after "
-                                "a step that needed t <= 1/4)" if "lbfgs_single_pass" in table else args.mode),
+                   "two_loop": (("single_pass on the point ring (one sweep over the last k+1 points and gradients per trial of a "
+                                 "step, pairs formed in registers)" if opt.ring_layout == 2 else
+                                 "single_pass on the pair ring (one sweep over the history per trial; gram + combine only after "
+                                 "a step that needed t <= 1/4)") if "lbfgs_single_pass" in table else args.mode),
+                   "history_layout": {0: "slabs", 1: "tile-major pairs", 2: "tile-major points"}[opt.ring_layout],
                    "parallelism": (f"1 optimizer instance per GPU (replicas), world size {world}; convergence flag: "
                                    f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",

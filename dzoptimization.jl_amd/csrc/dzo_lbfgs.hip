@@ -131,6 +131,11 @@ struct dzo_lbfgs_s {
     // place (lbfgs_leave_points) and continues on the kernels above.
     bool points = false;
     bool xg_lin_stale = false;      // point 0 is newer than the contiguous x_user / g_user
+    // step_direction is not written by the passes (nothing on the point ring reads it: every trial recomputes it in
+    // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
+    bool lazy_d = true;             // DZO_TUNE_LAZY_D
+    bool d_stale = false;
+    int dview_k = 0, dview_newest = 0;
     template <typename T> T *s_slot(int slot) const {
         return blocked ? (T *)((char *)S + (size_t)(2 * slot) * dzo::kTileBytes) : (T *)S + (int64_t)slot * pair_stride;
     }
@@ -807,6 +812,7 @@ template <typename T> struct FusedParams {
     double *gram_partials;                     // [kGramValues * k_next][gridDim.x], post-push order
     double *obj_partials;                      // [gridDim.x]
     int32_t *changed;
+    int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain
 };
 
@@ -1195,20 +1201,22 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
             if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
         }
         if (owner && !(p.debug_skip & 2)) {
-            if constexpr (!FIRST) store16_nt(atw(p.d, boff), q);
+            if constexpr (!FIRST) { if (p.store_d) store16_nt(atw(p.d, boff), q); }
             // the trial point and its gradient go straight into the spare slot's tiles; the first / last owned
             // vector of the row is also the right / left halo copy of the neighbouring row's tile
             char *xt = rowbase(row) + p.new_off;
             char *gt = xt + kTileBytes;
-            store16_nt(reinterpret_cast<T *>(xt + toff), xn);
-            store16_nt(reinterpret_cast<T *>(gt + toff), gn);
-            if (lane == kLead && row > 0) {
-                store16(reinterpret_cast<T *>(xt - (int64_t)p.rowbytes + 63 * 16), xn);
-                store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gn);
-            }
-            if (lane == kLead + kOwn - 1 && row + 1 < rows) {
-                store16(reinterpret_cast<T *>(xt + p.rowbytes), xn);
-                store16(reinterpret_cast<T *>(gt + p.rowbytes), gn);
+            if (!(p.debug_skip & 64)) {
+                store16_nt(reinterpret_cast<T *>(xt + toff), xn);
+                store16_nt(reinterpret_cast<T *>(gt + toff), gn);
+                if (lane == kLead && row > 0) {
+                    store16(reinterpret_cast<T *>(xt - (int64_t)p.rowbytes + 63 * 16), xn);
+                    store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gn);
+                }
+                if (lane == kLead + kOwn - 1 && row + 1 < rows) {
+                    store16(reinterpret_cast<T *>(xt + p.rowbytes), xn);
+                    store16(reinterpret_cast<T *>(gt + p.rowbytes), gn);
+                }
             }
         }
         if (!owner) {
@@ -1801,6 +1809,7 @@ static int32_t lbfgs_refresh_lin(dzo_lbfgs_s *o) {
 }
 
 static void lbfgs_mark_unsettled(dzo_lbfgs_s *o);
+static int32_t lbfgs_materialize_d(dzo_lbfgs_s *o);
 
 // Point ring -> pair ring, in place: the caller's arrays receive point 0, then slot_of(i) <- point i - point i+1
 // from the newest pair to the oldest (each subtraction reads two slots no earlier one has touched).  The pair
@@ -1810,8 +1819,9 @@ static int32_t lbfgs_leave_points(dzo_lbfgs_s *o) {
     if (!o->points) return DZO_OK;
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
-    DZO_TRY(lbfgs_points_settle(o));
-    DZO_TRY(lbfgs_refresh_lin(o));                        // delta_point / delta_gradient while the points still exist
+    DZO_TRY(lbfgs_materialize_d(o));                      // step_direction, delta_point / delta_gradient and the caller's
+    DZO_TRY(lbfgs_points_settle(o));                      // arrays while the points still exist
+    DZO_TRY(lbfgs_refresh_lin(o));
     {
         DZO_TIMED("lbfgs_ring_to_pairs", c.stream);
         for (int i = 0; i < o->k; ++i) {
@@ -2282,6 +2292,58 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
 // step! on the point ring: every trial of the step is one lbfgs_point_pass_kernel launch (t = 1, then the halvings
 // of :152 -- skipping a t/2 whose objective, carried by the previous pass, is already known to be no decrease),
 // x and g (= point 0) untouched until a trial is accepted, which makes the spare slot point 0.
+// grid of a point pass: the resident blocks, bounded by the partial-sum buffers
+template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedParams<T>)) {
+    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    int64_t blocks = (rows + kWaves - 1) / kWaves;
+    const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
+    if (blocks > res) blocks = res;
+    if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
+    if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;             // two objective partials per block in the problem scratch
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// step_direction of the last step, on demand: the same pass once more over the view of the ring that step started
+// from (its points are all still there: the push only rotated the ring, and the slot the next pass will overwrite is
+// that view's oldest point), with the scalars that step used, writing d and nothing else.
+template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int k = o->dview_k;
+    FusedParams<T> fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.n = c.n; fp.k = k; fp.k_next = 1; fp.t = (T)1; fp.t_half = (T)0.5;
+    fp.d = (T *)o->d; fp.store_d = 1;
+    fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
+    fp.new_off = (uint32_t)(2 * o->spare()) * (uint32_t)kTileBytes;          // (never written: no tile stores in this mode)
+    fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
+    auto old_slot = [&](int j) { return ((o->dview_newest - j) % o->nslots + o->nslots) % o->nslots; };
+    for (int j = 0; j <= kFusedMaxK; ++j) fp.soff[j] = (uint32_t)(2 * old_slot(j < k ? j : k)) * (uint32_t)kTileBytes;
+    fp.gram_partials = o->gram_partials;                  // (consumed by the step's gated gram_finish; scratch here)
+    fp.obj_partials = c.problem->scratch;
+    fp.changed = c.flag();
+    fp.debug_skip = 1 | 64;                               // no pair dots, no tile stores (and with them no halo copies)
+    void (*kern)(FusedParams<T>) = o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
+                                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
+                                   : lbfgs_point_pass_kernel<T, 20>;
+    const int grid = points_grid<T>(o, kern);
+    {
+        DZO_TIMED("lbfgs_direction_on_demand", s);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
+    }
+    DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));                 // (the pass raised the change flag)
+    c.flag_armed = true;
+    DZO_HIP(hipGetLastError());
+    o->d_stale = false;
+    return DZO_OK;
+}
+static int32_t lbfgs_materialize_d(dzo_lbfgs_s *o) {
+    if (!o->points || !o->d_stale) return DZO_OK;
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    DZO_DISPATCH(o->core.dtype, return lbfgs_materialize_d_t<T>(o));
+}
+
 template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
@@ -2289,6 +2351,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     const int k = o->k;
     const int64_t nvec = c.n / N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    (void)rows;
     if (k > 0) {
         DZO_TRY(gram_scalars<T>(o));                      // alpha / coef / scale of THIS step (computed behind the last decision)
         o->scalars_ready = false;
@@ -2310,12 +2373,11 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
                                    : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
                                    : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
                                    : lbfgs_point_pass_kernel<T, 20>;
-    int64_t blocks = (rows + kWaves - 1) / kWaves;
-    const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
-    if (blocks > res) blocks = res;
-    if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
-    if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;             // two objective partials per block in the problem scratch
-    const int grid = (int)(blocks < 1 ? 1 : blocks);
+    const int grid = points_grid<T>(o, kern);
+    fp.store_d = o->lazy_d ? 0 : 1;
+    o->d_stale = false;                                   // (whatever was pending belonged to the previous step)
+    const int view_k = k, view_newest = o->newest;
+    auto direction_pending = [&]() { if (k > 0 && o->lazy_d) { o->d_stale = true; o->dview_k = view_k; o->dview_newest = view_newest; } };
     c.last_trials = 0;
     o->single_pass_steps += 1;
     int64_t halvings = 0;
@@ -2352,6 +2414,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         const int32_t status = reinterpret_cast<int32_t *>(c.host + 3)[0];
         if (status == 2) {                                // :128-131 (x_new == x_old everywhere)
             c.is_stuck = true;
+            direction_pending();
             // delta_point = x_old (:118), delta_gradient still the previous step's
             if (o->k > 0) {
                 ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
@@ -2371,6 +2434,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
             o->gram_ready = false;
             o->gram_stale = 0;
             o->xg_lin_stale = true;
+            direction_pending();
             lbfgs_mark_unsettled(o);
             return DZO_OK;
         }
@@ -2391,6 +2455,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         }
         if (!go_on) {                                     // build-added escape from the NaN loop
             c.is_stuck = true;
+            direction_pending();
             ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin);
             if (o->k > 0) ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
             DZO_HIP(hipGetLastError());
@@ -2571,6 +2636,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     if (o->blocked && tune("DZO_TUNE_POINT_RING", 1) != 0) {
         // point ring: the start point and its gradient are point 0
         o->points = true;
+        o->lazy_d = tune("DZO_TUNE_LAZY_D", 1) != 0;
         DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
         DZO_HIP(hipGetLastError());
     }
@@ -2814,6 +2880,7 @@ int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_d
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
     DZO_TRY(lbfgs_settle(o));                             // current_point / current_gradient ARE the caller's arrays again
     if (what == 1 || what == 3) DZO_TRY(lbfgs_refresh_lin(o));   // blocked ring: delta_point / delta_gradient gathered on demand
+    if (what == 4) DZO_TRY(lbfgs_materialize_d(o));              // point ring: step_direction formed on demand
     if ((what == 5 || what == 6) && o->blocked) {
         // S[i] / Y[i] of a blocked ring: a contiguous COPY of the pair's stream (read-only snapshot; use
         // dzo_lbfgs_set_history to install pairs)
@@ -2882,6 +2949,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
     if (o->points) {                                     // installed PAIRS: the ring is a pair ring from here on
+        DZO_TRY(lbfgs_materialize_d(o));
         DZO_TRY(lbfgs_points_settle(o));
         o->points = false;
         lbfgs_mark_unsettled(o);
