@@ -54,6 +54,7 @@ struct dzo_adgd_s {
     // the same recurrence and checks the value the device used (spec_corrected counts disagreements: none, both
     // sides evaluate the same IEEE expressions).
     bool pipeline = true;            // DZO_TUNE_ADGD_PIPELINE=0: one host round trip per pass
+    bool nt_stores = true;           // DZO_TUNE_ADGD_NT_STORES=0: plain stores of the trial point / gradient (measured: no difference)
     dzo::AdgdDev *dev = nullptr;
     double *slots = nullptr, *slots_dev = nullptr;   // pinned: 2 x 8 doubles, outcome of the last two decisions
     hipEvent_t decided[2] = {nullptr, nullptr};
@@ -85,6 +86,7 @@ template <typename T> struct AdgdFusedParams {
     T *x0, *g0, *x1, *g1, *x2, *g2;            // the three pairs
     double *partials;                          // [3][gridDim.x]: objective, |dx|^2, |dg|^2
     int32_t *changed;
+    int nt_stores;                             // DZO_TUNE_ADGD_NT_STORES
 };
 
 // One kernel for the first trial and for every later trial of the same step (:151-152): x and g still hold
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
             }
         }
         if (owner) {
-            store16_nt(xout + v * N, xn);
-            store16_nt(gout + v * N, gn);
+            if (p.nt_stores) { store16_nt(xout + v * N, xn); store16_nt(gout + v * N, gn); }
+            else { store16(xout + v * N, xn); store16(gout + v * N, gn); }
         }
     }
     block_raise_flag(diff, p.changed, &lds_flag);
@@ -329,6 +331,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     fp.x2 = (T *)o->xbuf[2]; fp.g2 = (T *)o->gbuf[2];
     fp.partials = c.partials();
     fp.changed = c.flag();
+    fp.nt_stores = o->nt_stores ? 1 : 0;
     int64_t blocks = (rows + kWaves - 1) / kWaves;
     if (blocks > 1024) blocks = 1024;                                        // 3 x 1024 partials fit the workspace
     const int grid = (int)(blocks < 1 ? 1 : blocks);
@@ -537,6 +540,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     o->current_step_size = s0; o->previous_step_size = s0;         // :241
     o->fused = getenv("DZO_TUNE_ADGD_FUSED") ? atoi(getenv("DZO_TUNE_ADGD_FUSED")) != 0 : true;
     o->pipeline = getenv("DZO_TUNE_ADGD_PIPELINE") ? atoi(getenv("DZO_TUNE_ADGD_PIPELINE")) != 0 : true;
+    o->nt_stores = getenv("DZO_TUNE_ADGD_NT_STORES") ? atoi(getenv("DZO_TUNE_ADGD_NT_STORES")) != 0 : true;
     *out = o;
     return DZO_OK;
 }
