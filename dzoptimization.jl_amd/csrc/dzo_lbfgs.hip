@@ -812,6 +812,7 @@ template <typename T> struct FusedParams {
     double *gram_partials;                     // [kGramValues * k_next][gridDim.x], post-push order
     double *obj_partials;                      // [gridDim.x]
     int32_t *changed;
+    int nt_tiles;                              // point ring: non-temporal stores for the new point's tiles (when they do not fit the Infinity Cache)
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain
 };
@@ -1207,11 +1208,11 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
             char *xt = rowbase(row) + p.new_off;
             char *gt = xt + kTileBytes;
             if (!(p.debug_skip & 64)) {
-                // PLAIN stores: the next pass reads these tiles first (point 0), and what of them is still in the
-                // Infinity Cache then is not fetched from HBM -- measured inside step! at n = 1e7, k = 20: 695 us
-                // against 735 us with non-temporal stores (two interleaved rounds), the opposite of the pair ring,
-                // whose five streams of non-reused outputs are better kept out of the cache
-                if (p.debug_skip & 512) {
+                // PLAIN stores while the two streams fit the Infinity Cache: the next pass reads these tiles first
+                // (point 0).  Measured inside step! at n = 1e7, k = 20: 695 us against 735 us with non-temporal
+                // stores (two interleaved rounds) -- the opposite of the pair ring, whose five streams of non-reused
+                // outputs are better kept out of the cache; at n = 3e7 (480 MB per pass) plain stores lose 8 %
+                if (p.nt_tiles) {
                     store16_nt(reinterpret_cast<T *>(xt + toff), xn);
                     store16_nt(reinterpret_cast<T *>(gt + toff), gn);
                 } else {
@@ -2384,6 +2385,10 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
                                    : lbfgs_point_pass_kernel<T, 20>;
     const int grid = points_grid<T>(o, kern);
     fp.store_d = o->lazy_d ? 0 : 1;
+    {
+        const int64_t cache_mb = tune("DZO_TUNE_POINT_PLAIN_MB", 200);       // two streams of n T bytes against the 256-MiB Infinity Cache
+        fp.nt_tiles = 2 * (int64_t)c.n * (int64_t)sizeof(T) > (cache_mb << 20) ? 1 : 0;
+    }
     o->d_stale = false;                                   // (whatever was pending belonged to the previous step)
     const int view_k = k, view_newest = o->newest;
     auto direction_pending = [&]() { if (k > 0 && o->lazy_d) { o->d_stale = true; o->dview_k = view_k; o->dview_newest = view_newest; } };
