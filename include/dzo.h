@@ -264,11 +264,11 @@ int32_t dzo_lbfgs_post_gradient(dzo_lbfgs_t opt);
  *          (idx 0 = newest, the reference's index 1)
  * Validity: 0 and 2 are the arrays the constructor was given (aliased, :393) and stay valid for the
  * optimizer's life; a get_ptr / dzo_synchronize / dzo_memcpy_* call settles the live copy into them.
- * 1, 3 and 4 are valid until the next step.  5 and 6: an optimizer made by dzo_lbfgs_create_problem on
- * the built-in chained Rosenbrock with history_length <= 20 keeps its pairs tile-major in HBM
- * ("blocked ring"); for it 5 / 6 return a contiguous COPY of the pair, valid until the next
- * step -- read-only; install pairs with dzo_lbfgs_set_history.  Every other optimizer returns the live
- * vectors of the ring. */
+ * 1, 3 and 4 are valid until the next step.  An optimizer made by dzo_lbfgs_create_problem on the
+ * built-in chained Rosenbrock with history_length <= 20 keeps its history tile-major in HBM (DESIGN.md,
+ * "blocked ring" / "point ring"): for it 1, 3, 4, 5 and 6 return contiguous COPIES formed by the call, valid
+ * until the next step -- read-only; install pairs with dzo_lbfgs_set_history.  Every other optimizer
+ * returns the live vectors. */
 int32_t dzo_lbfgs_get_i(dzo_lbfgs_t opt, int32_t what, int64_t *value);
 int32_t dzo_lbfgs_get_s(dzo_lbfgs_t opt, int32_t what, double *value);
 int32_t dzo_lbfgs_set_s(dzo_lbfgs_t opt, int32_t what, double value);
