@@ -2454,7 +2454,6 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         }
         // rejected (:151-152)
         if (attempt == 0) o->single_pass_rejections += 1;
-        else o->single_pass_retries += 0;
         auto halve = [&]() -> bool {                      // false: the halving limit ended the search
             t = round_to_dtype(c.dtype, t * 0.5);
             return !(c.max_halvings > 0 && ++halvings >= c.max_halvings);
