@@ -133,6 +133,7 @@ struct dzo_lbfgs_s {
     bool xg_lin_stale = false;      // point 0 is newer than the contiguous x_user / g_user
     // step_direction is not written by the passes (nothing on the point ring reads it: every trial recomputes it in
     // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
+    const void *stage_kern = nullptr; size_t stage_bytes = 0; bool stage_small = false;   // dynamic-LDS attribute of the point pass
     bool lazy_d = true;             // DZO_TUNE_LAZY_D
     bool d_stale = false;
     int dview_k = 0, dview_newest = 0;
@@ -813,8 +814,9 @@ template <typename T> struct FusedParams {
     double *obj_partials;                      // [gridDim.x]
     int32_t *changed;
     int nt_tiles;                              // point ring: non-temporal stores for the new point's tiles (when they do not fit the Infinity Cache)
+    int stage_rows;                            // point ring: rows whose new tiles a wave collects in LDS before it writes them in one burst
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
-    int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain
+    int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 8 = no wave butterflies (point pass), 64 = no tile stores
 };
 
 // PLAIN: ablation build with plain instead of non-temporal history loads (DZO_TUNE_SP_DEBUG bit 256,
@@ -1097,8 +1099,17 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
     __shared__ double wacc[kWaves][kFusedMaxK + 1][kGramValues];
     __shared__ double lds[kWaves];
     __shared__ int lds_flag;
+    // The new point's tiles are not written row by row: a wave collects them in its own slice of LDS and writes
+    // stage_rows rows in one burst.  HBM pays for every switch between reading and writing: with this pass's
+    // memory shape alone (tools/pointbench.hip: 42 tile reads per row, no arithmetic) the sweep takes 495 us
+    // without writes, 650 us with the two tiles written row by row and 609 us with bursts of 16 rows.
+    extern __shared__ __attribute__((aligned(16))) char stage_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int stage_rows = p.stage_rows;
+    char *stage = stage_lds + (size_t)wave * stage_rows * (2 * kTileBytes);
+    int staged = 0;
+    int64_t stage_row0 = 0;                    // the row in slot 0 of the batch being collected
     const int k = p.k, kn = p.k_next;          // k <= K
     // pairs i >= k get a zero coefficient, and the host points the table entries of the points beyond k at point
     // k, so that those pairs are X_k - X_k = 0: every load below is unconditional straight-line code
@@ -1131,6 +1142,43 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
     auto tl = [&](char *rb, uint32_t uoff) {
         asm volatile("" : "+s"(uoff));                           // (see lbfgs_single_pass_kernel)
         return reinterpret_cast<const T *>(rb + (uint32_t)(uoff + toff));
+    };
+    // the staged rows (stage_row0, stage_row0 + stride, ...) to the spare slot's tiles: the owned vectors, and the
+    // first / last owned vector of a row also as the right / left halo copy of the neighbouring row's tile.
+    // PLAIN stores while the two streams fit the Infinity Cache (the next pass reads these tiles first: measured
+    // inside step! at n = 1e7, k = 20, 695 us against 735 us with non-temporal stores -- the opposite of the pair
+    // ring, whose five streams of non-reused outputs are better kept out of the cache); non-temporal beyond
+    // (n = 3e7, 480 MB per pass: plain stores lose 8 %)
+    auto flush_stage = [&]() {
+        for (int b = 0; b < staged; ++b) {
+            const int64_t r = stage_row0 + (int64_t)b * stride;
+            const int64_t v = r * kOwn - kLead + lane;
+            const bool own = v >= 0 && v < nvec && lane >= kLead && lane < kLead + kOwn;
+            T xs[N], gs[N];
+            const char *sl = stage + (size_t)b * (2 * kTileBytes) + toff;
+            load16(reinterpret_cast<const T *>(sl), xs);
+            load16(reinterpret_cast<const T *>(sl + kTileBytes), gs);
+            if (own) {
+                char *xt = rowbase(r) + p.new_off;
+                char *gt = xt + kTileBytes;
+                if (p.nt_tiles) {
+                    store16_nt(reinterpret_cast<T *>(xt + toff), xs);
+                    store16_nt(reinterpret_cast<T *>(gt + toff), gs);
+                } else {
+                    store16(reinterpret_cast<T *>(xt + toff), xs);
+                    store16(reinterpret_cast<T *>(gt + toff), gs);
+                }
+                if (lane == kLead && r > 0) {
+                    store16(reinterpret_cast<T *>(xt - (int64_t)p.rowbytes + 63 * 16), xs);
+                    store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gs);
+                }
+                if (lane == kLead + kOwn - 1 && r + 1 < rows) {
+                    store16(reinterpret_cast<T *>(xt + p.rowbytes), xs);
+                    store16(reinterpret_cast<T *>(gt + p.rowbytes), gs);
+                }
+            }
+        }
+        staged = 0;
     };
     // K + 1 points and K + 1 gradients of a row; two register sets (as lbfgs_single_pass_kernel)
     auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N]) {
@@ -1201,32 +1249,16 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
             yn[j] = gn[j] - gv[0][j];                               // :478-480
             if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
         }
-        if (owner && !(p.debug_skip & 2)) {
-            if constexpr (!FIRST) { if (p.store_d) store16_nt(atw(p.d, boff), q); }
-            // the trial point and its gradient go straight into the spare slot's tiles; the first / last owned
-            // vector of the row is also the right / left halo copy of the neighbouring row's tile
-            char *xt = rowbase(row) + p.new_off;
-            char *gt = xt + kTileBytes;
+        if (!(p.debug_skip & 2)) {
+            if constexpr (!FIRST) { if (owner && p.store_d) store16_nt(atw(p.d, boff), q); }
             if (!(p.debug_skip & 64)) {
-                // PLAIN stores while the two streams fit the Infinity Cache: the next pass reads these tiles first
-                // (point 0).  Measured inside step! at n = 1e7, k = 20: 695 us against 735 us with non-temporal
-                // stores (two interleaved rounds) -- the opposite of the pair ring, whose five streams of non-reused
-                // outputs are better kept out of the cache; at n = 3e7 (480 MB per pass) plain stores lose 8 %
-                if (p.nt_tiles) {
-                    store16_nt(reinterpret_cast<T *>(xt + toff), xn);
-                    store16_nt(reinterpret_cast<T *>(gt + toff), gn);
-                } else {
-                    store16(reinterpret_cast<T *>(xt + toff), xn);
-                    store16(reinterpret_cast<T *>(gt + toff), gn);
-                }
-                if (lane == kLead && row > 0) {
-                    store16(reinterpret_cast<T *>(xt - (int64_t)p.rowbytes + 63 * 16), xn);
-                    store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gn);
-                }
-                if (lane == kLead + kOwn - 1 && row + 1 < rows) {
-                    store16(reinterpret_cast<T *>(xt + p.rowbytes), xn);
-                    store16(reinterpret_cast<T *>(gt + p.rowbytes), gn);
-                }
+                // the trial point and its gradient into this wave's LDS slice (every lane: the slice is private to
+                // the wave, no barrier); they reach the spare slot's tiles in flush_stage()
+                if (staged == 0) stage_row0 = row;
+                char *sl = stage + (size_t)staged * (2 * kTileBytes) + toff;
+                store16(reinterpret_cast<T *>(sl), xn);
+                store16(reinterpret_cast<T *>(sl + kTileBytes), gn);
+                staged += 1;
             }
         }
         if (!owner) {
@@ -1273,7 +1305,8 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
                     t5[4] = __builtin_fma(sx, (double)yq, t5[4]);
                 }
                 double tot[kGramValues];
-                wave_sum5(t5, lane, tot);
+                if (p.debug_skip & 8) { for (int c = 0; c < kGramValues; ++c) tot[c] = t5[c]; }   // (ablation: no butterfly)
+                else wave_sum5(t5, lane, tot);
                 if (lane == i + 1) {
 #pragma unroll
                     for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
@@ -1292,14 +1325,17 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
         uint32_t nboff = byte_offset(in_range(nrow));
         issue(in_range(nrow), xB, gB);
         compute(row, boff, xA, gA);
+        if (staged >= stage_rows) flush_stage();
         row = nrow; boff = nboff;
         if (row >= rows) break;
         nrow = row + stride;
         nboff = byte_offset(in_range(nrow));
         issue(in_range(nrow), xA, gA);
         compute(row, boff, xB, gB);
+        if (staged >= stage_rows) flush_stage();
         row = nrow; boff = nboff;
     }
+    flush_stage();
     if (lane < kn) {
 #pragma unroll
         for (int c = 0; c < kGramValues; ++c) wacc[wave][lane][c] = acc[c];
@@ -2334,6 +2370,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
     fp.debug_skip = 1 | 64;                               // no pair dots, no tile stores (and with them no halo copies)
+    fp.stage_rows = 1;
     void (*kern)(FusedParams<T>) = o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
                                    : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
                                    : lbfgs_point_pass_kernel<T, 20>;
@@ -2389,6 +2426,23 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         const int64_t cache_mb = tune("DZO_TUNE_POINT_PLAIN_MB", 200);       // two streams of n T bytes against the 256-MiB Infinity Cache
         fp.nt_tiles = 2 * (int64_t)c.n * (int64_t)sizeof(T) > (cache_mb << 20) ? 1 : 0;
     }
+    // rows of new tiles a wave collects in LDS before it writes them (2 KiB per row and wave; the whole 160-KiB LDS
+    // of a CU is this one block's)
+    fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", 16);
+    if (fp.stage_rows < 1) fp.stage_rows = 1;
+    if (fp.stage_rows > 18) fp.stage_rows = 18;
+    size_t stage_bytes = (size_t)kWaves * fp.stage_rows * 2 * kTileBytes;
+    if (o->stage_kern != (const void *)kern || o->stage_bytes != stage_bytes) {   // (once per kernel and size)
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess) {
+            (void)hipGetLastError();                      // a device that does not grant it: stay within the default 64 KiB
+            o->stage_small = true;
+        }
+        o->stage_kern = (const void *)kern; o->stage_bytes = stage_bytes;
+    }
+    if (o->stage_small && fp.stage_rows > 7) {
+        fp.stage_rows = 7;
+        stage_bytes = (size_t)kWaves * fp.stage_rows * 2 * kTileBytes;
+    }
     o->d_stale = false;                                   // (whatever was pending belonged to the previous step)
     const int view_k = k, view_newest = o->newest;
     auto direction_pending = [&]() { if (k > 0 && o->lazy_d) { o->d_stale = true; o->dview_k = view_k; o->dview_newest = view_newest; } };
@@ -2402,7 +2456,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         c.flag_armed = false;
         {
             DZO_TIMED(attempt == 0 ? "lbfgs_single_pass" : "lbfgs_single_pass_retry", s);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), stage_bytes, s, fp);
         }
         {
             // decision + Gram reduction in one launch, then the gated recurrence for the next step (as

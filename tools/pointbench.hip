@@ -1,0 +1,95 @@
+// pointbench.hip -- what the MEMORY SHAPE of the point pass costs without its arithmetic (dev tool).
+//   hipcc -O3 --offload-arch=gfx950 -o tools/bin/pointbench tools/pointbench.hip && tools/bin/pointbench
+// Ring [row][slot 0..21][x tile | g tile][1 KiB]; one wave per SIMD; per wave-row all 42 tiles of slots 0..20 are
+// loaded (non-temporal, 16 B per lane) into one of two register sets while the other set is "computed" (summed,
+// plus SPIN dependent fma per loaded vector to stand in for the real work), then W of the two tiles of slot 21
+// are stored (plain or non-temporal).  Reports the time of one sweep over rows = n / (2 * 62) and the bandwidth.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef double v2 __attribute__((ext_vector_type(2)));
+constexpr int kTiles = 42, kRowBytes = 44 * 1024;
+
+template <int W, bool NTS, int SPIN, int BATCH = 1>
+__global__ __launch_bounds__(256, 1) void sweep(char *ring, long rows, double *sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long stride = (long)gridDim.x * 4;
+    v2 A[kTiles], B[kTiles];
+    double acc = 0;
+    auto issue = [&](long row, v2 (&r)[kTiles]) {
+        const char *rb = ring + (unsigned long)__builtin_amdgcn_readfirstlane((int)row) * kRowBytes + lane * 16;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) r[t] = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(rb + t * 1024));
+    };
+    auto compute = [&](long row, v2 (&r)[kTiles]) {
+        v2 s = {0, 0};
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            v2 v = r[t];
+#pragma unroll
+            for (int k = 0; k < SPIN; ++k) { s.x = __builtin_fma(v.x, 1.0000001, s.x); s.y = __builtin_fma(v.y, 0.9999999, s.y); }
+            if (SPIN == 0) { s.x += v.x; s.y += v.y; }
+        }
+        if (BATCH == 1) {
+            char *wb = ring + (unsigned long)__builtin_amdgcn_readfirstlane((int)row) * kRowBytes + 42 * 1024 + lane * 16;
+            if (lane >= 1 && lane < 63) {
+                if (W >= 1) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb)); else *reinterpret_cast<v2 *>(wb) = s; }
+                if (W >= 2) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb + 1024)); else *reinterpret_cast<v2 *>(wb + 1024) = s; }
+            }
+        } else {
+            // the outputs of BATCH consecutive rows of this wave written together (as if staged in LDS)
+            const long it = (row - ((long)blockIdx.x * 4 + wave)) / stride;
+            if (it % BATCH == BATCH - 1) {
+                for (int b = 0; b < BATCH; ++b) {
+                    const long r = row - (long)b * stride;
+                    char *wb = ring + (unsigned long)__builtin_amdgcn_readfirstlane((int)r) * kRowBytes + 42 * 1024 + lane * 16;
+                    if (lane >= 1 && lane < 63) {
+                        if (W >= 1) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb)); else *reinterpret_cast<v2 *>(wb) = s; }
+                        if (W >= 2) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb + 1024)); else *reinterpret_cast<v2 *>(wb + 1024) = s; }
+                    }
+                }
+            }
+        }
+        acc += s.x + s.y;
+    };
+    long row = (long)blockIdx.x * 4 + wave;
+    auto clampr = [&](long r) { return r < rows ? r : rows - 1; };
+    issue(clampr(row), A);
+    while (row < rows) {
+        issue(clampr(row + stride), B);
+        compute(row, A);
+        row += stride;
+        if (row >= rows) break;
+        issue(clampr(row + stride), A);
+        compute(row, B);
+        row += stride;
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
+template <typename F> static double time_us(F f, int reps = 8) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return 1e3 * ms / reps;
+}
+
+int main() {
+    const long n = 10000000, nvec = n / 2, rows = (nvec + 61) / 62;
+    char *ring; double *sink;
+    CK(hipMalloc(&ring, (size_t)rows * kRowBytes)); CK(hipMalloc(&sink, 64));
+    CK(hipMemset(ring, 0, (size_t)rows * kRowBytes)); CK(hipDeviceSynchronize());
+    const double rd = (double)rows * kTiles * 1024, wr1 = (double)rows * 992;
+#define RUN(W, NTS, SPIN) { double us = time_us([&] { hipLaunchKernelGGL((sweep<W, NTS, SPIN>), dim3(256), dim3(256), 0, 0, ring, rows, sink); }); \
+        printf("42 tile reads + %d tile writes (%s), %2d fma per vector: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", 2 * SPIN, us, (rd + W * wr1) / us / 1e3); }
+#define RUNB(W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep<W, NTS, SPIN, BATCH>), dim3(256), dim3(256), 0, 0, ring, rows, sink); }); \
+        printf("42 tile reads + %d tile writes (%s) in batches of %2d rows, %2d fma per vector: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", BATCH, 2 * SPIN, us, (rd + W * wr1) / us / 1e3); }
+    RUNB(2, false, 8, 4) RUNB(2, false, 8, 8) RUNB(2, false, 8, 16) RUNB(2, true, 8, 8) RUNB(2, true, 8, 16)
+    RUN(0, true, 0) RUN(1, true, 0) RUN(2, true, 0) RUN(1, false, 0) RUN(2, false, 0)
+    RUN(0, true, 8) RUN(2, true, 8) RUN(2, false, 8)
+    RUN(0, true, 24) RUN(2, true, 24) RUN(2, false, 24)
+    RUN(0, true, 48) RUN(2, false, 48)
+    return 0;
+}
