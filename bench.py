@@ -103,7 +103,18 @@ def _make_comm(dzo, world):
     (two ranks on one GPU, which RCCL refuses) keeps torch.distributed for the flag."""
     if world <= 1 or os.environ.get("BENCH_DIST_BACKEND", "nccl") != "nccl":
         return None
-    return dzo.Comm.from_torch_distributed()
+    import torch
+    import torch.distributed as dist
+    comm, ok = None, 1
+    try:
+        comm = dzo.Comm.from_torch_distributed()
+    except Exception as e:                                # (keep the run alive: the flag then travels over torch.distributed)
+        print(f"[bench] rank {dist.get_rank()}: RCCL communicator behind the C ABI unavailable ({e}); "
+              f"falling back to torch.distributed for the convergence flag", file=sys.stderr)
+        ok = 0
+    agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)         # all ranks use the same transport
+    return comm if int(agreed.item()) == 1 else None
 
 
 def _barrier(world):
