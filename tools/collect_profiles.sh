@@ -16,6 +16,22 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w
 echo "write done"
 python3 tools/summarize_profile.py $TAG $OUT/trace $OUT/fetch $OUT/write
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) profiles/${TAG}_rocprofv3_kernel_stats_raw.csv
+python3 - "$TAG" <<'PY'
+# the two-pass leg's kernels (Gram pass, combine, reduce, finish) with their PMC traffic, as one small table
+import csv, json, sys
+tag = sys.argv[1]
+rows = list(csv.DictReader(open(f'profiles/{tag}_kernel_stats.csv')))
+pmc = json.load(open(f'profiles/{tag}_pmc.json'))
+keep = [r for r in rows if r['kernel'].startswith('gram_pass_lanes_kernel<double, true, 4, false>') or r['kernel'].startswith('combine_kernel<double')
+        or r['kernel'] in ('gram_reduce_kernel', 'gram_finish_kernel')]
+with open(f'profiles/{tag}_two_pass_kernel_stats.csv', 'w') as f:
+    w = csv.DictWriter(f, fieldnames=list(keep[0].keys()) + ['pmc_read_bytes_per_launch', 'pmc_write_bytes_per_launch'])
+    w.writeheader()
+    for r in keep:
+        p = pmc.get(r['kernel'], {})
+        r['pmc_read_bytes_per_launch'] = p.get('read_bytes_per_launch', ''); r['pmc_write_bytes_per_launch'] = p.get('write_bytes_per_launch', '')
+        w.writerow(r)
+PY
 python3 bench.py > profiles/${TAG}_bench_line.json 2> $OUT/bench.err
 echo "bench line done"
 for w in bfgs_dense bfgs_batched lbfgs_lse_f32; do python3 bench.py --workload $w > profiles/${TAG}_bench_$w.json 2> $OUT/bench_$w.err; echo "$w done"; done
