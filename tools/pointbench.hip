@@ -12,7 +12,7 @@
 typedef double v2 __attribute__((ext_vector_type(2)));
 constexpr int kTiles = 42, kRowBytes = 44 * 1024;
 
-template <int W, bool NTS, int SPIN, int BATCH = 1>
+template <int W, bool NTS, int SPIN, int BATCH = 1, int HALO = 0>
 __global__ __launch_bounds__(256, 1) void sweep(char *ring, long rows, double *sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long stride = (long)gridDim.x * 4;
@@ -48,6 +48,11 @@ __global__ __launch_bounds__(256, 1) void sweep(char *ring, long rows, double *s
                     if (lane >= 1 && lane < 63) {
                         if (W >= 1) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb)); else *reinterpret_cast<v2 *>(wb) = s; }
                         if (W >= 2) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb + 1024)); else *reinterpret_cast<v2 *>(wb + 1024) = s; }
+                    }
+                    if (HALO) {                                     // the halo copies of the real pass: 16-B stores into the neighbouring rows' tiles
+                        char *t0 = ring + (unsigned long)__builtin_amdgcn_readfirstlane((int)r) * kRowBytes + 42 * 1024;
+                        if (lane == 1 && r > 0) { *reinterpret_cast<v2 *>(t0 - kRowBytes + 63 * 16) = s; if (HALO > 1) *reinterpret_cast<v2 *>(t0 - kRowBytes + 1024 + 63 * 16) = s; }
+                        if (lane == 62 && r + 1 < rows) { *reinterpret_cast<v2 *>(t0 + kRowBytes) = s; if (HALO > 1) *reinterpret_cast<v2 *>(t0 + kRowBytes + 1024) = s; }
                     }
                 }
             }
@@ -86,6 +91,9 @@ int main() {
         printf("42 tile reads + %d tile writes (%s), %2d fma per vector: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", 2 * SPIN, us, (rd + W * wr1) / us / 1e3); }
 #define RUNB(W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep<W, NTS, SPIN, BATCH>), dim3(256), dim3(256), 0, 0, ring, rows, sink); }); \
         printf("42 tile reads + %d tile writes (%s) in batches of %2d rows, %2d fma per vector: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", BATCH, 2 * SPIN, us, (rd + W * wr1) / us / 1e3); }
+#define RUNH(W, NTS, SPIN, BATCH, HALO) { double us = time_us([&] { hipLaunchKernelGGL((sweep<W, NTS, SPIN, BATCH, HALO>), dim3(256), dim3(256), 0, 0, ring, rows, sink); }); \
+        printf("42 tile reads + %d tile writes (%s) in batches of %2d rows + halo copies of %d streams: %7.1f us\n", W, NTS ? "nt   " : "plain", BATCH, HALO, us); }
+    RUNH(2, false, 8, 16, 0) RUNH(2, false, 8, 16, 1) RUNH(2, false, 8, 16, 2) RUNH(2, false, 8, 16, 0) RUNH(2, false, 8, 16, 2)
     RUNB(2, false, 8, 4) RUNB(2, false, 8, 8) RUNB(2, false, 8, 16) RUNB(2, true, 8, 8) RUNB(2, true, 8, 16)
     RUN(0, true, 0) RUN(1, true, 0) RUN(2, true, 0) RUN(1, false, 0) RUN(2, false, 0)
     RUN(0, true, 8) RUN(2, true, 8) RUN(2, false, 8)
