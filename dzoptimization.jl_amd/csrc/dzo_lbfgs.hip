@@ -2372,6 +2372,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.debug_skip = 1 | 64;                               // no pair dots, no tile stores (and with them no halo copies)
     fp.stage_rows = 1;
     void (*kern)(FusedParams<T>) = o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
+                                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12>
                                    : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
                                    : lbfgs_point_pass_kernel<T, 20>;
     const int grid = points_grid<T>(o, kern);
@@ -2418,6 +2419,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
     void (*kern)(FusedParams<T>) = k == 0 ? lbfgs_point_pass_kernel<T, 8, true>
                                    : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
+                                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12>
                                    : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
                                    : lbfgs_point_pass_kernel<T, 20>;
     const int grid = points_grid<T>(o, kern);
