@@ -121,6 +121,14 @@ struct dzo_lbfgs_s {
     // are gathered back only when somebody asks.
     bool blocked = false;
     int64_t rowbytes = 0, ring_rows = 0;
+    // Two arrangements of the tiles: TILE-major (tile_stride = 1 KiB, rowbytes = 2 nslots KiB: a wave-row's tiles of
+    // all streams adjacent) and STREAM-major (tile_stride = one whole stream, rowbytes = 1 KiB: every stream
+    // contiguous).  Reads do not care (tools/pointbench.hip: 495 vs 503 us for the 42 tile reads per row); writes do:
+    // a stream that is written lands in consecutive DRAM pages only when it is contiguous (two written tiles per
+    // row: 650 us tile-major, 585 us stream-major; in bursts of 16 rows 609 vs 550-560 us).  Stream-major is used
+    // whenever the ring's byte offsets fit 32 bits (config 3: 3.63 GB).
+    int64_t tile_stride = dzo::kTileBytes;
+    size_t ring_bytes = 0;
     void *dx_lin = nullptr, *dg_lin = nullptr;
     bool lin_stale = false;         // dx_lin / dg_lin do not hold the newest pair (a single-pass step pushed it)
     void *export_slab = nullptr;    // contiguous copies of S[i] / Y[i] handed out by get_ptr (2 m vectors, lazily)
@@ -138,16 +146,16 @@ struct dzo_lbfgs_s {
     bool d_stale = false;
     int dview_k = 0, dview_newest = 0;
     template <typename T> T *s_slot(int slot) const {
-        return blocked ? (T *)((char *)S + (size_t)(2 * slot) * dzo::kTileBytes) : (T *)S + (int64_t)slot * pair_stride;
+        return blocked ? (T *)((char *)S + (size_t)(2 * slot) * (size_t)tile_stride) : (T *)S + (int64_t)slot * pair_stride;
     }
     template <typename T> T *y_slot(int slot) const {
-        return blocked ? (T *)((char *)S + (size_t)(2 * slot + 1) * dzo::kTileBytes) : (T *)Y + (int64_t)slot * pair_stride;
+        return blocked ? (T *)((char *)S + (size_t)(2 * slot + 1) * (size_t)tile_stride) : (T *)Y + (int64_t)slot * pair_stride;
     }
     void *s_slot_v(int slot) const {
-        return blocked ? (void *)((char *)S + (size_t)(2 * slot) * dzo::kTileBytes) : (void *)((char *)S + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype));
+        return blocked ? (void *)((char *)S + (size_t)(2 * slot) * (size_t)tile_stride) : (void *)((char *)S + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype));
     }
     void *y_slot_v(int slot) const {
-        return blocked ? (void *)((char *)S + (size_t)(2 * slot + 1) * dzo::kTileBytes) : (void *)((char *)Y + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype));
+        return blocked ? (void *)((char *)S + (size_t)(2 * slot + 1) * (size_t)tile_stride) : (void *)((char *)Y + (size_t)slot * pair_stride * dzo::dtype_size(core.dtype));
     }
     void refresh_delta_ptrs() {
         if (blocked) { core.dx = dx_lin; core.dg = dg_lin; }
@@ -810,6 +818,7 @@ template <typename T> struct FusedParams {
     uint32_t soff[kFusedMaxK + 1];             // logical pair -> byte offset of its s tile within a row (y tile: + kTileBytes);
                                                // point ring: logical POINT j (0 = current) -> its x tile (gradient tile: + kTileBytes)
     uint32_t new_off;                          // s tile of the spare slot: delta_point / delta_gradient of this step
+    uint32_t ystride;                          // from a slot's s (x) tile to its y (g) tile: 1 KiB tile-major, one stream stream-major
     double *gram_partials;                     // [kGramValues * k_next][gridDim.x], post-push order
     double *obj_partials;                      // [gridDim.x]
     int32_t *changed;
@@ -891,15 +900,15 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
         char *rb = rowbase(row);
         if constexpr (PLAIN) {
 #pragma unroll
-            for (int i = 0; i < K; ++i) load16(tl(rb, p.soff[i] + (uint32_t)kTileBytes), yv[i]);
+            for (int i = 0; i < K; ++i) load16(tl(rb, p.soff[i] + p.ystride), yv[i]);
 #pragma unroll
             for (int i = K - 1; i >= 0; --i) load16(tl(rb, p.soff[i]), sv[i]);
             return;
         }
-        if (p.debug_skip & 16) { load16(tl(rb, p.soff[0] + (uint32_t)kTileBytes), yv[0]); load16(tl(rb, p.soff[0]), sv[0]); }
-        else { load16_nt(tl(rb, p.soff[0] + (uint32_t)kTileBytes), yv[0]); load16_nt(tl(rb, p.soff[0]), sv[0]); }
+        if (p.debug_skip & 16) { load16(tl(rb, p.soff[0] + p.ystride), yv[0]); load16(tl(rb, p.soff[0]), sv[0]); }
+        else { load16_nt(tl(rb, p.soff[0] + p.ystride), yv[0]); load16_nt(tl(rb, p.soff[0]), sv[0]); }
 #pragma unroll
-        for (int i = 1; i < K; ++i) load16_nt(tl(rb, p.soff[i] + (uint32_t)kTileBytes), yv[i]);
+        for (int i = 1; i < K; ++i) load16_nt(tl(rb, p.soff[i] + p.ystride), yv[i]);
 #pragma unroll
         for (int i = K - 1; i >= 1; --i) load16_nt(tl(rb, p.soff[i]), sv[i]);
     };
@@ -970,7 +979,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             // the new pair goes straight into its tiles; the first / last owned vector of the row is also
             // the right / left halo copy of the neighbouring row's tile
             char *st = rowbase(row) + p.new_off;
-            char *yt = st + kTileBytes;
+            char *yt = st + p.ystride;
             if (!(p.debug_skip & 64)) {
                 store16_nt(reinterpret_cast<T *>(st + toff), sn);
                 store16_nt(reinterpret_cast<T *>(yt + toff), yn);
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
             load16(reinterpret_cast<const T *>(sl + kTileBytes), gs);
             if (own) {
                 char *xt = rowbase(r) + p.new_off;
-                char *gt = xt + kTileBytes;
+                char *gt = xt + p.ystride;
                 if (p.nt_tiles) {
                     store16_nt(reinterpret_cast<T *>(xt + toff), xs);
                     store16_nt(reinterpret_cast<T *>(gt + toff), gs);
@@ -1184,7 +1193,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
     auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N]) {
         char *rb = rowbase(row);
 #pragma unroll
-        for (int j = 0; j <= K; ++j) load16_nt(tl(rb, p.soff[j] + (uint32_t)kTileBytes), gv[j]);
+        for (int j = 0; j <= K; ++j) load16_nt(tl(rb, p.soff[j] + p.ystride), gv[j]);
 #pragma unroll
         for (int j = K; j >= 0; --j) load16_nt(tl(rb, p.soff[j]), xv[j]);
     };
@@ -1875,7 +1884,7 @@ static int32_t lbfgs_leave_points(dzo_lbfgs_s *o) {
             DZO_DISPATCH(c.dtype, (ring_diff<T>(o, o->s_slot_v(a), o->s_slot_v(b)), ring_diff<T>(o, o->y_slot_v(a), o->y_slot_v(b))));
         }
         if (o->k == 0) {                                  // an empty pair ring is a zeroed one (:366-374)
-            DZO_HIP(hipMemsetAsync(o->S, 0, (size_t)o->ring_rows * (size_t)o->rowbytes, c.stream));
+            DZO_HIP(hipMemsetAsync(o->S, 0, o->ring_bytes, c.stream));
         }
         DZO_HIP(hipGetLastError());
     }
@@ -2233,11 +2242,11 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     fp.x = (const T *)c.x; fp.g = (const T *)c.g; fp.x_out = (T *)o->x_twin; fp.g_out = (T *)o->g_twin;
     fp.d = (T *)o->d;
     fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
-    fp.new_off = (uint32_t)(2 * o->spare()) * (uint32_t)kTileBytes;
+    fp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); fp.ystride = (uint32_t)o->tile_stride;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     for (int i = 0; i < kFusedMaxK; ++i) {                // entries >= k: any valid vector (zero coefficient)
         const int slot = o->slot_of(i < k ? i : 0);
-        fp.soff[i] = (uint32_t)(2 * slot) * (uint32_t)kTileBytes;
+        fp.soff[i] = (uint32_t)((uint64_t)(2 * slot) * (uint64_t)o->tile_stride);
     }
     fp.gram_partials = o->gram_partials;
     fp.obj_partials = c.problem->scratch;
@@ -2362,10 +2371,10 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.n = c.n; fp.k = k; fp.k_next = 1; fp.t = (T)1; fp.t_half = (T)0.5;
     fp.d = (T *)o->d; fp.store_d = 1;
     fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
-    fp.new_off = (uint32_t)(2 * o->spare()) * (uint32_t)kTileBytes;          // (never written: no tile stores in this mode)
+    fp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); fp.ystride = (uint32_t)o->tile_stride;   // (never written: no tile stores in this mode)
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     auto old_slot = [&](int j) { return ((o->dview_newest - j) % o->nslots + o->nslots) % o->nslots; };
-    for (int j = 0; j <= kFusedMaxK; ++j) fp.soff[j] = (uint32_t)(2 * old_slot(j < k ? j : k)) * (uint32_t)kTileBytes;
+    for (int j = 0; j <= kFusedMaxK; ++j) fp.soff[j] = (uint32_t)((uint64_t)(2 * old_slot(j < k ? j : k)) * (uint64_t)o->tile_stride);
     fp.gram_partials = o->gram_partials;                  // (consumed by the step's gated gram_finish; scratch here)
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
@@ -2409,10 +2418,10 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.n = c.n; fp.k = k; fp.k_next = k < o->m ? k + 1 : o->m;
     fp.d = (T *)o->d;
     fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
-    fp.new_off = (uint32_t)(2 * o->spare()) * (uint32_t)kTileBytes;
+    fp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); fp.ystride = (uint32_t)o->tile_stride;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     for (int j = 0; j <= kFusedMaxK; ++j)                 // points beyond k: point k again (those pairs are zero)
-        fp.soff[j] = (uint32_t)(2 * o->slot_of(j < k ? j : k)) * (uint32_t)kTileBytes;
+        fp.soff[j] = (uint32_t)((uint64_t)(2 * o->slot_of(j < k ? j : k)) * (uint64_t)o->tile_stride);
     fp.gram_partials = o->gram_partials;
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
@@ -2425,7 +2434,9 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     const int grid = points_grid<T>(o, kern);
     fp.store_d = o->lazy_d ? 0 : 1;
     {
-        const int64_t cache_mb = tune("DZO_TUNE_POINT_PLAIN_MB", 200);       // two streams of n T bytes against the 256-MiB Infinity Cache
+        // tile-major ring: plain stores while the two streams fit the 256-MiB Infinity Cache (695 vs 735 us at
+        // n = 1e7); stream-major ring: non-temporal (655-672 vs 659-682 us over four interleaved rounds)
+        const int64_t cache_mb = tune("DZO_TUNE_POINT_PLAIN_MB", o->tile_stride == kTileBytes ? 200 : 0);
         fp.nt_tiles = 2 * (int64_t)c.n * (int64_t)sizeof(T) > (cache_mb << 20) ? 1 : 0;
     }
     // rows of new tiles a wave collects in LDS before it writes them (2 KiB per row and wave; the whole 160-KiB LDS
@@ -2631,8 +2642,17 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     if (o->blocked) {
         const int64_t nvec = n / (16 / (int64_t)es);
         o->ring_rows = (nvec + kRowOwn - 1) / kRowOwn;
-        o->rowbytes = (int64_t)2 * m1 * kTileBytes;
-        ALLOC(o->S, (size_t)o->ring_rows * (size_t)o->rowbytes);
+        {
+            const int64_t stream_bytes = ((o->ring_rows * kTileBytes + 1023) / 1024 | 1) * 1024;   // an odd number of KiB (HBM channel skew)
+            const uint64_t total = (uint64_t)2 * m1 * (uint64_t)stream_bytes;
+            if (tune("DZO_TUNE_STREAM_MAJOR", 1) != 0 && total + (1u << 20) < (1ull << 32)) {      // 32-bit byte offsets in the passes
+                o->tile_stride = stream_bytes; o->rowbytes = kTileBytes; o->ring_bytes = (size_t)total;
+            } else {
+                o->tile_stride = kTileBytes; o->rowbytes = (int64_t)2 * m1 * kTileBytes;
+                o->ring_bytes = (size_t)o->ring_rows * (size_t)o->rowbytes;
+            }
+        }
+        ALLOC(o->S, o->ring_bytes);
         o->Y = nullptr;
         o->pair_stride = 0;
         ALLOC(o->dx_lin, (size_t)o->stride * es);
@@ -2691,7 +2711,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->link_partials = base;
     // :366-374 zero-filled deltas: the whole ring starts zeroed
     if (o->blocked) {
-        DZO_HIP(hipMemsetAsync(o->S, 0, (size_t)o->ring_rows * (size_t)o->rowbytes, c.stream));
+        DZO_HIP(hipMemsetAsync(o->S, 0, o->ring_bytes, c.stream));
         DZO_HIP(hipMemsetAsync(o->dx_lin, 0, (size_t)o->stride * es, c.stream));
         DZO_HIP(hipMemsetAsync(o->dg_lin, 0, (size_t)o->stride * es, c.stream));
     } else if (o->interleaved) {

@@ -74,6 +74,58 @@ __global__ __launch_bounds__(256, 1) void sweep(char *ring, long rows, double *s
     if (acc == 1.2345e300) sink[0] = acc;
 }
 
+
+// the same sweep over a STREAM-major ring: tile (stream q, row r) at q * stream_bytes + r * 1024 -- every stream is
+// contiguous, so what a block's four waves write (rows 4b .. 4b+3) is one 4-KiB piece per written stream
+template <int W, bool NTS, int SPIN, int BATCH>
+__global__ __launch_bounds__(256, 1) void sweep_sm(char *ring, long rows, long stream_bytes, double *sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long stride = (long)gridDim.x * 4;
+    v2 A[kTiles], B[kTiles];
+    double acc = 0;
+    auto issue = [&](long row, v2 (&r)[kTiles]) {
+        const char *rb = ring + (unsigned long)__builtin_amdgcn_readfirstlane((int)row) * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) r[t] = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(rb + (unsigned long)t * stream_bytes));
+    };
+    v2 held[BATCH];
+    auto compute = [&](long row, v2 (&r)[kTiles]) {
+        v2 s = {0, 0};
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            v2 v = r[t];
+#pragma unroll
+            for (int k = 0; k < SPIN; ++k) { s.x = __builtin_fma(v.x, 1.0000001, s.x); s.y = __builtin_fma(v.y, 0.9999999, s.y); }
+            if (SPIN == 0) { s.x += v.x; s.y += v.y; }
+        }
+        const long it = (row - ((long)blockIdx.x * 4 + wave)) / stride;
+        if (it % BATCH == BATCH - 1) {
+            for (int b = 0; b < BATCH; ++b) {
+                const long r2 = row - (long)b * stride;
+                char *wb = ring + 42 * stream_bytes + (unsigned long)__builtin_amdgcn_readfirstlane((int)r2) * 1024 + lane * 16;
+                if (lane >= 1 && lane < 63) {
+                    if (W >= 1) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb)); else *reinterpret_cast<v2 *>(wb) = s; }
+                    if (W >= 2) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb + stream_bytes)); else *reinterpret_cast<v2 *>(wb + stream_bytes) = s; }
+                }
+            }
+        }
+        acc += s.x + s.y;
+    };
+    long row = (long)blockIdx.x * 4 + wave;
+    auto clampr = [&](long r) { return r < rows ? r : rows - 1; };
+    issue(clampr(row), A);
+    while (row < rows) {
+        issue(clampr(row + stride), B);
+        compute(row, A);
+        row += stride;
+        if (row >= rows) break;
+        issue(clampr(row + stride), A);
+        compute(row, B);
+        row += stride;
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
 template <typename F> static double time_us(F f, int reps = 8) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -91,6 +143,14 @@ int main() {
         printf("42 tile reads + %d tile writes (%s), %2d fma per vector: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", 2 * SPIN, us, (rd + W * wr1) / us / 1e3); }
 #define RUNB(W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep<W, NTS, SPIN, BATCH>), dim3(256), dim3(256), 0, 0, ring, rows, sink); }); \
         printf("42 tile reads + %d tile writes (%s) in batches of %2d rows, %2d fma per vector: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", BATCH, 2 * SPIN, us, (rd + W * wr1) / us / 1e3); }
+    {
+        const long stream_bytes = ((rows * 1024 + 1023) / 1024 | 1) * 1024;      // an odd number of KiB
+        char *ring2; CK(hipMalloc(&ring2, (size_t)stream_bytes * 44)); CK(hipMemset(ring2, 0, (size_t)stream_bytes * 44)); CK(hipDeviceSynchronize());
+#define RUNS(W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep_sm<W, NTS, SPIN, BATCH>), dim3(256), dim3(256), 0, 0, ring2, rows, stream_bytes, sink); }); \
+        printf("STREAM-major: 42 tile reads + %d tile writes (%s) in batches of %2d rows: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", BATCH, us, (rd + W * wr1) / us / 1e3); }
+        RUNS(0, true, 8, 1) RUNS(2, true, 8, 1) RUNS(2, false, 8, 1) RUNS(2, false, 8, 16) RUNS(2, true, 8, 16) RUNS(1, false, 8, 1)
+        CK(hipFree(ring2));
+    }
 #define RUNH(W, NTS, SPIN, BATCH, HALO) { double us = time_us([&] { hipLaunchKernelGGL((sweep<W, NTS, SPIN, BATCH, HALO>), dim3(256), dim3(256), 0, 0, ring, rows, sink); }); \
         printf("42 tile reads + %d tile writes (%s) in batches of %2d rows + halo copies of %d streams: %7.1f us\n", W, NTS ? "nt   " : "plain", BATCH, HALO, us); }
     RUNH(2, false, 8, 16, 0) RUNH(2, false, 8, 16, 1) RUNH(2, false, 8, 16, 2) RUNH(2, false, 8, 16, 0) RUNH(2, false, 8, 16, 2)
