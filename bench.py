@@ -712,7 +712,8 @@ def main():
                                  "step, pairs formed in registers)" if opt.ring_layout == 2 else
                                  "single_pass on the pair ring (one sweep over the history per trial; gram + combine only after "
                                  "a step that needed t <= 1/4)") if "lbfgs_single_pass" in table else args.mode),
-                   "history_layout": {0: "slabs", 1: "tile-major pairs", 2: "tile-major points"}[opt.ring_layout],
+                   "history_layout": ({0: "slabs", 1: "tiles of pairs", 2: "tiles of points"}[opt.ring_layout] +
+                                      {0: "", 1: ", tile-major", 2: ", stream-major"}[opt.tile_arrangement]),
                    "parallelism": (f"1 optimizer instance per GPU (replicas), world size {world}; convergence flag: "
                                    f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",

@@ -638,6 +638,7 @@ class LBFGSOptimizer(_OptBase):
     single_pass_rejections = property(lambda s: s._i(12))
     single_pass_retries = property(lambda s: s._i(13))    # rejected first trials continued by a second pass at t/2
     ring_layout = property(lambda s: s._i(14))            # 0 slabs, 1 tile-major pairs, 2 tile-major points (the point ring)
+    tile_arrangement = property(lambda s: s._i(15))       # 0 no tiles (slabs), 1 tile-major, 2 stream-major
 
     def compute_step_direction(self, sync=True):
         """``compute_lbfgs_step_direction!`` (:430-451).  ``sync=False`` only enqueues the kernels (the

@@ -2919,7 +2919,8 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 11: *value = o->single_pass_steps; break;
     case 12: *value = o->single_pass_rejections; break;
     case 13: *value = o->single_pass_retries; break;
-    case 14: *value = o->points ? 2 : (o->blocked ? 1 : 0); break;   // history layout: 0 slabs, 1 tile-major pairs, 2 tile-major points
+    case 14: *value = o->points ? 2 : (o->blocked ? 1 : 0); break;   // history layout: 0 slabs, 1 tiles of pairs, 2 tiles of points
+    case 15: *value = o->blocked ? (o->tile_stride == kTileBytes ? 1 : 2) : 0; break;   // arrangement of the tiles: 1 tile-major, 2 stream-major
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;

@@ -218,8 +218,9 @@ int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
  * last step (0 quasi-Newton, 1 replaced by the descent check, 2 fallback); fields 11 / 12: steps
  * taken as one sweep over the history (single-pass step) and how many of those had their first
  * trial rejected; field 13: how many of the rejected ones were continued by the same pass at
- * t/2; field 14: layout of the history in HBM -- 0 slabs, 1 tile-major pairs, 2 tile-major points
- * (DESIGN.md "point ring": informational);
+ * t/2; field 14: layout of the history in HBM -- 0 slabs, 1 tiles of pairs, 2 tiles of points
+ * (DESIGN.md "point ring"); field 15: arrangement of the tiles -- 1 tile-major, 2 stream-major
+ * (informational);
  * dzo_lbfgs_get_s field 2: last_step_length. */
 int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t opt, int32_t descent_check, int32_t steepest_descent_fallback);
 
