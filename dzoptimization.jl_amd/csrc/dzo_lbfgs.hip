@@ -2645,7 +2645,9 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         {
             const int64_t stream_bytes = ((o->ring_rows * kTileBytes + 1023) / 1024 | 1) * 1024;   // an odd number of KiB (HBM channel skew)
             const uint64_t total = (uint64_t)2 * m1 * (uint64_t)stream_bytes;
-            if (tune("DZO_TUNE_STREAM_MAJOR", 1) != 0 && total + (1u << 20) < (1ull << 32)) {      // 32-bit byte offsets in the passes
+            // (few streams: the whole wave-row of a tile-major ring sits in a handful of DRAM pages and its reads win --
+            // n = 1e7: m = 5 pass 234 us tile-major / 253 us stream-major, m = 10 398 / 383, m = 20 684 / 660)
+            if (tune("DZO_TUNE_STREAM_MAJOR", o->m >= 9 ? 1 : 0) != 0 && total + (1u << 20) < (1ull << 32)) {      // 32-bit byte offsets in the passes
                 o->tile_stride = stream_bytes; o->rowbytes = kTileBytes; o->ring_bytes = (size_t)total;
             } else {
                 o->tile_stride = kTileBytes; o->rowbytes = (int64_t)2 * m1 * kTileBytes;
