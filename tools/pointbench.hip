@@ -77,10 +77,12 @@ __global__ __launch_bounds__(256, 1) void sweep(char *ring, long rows, double *s
 
 // the same sweep over a STREAM-major ring: tile (stream q, row r) at q * stream_bytes + r * 1024 -- every stream is
 // contiguous, so what a block's four waves write (rows 4b .. 4b+3) is one 4-KiB piece per written stream
-template <int W, bool NTS, int SPIN, int BATCH>
+template <int W, bool NTS, int SPIN, int BATCH, bool CHUNK = false>
 __global__ __launch_bounds__(256, 1) void sweep_sm(char *ring, long rows, long stream_bytes, double *sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long stride = (long)gridDim.x * 4;
+    const long nwaves = (long)gridDim.x * 4;
+    const long per = (rows + nwaves - 1) / nwaves;                   // CHUNK: a wave takes `per` CONSECUTIVE rows
+    const long stride = CHUNK ? 1 : nwaves;
     v2 A[kTiles], B[kTiles];
     double acc = 0;
     auto issue = [&](long row, v2 (&r)[kTiles]) {
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256, 1) void sweep_sm(char *ring, long rows, long s
             for (int k = 0; k < SPIN; ++k) { s.x = __builtin_fma(v.x, 1.0000001, s.x); s.y = __builtin_fma(v.y, 0.9999999, s.y); }
             if (SPIN == 0) { s.x += v.x; s.y += v.y; }
         }
-        const long it = (row - ((long)blockIdx.x * 4 + wave)) / stride;
+        const long first = CHUNK ? ((long)blockIdx.x * 4 + wave) * per : ((long)blockIdx.x * 4 + wave);
+        const long it = (row - first) / stride;
         if (it % BATCH == BATCH - 1) {
             for (int b = 0; b < BATCH; ++b) {
                 const long r2 = row - (long)b * stride;
@@ -111,14 +114,15 @@ __global__ __launch_bounds__(256, 1) void sweep_sm(char *ring, long rows, long s
         }
         acc += s.x + s.y;
     };
-    long row = (long)blockIdx.x * 4 + wave;
+    long row = CHUNK ? ((long)blockIdx.x * 4 + wave) * per : (long)blockIdx.x * 4 + wave;
+    const long end = CHUNK ? (row + per < rows ? row + per : rows) : rows;
     auto clampr = [&](long r) { return r < rows ? r : rows - 1; };
     issue(clampr(row), A);
-    while (row < rows) {
+    while (row < end) {
         issue(clampr(row + stride), B);
         compute(row, A);
         row += stride;
-        if (row >= rows) break;
+        if (row >= end) break;
         issue(clampr(row + stride), A);
         compute(row, B);
         row += stride;
@@ -148,6 +152,9 @@ int main() {
         char *ring2; CK(hipMalloc(&ring2, (size_t)stream_bytes * 44)); CK(hipMemset(ring2, 0, (size_t)stream_bytes * 44)); CK(hipDeviceSynchronize());
 #define RUNS(W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep_sm<W, NTS, SPIN, BATCH>), dim3(256), dim3(256), 0, 0, ring2, rows, stream_bytes, sink); }); \
         printf("STREAM-major: 42 tile reads + %d tile writes (%s) in batches of %2d rows: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", BATCH, us, (rd + W * wr1) / us / 1e3); }
+#define RUNC(W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep_sm<W, NTS, SPIN, BATCH, true>), dim3(256), dim3(256), 0, 0, ring2, rows, stream_bytes, sink); }); \
+        printf("STREAM-major, consecutive rows per wave: 42 tile reads + %d tile writes (%s) in batches of %2d rows: %7.1f us  %6.0f GB/s\n", W, NTS ? "nt   " : "plain", BATCH, us, (rd + W * wr1) / us / 1e3); }
+        RUNC(0, true, 8, 1) RUNC(2, true, 8, 1) RUNC(2, true, 8, 16) RUNC(2, false, 8, 16)
         RUNS(0, true, 8, 1) RUNS(2, true, 8, 1) RUNS(2, false, 8, 1) RUNS(2, false, 8, 16) RUNS(2, true, 8, 16) RUNS(1, false, 8, 1)
         CK(hipFree(ring2));
     }
