@@ -363,6 +363,13 @@ function Base.getproperty(o::LBFGSOptimizer{T}, s::Symbol) where {T}
     s === :last_step_length && return fill(T(_lb_s(o, 2)))
     s === :history_resets && return Int(_lb_i(o, 8))
     s === :descent_resets && return Int(_lb_i(o, 9))
+    # informational (include/dzo.h): steps taken as one sweep, their rejected first trials / second passes, and how the
+    # history lives in HBM (0 slabs, 1 tiles of pairs, 2 tiles of points; tile arrangement 1 tile-major, 2 stream-major)
+    s === :single_pass_steps && return Int(_lb_i(o, 11))
+    s === :single_pass_rejections && return Int(_lb_i(o, 12))
+    s === :single_pass_retries && return Int(_lb_i(o, 13))
+    s === :ring_layout && return Int(_lb_i(o, 14))
+    s === :tile_arrangement && return Int(_lb_i(o, 15))
     return getfield(o, s)
 end
 
