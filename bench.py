@@ -8,11 +8,18 @@ objective, gradient, delta_gradient + rho, history push.  State is resident in H
 the timed region starts; the only per-step host traffic is the 40-byte {f_new, changed}
 read-back the reference's host-side `f_new < f` test needs.
 
-N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`): one process per GPU, each
-rank owns an independent optimizer instance (north_star: "batched-problems mode shards
-independent optimizer instances across the GPUs ... RCCL only for the global convergence
-flag; single huge-n problems stay on one GPU").  There is no data-path collective; the
-convergence flag is all-reduced over RCCL every --poll steps.  scaling = "weak".
+N > 1: one process per GPU (`python -m torch.distributed.run ... bench.py --gpus N`, or plain
+`python bench.py --gpus N`, which starts exactly that launcher as a child process before anything
+touches the GPU and exits with its return code).  Each rank owns an independent optimizer instance
+(north_star: "batched-problems mode shards independent optimizer instances across the GPUs ... RCCL
+only for the global convergence flag; single huge-n problems stay on one GPU"), so the headline
+fields are config 3 replicated per GPU ("replicas only"), and the line carries a
+`batched` object with the quantity north_star really shards: config 5, 1024 independent dense-BFGS
+instances per GPU, whole-job instance-step!()/s, per-rank rates, the polls of the convergence flag.
+There is no data-path collective; the flag is all-reduced (MIN over one int32) through the library's
+own RCCL communicator (dzo_comm_* behind the C ABI) -- a hard requirement: if that communicator cannot
+be created the run fails (BENCH_DIST_BACKEND=gloo is the explicit CPU-transport rehearsal for a 1-GPU
+box, where two ranks cannot share a device under RCCL).  scaling = "weak".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
 `cpu_baseline` objects.
@@ -73,48 +80,67 @@ def rosenbrock_chain_x0(n, seed=5):
 
 
 # ------------------------------------------------------------------------------ helpers
-def _dist_setup(gpus):
-    import torch
+def launch_command(argv, gpus, port):
+    """The command `python bench.py --gpus N` runs for N > 1 when no launcher started it: the driver's own
+    multi-GPU form (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, gpus):
+    """Start the N ranks as a CHILD process tree (never exec: a process that replaces itself after touching the GPU
+    takes the box down, and this parent has not touched it and never will) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(launch_command(argv, gpus, port), env=env)
+
+
+def _dist_setup(gpus, use_gpu=True):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     # rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks on the same device):
     #   BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0  -> both ranks on cuda:0, flag all-reduced over gloo
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if "BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["BENCH_FORCE_DEVICE"])
+    if not use_gpu:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        return world, rank, local
+    import torch
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    else:
-        if gpus != 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        torch.cuda.set_device(0)
     return world, rank, local
 
 
 def _make_comm(dzo, world):
-    """N > 1 over RCCL: the convergence flag goes through dzo_flag_allreduce_min (the C-ABI collective a
-    Julia host uses too); the unique id travels over the torch.distributed group.  The gloo rehearsal
-    (two ranks on one GPU, which RCCL refuses) keeps torch.distributed for the flag."""
+    """N > 1: the convergence flag goes through dzo_flag_allreduce_min / dzo_bfgs_batch_all_done (the C-ABI collective
+    a Julia host uses too); the unique id travels over the torch.distributed group.  A HARD requirement: when the
+    communicator cannot be created every rank raises the same error (Comm.from_torch_distributed keeps the ranks'
+    collectives matched while it fails) and the run ends non-zero -- a line printed over some other transport would
+    look like a measurement of this one.  Only BENCH_DIST_BACKEND=gloo (the explicit rehearsal on a 1-GPU box, where
+    RCCL refuses two ranks on one device) keeps torch.distributed for the flag."""
     if world <= 1 or os.environ.get("BENCH_DIST_BACKEND", "nccl") != "nccl":
         return None
-    import torch
-    import torch.distributed as dist
-    comm, ok = None, 1
-    try:
-        comm = dzo.Comm.from_torch_distributed()
-    except Exception as e:                                # (keep the run alive: the flag then travels over torch.distributed)
-        print(f"[bench] rank {dist.get_rank()}: RCCL communicator behind the C ABI unavailable ({e}); "
-              f"falling back to torch.distributed for the convergence flag", file=sys.stderr)
-        ok = 0
-    agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
-    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)         # all ranks use the same transport
-    return comm if int(agreed.item()) == 1 else None
+    comm = dzo.Comm.from_torch_distributed()
+    assert comm.nranks == world, (comm.nranks, world)
+    return comm
 
 
 def _barrier(world):
@@ -283,6 +309,88 @@ def quadratic_matrix(n, r=8):
     return 0.5 * (A + A.T)
 
 
+def batched_leg(dzo, sharding, args, world, rank, comm, info, steps, warmup):
+    """Config 5 (BASELINE configs[4]): B independent dense-BFGS instances per GPU (n = 256, chained Rosenbrock, fp64), block
+    partition of the instances over the ranks, the only collective the convergence flag.  Every rank runs it; returns the
+    fields of the JSON line (whole-job instance-step!()/s, per-rank rates so that a straggler is visible)."""
+    n = 256 if args.n == 10_000_000 else args.n
+    B = args.batch
+    lo = rank * B                                              # weak scaling: B instances per GPU
+    X0 = np.stack([pcg32_uniform(n, 1000 + lo + b) for b in range(B)])
+    batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
+    flag = sharding.ConvergenceFlag(poll=1, comm=comm)
+    if world > 1 and comm is None:
+        assert os.environ.get("BENCH_DIST_BACKEND", "nccl") != "nccl", "N > 1 without the RCCL communicator"
+    polls = 0
+    batch.step(warmup, poll=False)
+    dzo.synchronize()
+    dzo.profile_reset(); dzo.profile_enable(True)
+    _barrier(world)
+    it0 = int(batch.iteration_count.to_host().sum())
+    t0 = time.perf_counter()
+    chunk = max(1, args.poll)
+    done_steps = 0
+    while done_steps < steps:
+        k = min(chunk, steps - done_steps)
+        batch.step(k, poll=False)
+        done_steps += k
+        if comm is not None:
+            comm.all_done([batch])                             # dzo_bfgs_batch_all_done: local count + one 4-byte all-reduce
+        else:
+            flag.update(batch.count_active() == 0)             # (single GPU, or the gloo rehearsal)
+        polls += 1
+    dzo.synchronize()
+    el_local = time.perf_counter() - t0                        # this rank's own time, before it waits for the others
+    _barrier(world)
+    el = sharding.max_over_ranks(time.perf_counter() - t0)
+    dzo.profile_enable(False)
+    it1 = int(batch.iteration_count.to_host().sum())
+    inst_steps = sharding.sum_over_ranks(float(it1 - it0))
+    per_rank = [round(sharding.sum_over_ranks((it1 - it0) / el_local if r == rank else 0.0), 1) for r in range(world)]
+    tab = dzo.profile_table()
+    kern = {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in tab.items() if k.startswith("bfgs_batch")}
+    # the step kernel reads and writes the LOWER triangle of every H only: 1.5 n^2 T per BFGS instance-step
+    # (a gradient-descent step resets the triangle: 0.5 n^2 T; counted as a BFGS step here, an upper bound)
+    ach = 1.5 * n * n * 8 * (it1 - it0) / (1e-3 * tab["bfgs_batch_step"][1]) / 1e9 if "bfgs_batch_step" in tab else None
+    rccl_n = comm.nranks if comm is not None else None
+    if world > 1 and os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl":
+        assert rccl_n == world, "the flag did not travel over the library's RCCL communicator"
+    res = {"metric": "instance-step!() calls/sec, batched dense BFGS n=256 fp64 (config 5)",
+           "value": round(inst_steps / el, 1), "unit": "instance-step!() calls/s",
+           "ms_per_step": round(1e3 * el / steps, 4), "dtype": "f64", "steps": steps, "warmup": warmup,
+           "per_rank_instance_steps_per_s": per_rank,
+           "config": {"workload": f"batched BFGS, {B} instances/GPU x n={n}, chained Rosenbrock, fp64 (BASELINE configs[4])",
+                      "instances_per_gpu": B, "instances_total": B * world, "active_at_end": batch.count_active(),
+                      "rccl_world_size": rccl_n, "polls": polls,
+                      "parallelism": (f"instances sharded by rank (block partition), world size {world}; the only collective is "
+                                      f"the convergence flag: {'dzo_bfgs_batch_all_done (RCCL behind the C ABI)' if comm is not None else flag.transport}, "
+                                      f"{polls} polls in the timed region"),
+                      "device": info["name"]},
+           "roofline": {"bound": "hbm", "kernel": "batch_step_kernel<double, RP> (HIP-event name bfgs_batch_step)",
+                        "achieved": None if ach is None else round(ach, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "note": "rank 0's kernel; 1.5 n^2 T per accepted instance-step (lower triangle of H: read twice, written once); line searches included in the time"},
+           "kernels": kern}
+    batch.close()
+    return res
+
+
+def launch_check(args):
+    """--workload launch_check: the multi-rank plumbing (self-launch, rendezvous, rank environment, one collective)
+    WITHOUT a GPU -- what tests/test_bench_launch.py runs on CPU.  Prints the ranks the group saw."""
+    world, rank, local = _dist_setup(args.gpus, use_gpu=False)
+    seen = [None] * world
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_gather_object(seen, (rank, local, os.environ.get("MASTER_ADDR"), os.environ.get("BENCH_SELF_LAUNCHED", "0")))
+        dist.destroy_process_group()
+    else:
+        seen = [(rank, local, os.environ.get("MASTER_ADDR"), os.environ.get("BENCH_SELF_LAUNCHED", "0"))]
+    if rank == 0:
+        print(json.dumps({"metric": "launch_check", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks": seen}))
+    return 0
+
+
 def secondary_workload(args):
     """Configs 2, 4, 5 of BASELINE.json: same JSON shape, their own metric strings."""
     import importlib
@@ -383,55 +491,8 @@ def secondary_workload(args):
                                            "quoted only because the contract asks for it"},
                     "kernels": kern})
     elif args.workload == "bfgs_batched":
-        n = 256 if args.n == 10_000_000 else args.n
-        B = args.batch
-        lo = rank * B                                              # weak scaling: B instances per GPU
-        X0 = np.stack([pcg32_uniform(n, 1000 + lo + b) for b in range(B)])
-        batch = dzo.BatchedBFGS(dzo.ROSENBROCK_CHAIN, X0, 1.0)
-        comm = _make_comm(dzo, world)                              # RCCL communicator behind the C ABI when N > 1
-        flag = sharding.ConvergenceFlag(poll=1, comm=comm)
-        polls = 0
-        batch.step(args.warmup, poll=False)
-        dzo.synchronize()
-        dzo.profile_reset(); dzo.profile_enable(True)
-        _barrier(world)
-        it0 = int(batch.iteration_count.to_host().sum())
-        t0 = time.perf_counter()
-        chunk = max(1, args.poll)
-        done_steps = 0
-        while done_steps < args.steps:
-            k = min(chunk, args.steps - done_steps)
-            batch.step(k, poll=False)
-            done_steps += k
-            if comm is not None:
-                comm.all_done([batch])                             # dzo_bfgs_batch_all_done: local count + one 4-byte all-reduce
-            else:
-                flag.update(batch.count_active() == 0)             # (single GPU, or the gloo rehearsal)
-            polls += 1
-        dzo.synchronize(); _barrier(world)
-        el = sharding.max_over_ranks(time.perf_counter() - t0)
-        dzo.profile_enable(False)
-        it1 = int(batch.iteration_count.to_host().sum())
-        inst_steps = sharding.sum_over_ranks(float(it1 - it0))
-        tab = dzo.profile_table()
-        kern = {k: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for k, v in tab.items()}
-        # the step kernel reads and writes the LOWER triangle of every H only: 1.5 n^2 T per BFGS instance-step
-        # (a gradient-descent step resets the triangle: 0.5 n^2 T; counted as a BFGS step here, an upper bound)
-        ach = 1.5 * n * n * 8 * (it1 - it0) / (1e-3 * tab["bfgs_batch_step"][1]) / 1e9 if "bfgs_batch_step" in tab else None
-        out.update({"metric": "instance-step!() calls/sec, batched dense BFGS n=256 fp64 (config 5)",
-                    "value": round(inst_steps / el, 1), "unit": "instance-step!() calls/s",
-                    "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
-                    "config": {"workload": f"batched BFGS, {B} instances/GPU x n={n}, chained Rosenbrock, fp64 (BASELINE configs[4])",
-                               "instances_per_gpu": B, "instances_total": B * world, "active_at_end": batch.count_active(),
-                               "rccl_world_size": comm.nranks if comm is not None else None,
-                               "parallelism": (f"instances sharded by rank (block partition), world size {world}; the only collective is "
-                                               f"the convergence flag: {'dzo_bfgs_batch_all_done (RCCL behind the C ABI)' if comm is not None else flag.transport}, "
-                                               f"{polls} polls in the timed region"),
-                               "device": info["name"]},
-                    "roofline": {"bound": "hbm", "kernel": "bfgs_batch_step", "achieved": None if ach is None else round(ach, 1),
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                                 "traffic": None, "note": "1.5 n^2 T per accepted instance-step (lower triangle of H: read twice, written once); line searches included in the time"},
-                    "kernels": kern})
+        comm = _make_comm(dzo, world)                              # RCCL communicator behind the C ABI when N > 1 (hard requirement)
+        out.update(batched_leg(dzo, sharding, args, world, rank, comm, info, args.steps, args.warmup))
     elif args.workload == "adgd":
         # AdGDOptimizer (src/DZOptimization.jl:179-312) on the headline objective
         n = args.n
@@ -597,11 +658,18 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--kernel-events", type=int, default=1, choices=[1, 2],
                     help="HIP events in the timed region: 1 = the two-loop (roofline) kernels only, 2 = every kernel")
-    ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32", "adgd"],
+    ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32", "adgd", "launch_check"],
                     help="lbfgs = BASELINE configs[2] (the headline; default). The others are the remaining "
                          "BASELINE configs, reported as secondary lines.")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
+    ap.add_argument("--batched-steps", type=int, default=0,
+                    help="N > 1: timed synchronous steps of the config-5 `batched` object (default: max(--steps, 100))")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the driver's own multi-GPU form as a child, before anything here touches the GPU
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    if args.workload == "launch_check":
+        return launch_check(args)
     if args.workload != "lbfgs":
         return secondary_workload(args)
 
@@ -651,6 +719,12 @@ def main():
     any_stuck = sharding.max_over_ranks(1.0 if opt.is_stuck else 0.0) > 0
 
     table = dzo.profile_table()
+    # N > 1: the quantity north_star shards -- config 5, B independent dense-BFGS instances per GPU, the convergence
+    # flag over the same RCCL communicator (every rank takes part)
+    batched = None
+    if world > 1:
+        bsteps = args.batched_steps or max(args.steps, 100)
+        batched = batched_leg(dzo, sharding, args, world, rank, comm, info, bsteps, args.warmup)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -683,7 +757,12 @@ def main():
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            symbol = {"lbfgs_single_pass": ("lbfgs_point_pass_kernel<double, 20, false>" if opt.ring_layout == 2 and m > 16 else
+                                            "lbfgs_point_pass_kernel" if opt.ring_layout == 2 else "lbfgs_single_pass_kernel"),
+                      "lbfgs_gram_pass": "gram_pass_lanes_kernel", "lbfgs_combine": "combine_kernel",
+                      "lbfgs_chain_link": "chain_link_kernel"}[dom]
+            roofline = {"bound": "hbm", "kernel": symbol, "hip_event_name": dom,
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize, opt.ring_layout),
                         "avg_launch_us": kernels[dom]["avg_us"]}
@@ -722,6 +801,8 @@ def main():
                    "f_start": f_start, "f_end": opt.current_objective_value, "device": info["name"]},
         "roofline": roofline, "kernels": kernels,
     }
+    if batched is not None:
+        out["batched"] = batched
     if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N = 1 only
         threads = host_cores()
         cn = args.cpu_n or n

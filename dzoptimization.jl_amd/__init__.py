@@ -209,6 +209,7 @@ ABI = {
     "dzo_comm_init_all": [_P(_i32), _i32, _P(_vp)], "dzo_comm_destroy": [_vp],
     "dzo_comm_info": [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i64)],
     "dzo_flag_allreduce_min": [_vp, _P(_i32), _P(_i32)],
+    "dzo_flag_allreduce_min_n": [_vp, _P(_i32), _i32, _P(_i32)],
     "dzo_bfgs_batch_all_done": [_vp, _P(_vp), _i32, _P(_i32)],
 }
 
@@ -1049,9 +1050,33 @@ class Comm:
         broadcast through the group (any backend), then every rank joins."""
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        return cls.init_rank(box[0], world, rank)
+        # Every rank runs the SAME sequence of collectives whatever fails locally (a rank that raised before a
+        # collective the others have entered would hang the group): (1) every rank probes that it can load RCCL
+        # through the C ABI -- rank 0's probe is the id itself -- and the outcomes are gathered; (2) only when all
+        # are fine does anyone enter the RCCL bootstrap; (3) the outcomes of that are gathered as well.
+        uid, err = None, None
+        try:
+            uid = cls.unique_id()                         # (ranks > 0: a probe; their id is dropped)
+        except Exception as e:                            # noqa: BLE001 -- reported to every rank below
+            err = f"rank {rank}: {e}"
+        box = [None] * world
+        dist.all_gather_object(box, (uid if rank == 0 else None, err))
+        errs = [b[1] for b in box if b[1]]
+        if errs:
+            raise DzoError(5, "RCCL communicator not created (no rank entered the bootstrap): " + "; ".join(errs))
+        comm, err = None, None
+        try:
+            comm = cls.init_rank(box[0][0], world, rank)
+        except Exception as e:                            # noqa: BLE001
+            err = f"rank {rank}: {e}"
+        box = [None] * world
+        dist.all_gather_object(box, err)
+        errs = [b for b in box if b]
+        if errs:
+            if comm is not None:
+                comm.close()
+            raise DzoError(2, "ncclCommInitRank failed: " + "; ".join(errs))
+        return comm
 
     def _info(self):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
@@ -1067,7 +1092,7 @@ class Comm:
         flags = [int(local_flags)] if np.isscalar(local_flags) or isinstance(local_flags, bool) else [int(f) for f in local_flags]
         arr = (C.c_int32 * len(flags))(*flags)
         out = C.c_int32()
-        _check(lib().dzo_flag_allreduce_min(self.h, arr, C.byref(out)))
+        _check(lib().dzo_flag_allreduce_min_n(self.h, arr, len(flags), C.byref(out)))   # (the count is checked against the local ranks)
         return out.value
 
     def all_done(self, batches) -> bool:

@@ -516,6 +516,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     DZO_REQUIRE(out && x_dev && g_dev && n >= 1, DZO_ERR_INVALID, "bad argument");
     DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
     DZO_REQUIRE(initial_step_length > 0, DZO_ERR_ASSERT, "@assert initial_step_length > 0 (src/DZOptimization.jl:229)");
+    DZO_TRY(require_same_backend("AdGDOptimizer", "src/DZOptimization.jl:216-217", x_dev, "initial_point", g_dev, "initial_gradient"));
     dzo_adgd_s *o = new dzo_adgd_s();
     OptCore &c = o->core;
     c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
@@ -548,6 +549,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
 int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initial_step_length, dzo_adgd_t *out) {
     DZO_TRY(require_init());
     DZO_REQUIRE(problem && x_dev && out, DZO_ERR_INVALID, "null argument");
+    DZO_TRY(require_same_backend("AdGDOptimizer", "src/DZOptimization.jl:254,264", x_dev, "initial_point", nullptr, ""));
     if (problem->cons_on)                                          // :256-258
         DZO_TRY(dzo_box_clamp(problem->n, problem->dtype, x_dev, problem->cons_lo, problem->cons_hi));
     double f0 = 0;
@@ -566,8 +568,9 @@ int32_t dzo_adgd_create_problem(dzo_problem_t problem, void *x_dev, double initi
 
 int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (!o) return DZO_OK;
+    DeviceScope scope(o->device);
     if (o->core.stream && o->x_user) (void)adgd_settle(o);           // the caller's arrays end up holding the final point / gradient
-    unsettled_remove(o);
+    unsettled_retire(o);                                             // (a dzo_synchronize on another thread may be settling this handle right now)
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->dx_buf) (void)hipFree(o->dx_buf);
     if (o->dg_buf) (void)hipFree(o->dg_buf);
@@ -583,8 +586,8 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
 int32_t dzo_adgd_set_callbacks(dzo_adgd_t o, dzo_constraint_fn constraint, dzo_objective_fn objective,
                                dzo_gradient_fn gradient, void *cb_ctx) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     {
-        DeviceScope scope(o->device);
         std::lock_guard<std::recursive_mutex> lk(o->mu);
         DZO_TRY(adgd_cancel_pipeline(o));
     }
@@ -595,6 +598,7 @@ int32_t dzo_adgd_set_callbacks(dzo_adgd_t o, dzo_constraint_fn constraint, dzo_o
 
 int32_t dzo_adgd_step(dzo_adgd_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     return adgd_step(o);
 }
 

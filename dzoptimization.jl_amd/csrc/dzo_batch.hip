@@ -662,6 +662,7 @@ static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_
                     (problem_kind == DZO_PROBLEM_QUADRATIC && ob.A),
                 DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective and the dense quadratic with a shared A");
     DZO_REQUIRE(batch >= 1, DZO_ERR_INVALID, "batch must be >= 1");
+    DZO_TRY(require_same_backend("batched BFGSOptimizer", "src/DZOptimization.jl:363-364", x0_dev, "initial_points", nullptr, ""));
     DZO_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024, DZO_ERR_UNSUPPORTED,
                 "batched mode needs an even n in 2..1024 (got %lld)", (long long)n);
     dzo_bfgs_batch_s *b = new dzo_bfgs_batch_s();

@@ -1282,6 +1282,9 @@ static int32_t bfgs_convert(dzo_bfgs_s *src, dzo_bfgs_s *o) {
 
 static int32_t bfgs_create_common(dzo_bfgs_s *o, const void *x0_dev, double initial_step_length) {
     const size_t es = dtype_size(o->dtype);
+    // (the legacy optimizers predate KernelAbstractions; the same-device rule of src/DZOptimization.jl:363-364 is
+    // applied to the one array they are given)
+    DZO_TRY(require_same_backend("BFGSOptimizer", "src/DZOptimization.jl:363-364", x0_dev, "initial_point", nullptr, ""));
     DZO_TRY(bfgs_alloc(o));
     DZO_HIP(hipMemcpy(o->x, x0_dev, (size_t)o->n * es, hipMemcpyDeviceToDevice));   // :769 copy
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
@@ -1315,6 +1318,7 @@ static int32_t gd_create_common(dzo_bfgs_s *o, const void *x0_dev, double initia
     const size_t es = dtype_size(o->dtype);
     o->no_hessian = true;
     o->sign = 1.0;
+    DZO_TRY(require_same_backend("GradientDescentOptimizer", "src/DZOptimization.jl:363-364", x0_dev, "initial_point", nullptr, ""));
     DZO_TRY(bfgs_alloc(o));
     DZO_HIP(hipMemcpy(o->x, x0_dev, (size_t)o->n * es, hipMemcpyDeviceToDevice));   // :339 collect
     DZO_HIP(hipDeviceSynchronize());

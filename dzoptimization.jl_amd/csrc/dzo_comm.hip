@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "dzo_common.h"
@@ -40,6 +41,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;                    // dlerror() of the failed dlopen / the missing symbol, captured when it happened
 };
 
 static Rccl &rccl() {
@@ -50,6 +52,8 @@ static Rccl &rccl() {
         for (const char *nm : names) {
             r.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
+            const char *e = dlerror();                      // (read once: the call clears it)
+            r.why += std::string(r.why.empty() ? "" : "; ") + (e ? e : "dlopen failed");
         }
         if (!r.handle) return;
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name))
@@ -64,13 +68,14 @@ static Rccl &rccl() {
 #undef SYM
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd &&
                r.GetErrorString;
+        if (!r.ok) r.why = "librccl was loaded but lacks one of the nccl* entry points this library binds";
     });
     return r;
 }
 
 static int32_t require_rccl() {
     if (!rccl().ok) {
-        set_error("RCCL is not available: dlopen(librccl.so.1) failed or a symbol is missing (%s)", dlerror() ? dlerror() : "no dlerror");
+        set_error("RCCL is not available: %s", rccl().why.c_str());
         return DZO_ERR_UNSUPPORTED;
     }
     return DZO_OK;
@@ -206,6 +211,13 @@ int32_t dzo_comm_info(dzo_comm_t c, int32_t *nranks, int32_t *nlocal, int32_t *f
 
 // MIN over all ranks of one int32 per rank.  local_flags has one entry per LOCAL rank (one for a
 // process-per-GPU communicator).  Blocking: returns when *global_flag is known.
+int32_t dzo_flag_allreduce_min_n(dzo_comm_t c, const int32_t *local_flags, int32_t nflags, int32_t *global_flag) {
+    DZO_REQUIRE(c && local_flags && global_flag, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE((size_t)nflags == c->devices.size(), DZO_ERR_INVALID, "one flag per local rank of the communicator (%d given, %zu local ranks)",
+                nflags, c->devices.size());
+    return dzo_flag_allreduce_min(c, local_flags, global_flag);
+}
+
 int32_t dzo_flag_allreduce_min(dzo_comm_t c, const int32_t *local_flags, int32_t *global_flag) {
     DZO_REQUIRE(c && local_flags && global_flag, DZO_ERR_INVALID, "null argument");
     const size_t nl = c->devices.size();

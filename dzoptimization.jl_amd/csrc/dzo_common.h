@@ -105,6 +105,17 @@ int32_t settle_all_optimizers();
 // while its live copy sits in a twin
 void unsettled_add(void *handle, int32_t (*settle)(void *handle));
 void unsettled_remove(void *handle);
+// destroy: remove the handle and wait until no OTHER thread is inside a settle call on it (call without the
+// handle's own mutex held, after the handle has been settled by the caller)
+void unsettled_retire(void *handle);
+
+// The reference constructors' backend asserts (src/DZOptimization.jl:363-364, 376-378, 410, 420; AdGD :216-226):
+// every array a constructor is given must live on the device of the calling thread's library context, where the
+// constructor allocates (`similar`) everything else.  DZO_ERR_ASSERT with the reference's wording for a host
+// pointer, memory HIP does not know, or another GPU's memory.  Null pointers are skipped.
+int32_t require_same_backend(const char *where, const char *cite, const void *a, const char *a_name, const void *b, const char *b_name);
+// device that owns a device pointer; -1 for host memory / unknown pointers
+int32_t pointer_device(const void *p);
 
 // ------------------------------------------------------------------------------ profiling
 // HIP-event pairs recorded on the launching stream around each kernel (bench roofline leg).

@@ -5,6 +5,8 @@
 #include "dzo_common.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <thread>
 
 namespace dzo {
 
@@ -77,8 +79,15 @@ int32_t require_init() {
 }
 
 // ---------------------------------------------------------------------------- twin-buffer registry
+// g_unsettled: the handles whose live point / gradient sit in internal buffers.  g_settling: the handles some
+// thread is settling right now OUTSIDE the registry lock (the settle function takes the handle's own mutex and
+// waits on its stream).  A destroy on another thread -- Julia finalizers run on any thread -- must not free a
+// handle that is in g_settling: unsettled_retire() removes the entry and waits until no other thread is inside
+// a settle call on it.
 static std::mutex g_unsettled_mu;
+static std::condition_variable g_unsettled_cv;
 static std::vector<std::pair<void *, int32_t (*)(void *)>> g_unsettled;
+static std::vector<std::pair<void *, std::thread::id>> g_settling;
 
 void unsettled_add(void *handle, int32_t (*settle)(void *)) {
     std::lock_guard<std::mutex> lk(g_unsettled_mu);
@@ -86,22 +95,74 @@ void unsettled_add(void *handle, int32_t (*settle)(void *)) {
     g_unsettled.emplace_back(handle, settle);
 }
 
-void unsettled_remove(void *handle) {
-    std::lock_guard<std::mutex> lk(g_unsettled_mu);
+static void unsettled_erase_locked(void *handle) {
     for (size_t i = 0; i < g_unsettled.size(); ++i)
         if (g_unsettled[i].first == handle) { g_unsettled.erase(g_unsettled.begin() + (long)i); return; }
 }
 
+void unsettled_remove(void *handle) {
+    std::lock_guard<std::mutex> lk(g_unsettled_mu);
+    unsettled_erase_locked(handle);
+}
+
+void unsettled_retire(void *handle) {
+    std::unique_lock<std::mutex> lk(g_unsettled_mu);
+    unsettled_erase_locked(handle);
+    const std::thread::id me = std::this_thread::get_id();
+    g_unsettled_cv.wait(lk, [&] {
+        for (auto &b : g_settling) if (b.first == handle && b.second != me) return false;
+        return true;
+    });
+}
+
 int32_t settle_all_optimizers() {
+    const std::thread::id me = std::this_thread::get_id();
     for (int guard = 0; guard < 1 << 20; ++guard) {
         std::pair<void *, int32_t (*)(void *)> e;
         {
-            std::lock_guard<std::mutex> lk(g_unsettled_mu);
+            std::unique_lock<std::mutex> lk(g_unsettled_mu);
             if (g_unsettled.empty()) return DZO_OK;
             e = g_unsettled.back();
+            g_settling.emplace_back(e.first, me);        // the handle stays alive until this entry is gone
         }
         const int32_t rc = e.second(e.first);            // settles, waits for the copies, removes itself
-        if (rc != DZO_OK) { unsettled_remove(e.first); return rc; }
+        {
+            std::lock_guard<std::mutex> lk(g_unsettled_mu);
+            for (size_t i = 0; i < g_settling.size(); ++i)
+                if (g_settling[i].first == e.first && g_settling[i].second == me) { g_settling.erase(g_settling.begin() + (long)i); break; }
+            if (rc != DZO_OK) unsettled_erase_locked(e.first);
+        }
+        g_unsettled_cv.notify_all();
+        if (rc != DZO_OK) return rc;
+    }
+    return DZO_OK;
+}
+
+// ---------------------------------------------------------------------------- backend assert (a8)
+int32_t pointer_device(const void *p) {
+    hipPointerAttribute_t a;
+    if (p && hipPointerGetAttributes(&a, p) == hipSuccess && (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged)) return a.device;
+    (void)hipGetLastError();
+    return -1;
+}
+
+int32_t require_same_backend(const char *where, const char *cite, const void *a, const char *a_name, const void *b, const char *b_name) {
+    const int want = ctx().device;
+    const void *ptrs[2] = {a, b};
+    const char *names[2] = {a_name, b_name};
+    for (int i = 0; i < 2; ++i) {
+        if (!ptrs[i]) continue;
+        const int dev = pointer_device(ptrs[i]);
+        if (dev < 0) {
+            set_error("%s: @assert backend == get_backend(%s) (%s): %s is not device memory (a host pointer, or memory HIP does not know)",
+                      where, names[i], cite, names[i]);
+            return DZO_ERR_ASSERT;
+        }
+        if (dev != want) {
+            set_error("%s: @assert backend == get_backend(%s) (%s): %s lives on device %d, the calling thread's library context is device %d",
+                      where, names[i], cite, names[i], dev, want);
+            return DZO_ERR_ASSERT;
+        }
     }
     return DZO_OK;
 }
@@ -291,12 +352,7 @@ int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launch
 }
 
 // device that owns a device pointer (-1: unknown / host memory -> stay on the current device)
-static int device_of(const void *p) {
-    hipPointerAttribute_t a;
-    if (p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice) return a.device;
-    (void)hipGetLastError();
-    return -1;
-}
+static int device_of(const void *p) { return pointer_device(p); }
 
 int32_t dzo_malloc(void **ptr_dev, int64_t bytes) {
     DZO_TRY(require_init());

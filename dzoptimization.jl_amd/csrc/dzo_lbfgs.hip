@@ -139,6 +139,12 @@ struct dzo_lbfgs_s {
     // place (lbfgs_leave_points) and continues on the kernels above.
     bool points = false;
     bool xg_lin_stale = false;      // point 0 is newer than the contiguous x_user / g_user
+    // The caller's arrays ARE current_point / current_gradient (:393): what the host writes into them between two
+    // steps must be what the next step starts from.  On the point ring they are copies of point 0, so whenever the
+    // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
+    // if somebody changed them, continues on the pair ring with the caller's values (lbfgs_adopt_host_writes).
+    bool xg_host_may_write = false;
+    int32_t *xg_differs = nullptr;  // device flag of that comparison
     // step_direction is not written by the passes (nothing on the point ring reads it: every trial recomputes it in
     // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
     const void *stage_kern = nullptr; size_t stage_bytes = 0; bool stage_small = false;   // dynamic-LDS attribute of the point pass
@@ -1426,6 +1432,24 @@ __global__ __launch_bounds__(kBlock) void ring_gather_kernel(int64_t nvec, const
     }
 }
 
+// does the contiguous vector still equal the stream it was gathered from?  (bitwise, NaN == NaN; one plain store
+// per block that saw a difference)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ring_compare_kernel(int64_t nvec, const T *__restrict__ stream, const T *__restrict__ lin, int64_t rowbytes,
+                                                              int32_t *__restrict__ differs) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ int lds_flag;
+    bool diff = false;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBlock) {
+        T a[N], b[N];
+        load16(hist_ptr<true>(stream, v, rowbytes), a);
+        load16(lin + v * N, b);
+#pragma unroll
+        for (int j = 0; j < N; ++j) diff |= !is_equal(a[j], b[j]);
+    }
+    block_raise_flag(diff, differs, &lds_flag);
+}
+
 // ============================================================================ post-gradient
 // :480 delta_gradient = g - delta_gradient, fused with the partials of
 // rho = dot(delta_point, delta_gradient) (:505).
@@ -1827,6 +1851,11 @@ template <typename T> static void ring_gather_diff(dzo_lbfgs_s *o, const void *a
     const int grid = stream_grid(nvec, 1);
     hipLaunchKernelGGL(ring_gather_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)a, (const T *)b, (T *)lin, o->rowbytes);
 }
+template <typename T> static void ring_compare(dzo_lbfgs_s *o, const void *stream, const void *lin) {
+    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int grid = stream_grid(nvec, 1);
+    hipLaunchKernelGGL(ring_compare_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)stream, (const T *)lin, o->rowbytes, o->xg_differs);
+}
 template <typename T> static void ring_diff(dzo_lbfgs_s *o, void *a, const void *b) {
     const int grid = stream_grid(o->ring_rows * 64, 1);
     hipLaunchKernelGGL(ring_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->ring_rows, (T *)a, (const T *)b, o->rowbytes);
@@ -1839,6 +1868,7 @@ static int32_t lbfgs_points_settle(dzo_lbfgs_s *o) {
     DZO_DISPATCH(o->core.dtype, (ring_gather<T>(o, o->s_slot_v(o->newest), o->x_user), ring_gather<T>(o, o->y_slot_v(o->newest), o->g_user)));
     DZO_HIP(hipGetLastError());
     o->xg_lin_stale = false;
+    o->xg_host_may_write = true;                          // (whoever asked for the gather may write into the arrays)
     return DZO_OK;
 }
 
@@ -2546,6 +2576,29 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     }
 }
 
+// Point ring, before a step: if the host changed current_point / current_gradient since they were last gathered
+// (dzo_memcpy_*, its own kernels through the pointers of get_ptr, the arrays it passed to the constructor), the
+// step must start from the caller's values (:393 aliasing).  The ring keeps its own point 0 for the pairs --
+// exactly what the reference's stored delta_point_history is: unaffected by such a write -- and turns into the
+// pair ring; the run continues on the pair kernels with x / g = the caller's arrays.
+static int32_t lbfgs_adopt_host_writes(dzo_lbfgs_s *o) {
+    if (!o->points || !o->xg_host_may_write) return DZO_OK;
+    OptCore &c = o->core;
+    o->xg_host_may_write = false;
+    if (o->xg_lin_stale) return DZO_OK;                   // (the arrays do not hold a gathered copy at all)
+    DZO_HIP(hipMemsetAsync(o->xg_differs, 0, sizeof(int32_t), c.stream));
+    DZO_DISPATCH(c.dtype, (ring_compare<T>(o, o->s_slot_v(o->newest), o->x_user), ring_compare<T>(o, o->y_slot_v(o->newest), o->g_user)));
+    DZO_HIP(hipGetLastError());
+    int32_t differs = 0;
+    DZO_HIP(hipMemcpyAsync(&differs, o->xg_differs, sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+    DZO_HIP(hipStreamSynchronize(c.stream));
+    if (!differs) return DZO_OK;
+    DZO_TRY(lbfgs_leave_points(o));                       // (gathers nothing: the arrays are "fresh")
+    // the scalars computed behind the last decision belong to the old gradient
+    o->spec_scalars = false; o->gram_ready = false; o->scalars_ready = false; o->gram_rebuild = true;
+    return DZO_OK;
+}
+
 static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (c.is_stuck) return DZO_OK;                        // :456-458
@@ -2558,6 +2611,7 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     }
     bool quasi = false;
     o->last_step_kind = 0;
+    DZO_TRY(lbfgs_adopt_host_writes(o));
     if (o->points) {
         if (points_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_points<T>(o)); }
         DZO_TRY(lbfgs_leave_points(o));                   // an option the passes do not serve: continue on the pair ring
@@ -2608,6 +2662,8 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     DZO_REQUIRE(history_length >= 1 && history_length <= kMaxHistory, DZO_ERR_INVALID,
                 "history_length must be in 1..%d", kMaxHistory);
     DZO_REQUIRE(initial_step_length > 0, DZO_ERR_ASSERT, "@assert initial_step_length > 0 (src/DZOptimization.jl:380)");
+    // :363-364 (and :366-378: everything `similar` allocates below lands on the same device by construction)
+    DZO_TRY(require_same_backend("LBFGSOptimizer", "src/DZOptimization.jl:363-364", x_dev, "initial_point", g_dev, "initial_gradient"));
     dzo_lbfgs_s *o = new dzo_lbfgs_s();
     OptCore &c = o->core;
     c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
@@ -2690,7 +2746,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         const int64_t tiles = (n / (16 / (int64_t)es) + tile_v - 1) / tile_v;
         if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
     }
-    const size_t nscal = 2 + (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
+    const size_t nscal = 2 + 2 + (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
                          (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1) + 4 * (size_t)kMaxPartialBlocks;
     double *base = nullptr;
     ALLOC(base, nscal * sizeof(double));
@@ -2698,6 +2754,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     (void)hipMemset(base, 0, nscal * sizeof(double));
     (void)hipDeviceSynchronize();
     o->gram_ticket = reinterpret_cast<unsigned int *>(base); base += 2;   // (zeroed with the rest; re-armed by the kernel)
+    o->xg_differs = reinterpret_cast<int32_t *>(base); base += 2;
     o->rho = base; base += m1;
     o->alpha = base; base += kMaxHistory;
     o->coef = base; base += kMaxHistory;
@@ -2711,47 +2768,54 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     o->yg = base; base += kMaxHistory;
     o->gram_partials = base; base += (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1);
     o->link_partials = base;
-    // :366-374 zero-filled deltas: the whole ring starts zeroed
-    if (o->blocked) {
-        DZO_HIP(hipMemsetAsync(o->S, 0, o->ring_bytes, c.stream));
-        DZO_HIP(hipMemsetAsync(o->dx_lin, 0, (size_t)o->stride * es, c.stream));
-        DZO_HIP(hipMemsetAsync(o->dg_lin, 0, (size_t)o->stride * es, c.stream));
-    } else if (o->interleaved) {
-        DZO_HIP(hipMemsetAsync(o->S, 0, 2 * slab, c.stream));
-    } else {
-        DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
-        DZO_HIP(hipMemsetAsync(o->Y, 0, slab, c.stream));
-    }
-    o->k = 0; o->newest = o->nslots - 1;   // spare() == 0
-    o->refresh_delta_ptrs();
-    if (o->blocked && tune("DZO_TUNE_POINT_RING", 1) != 0) {
-        // point ring: the start point and its gradient are point 0
-        o->points = true;
-        o->lazy_d = tune("DZO_TUNE_LAZY_D", 1) != 0;
-        DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
-        DZO_HIP(hipGetLastError());
-    }
-    // :381-388
-    double gnorm = 0;
-    rc = dot_blocking(c.stream, n, dtype, g_dev, g_dev, c.partials(), c.host, &gnorm);
-    if (rc != DZO_OK) { dzo_lbfgs_destroy(o); return rc; }
-    gnorm = dtype == DZO_F32 ? (double)sqrtf((float)gnorm) : sqrt(gnorm);
-    c.is_stuck = (gnorm == 0.0);                          // :382 iszero
-    if (c.is_stuck) {
-        DZO_HIP(hipMemsetAsync(o->d, 0, (size_t)o->stride * es, c.stream));   // :384
-    } else {
-        const double sc = round_to_dtype(dtype, -initial_step_length / gnorm);
-        DZO_DISPATCH(dtype, launch_scal_oop<T>(c.stream, n, (T *)o->d, (T)sc, (const T *)g_dev));  // :386-387
-    }
-    DZO_HIP(hipStreamSynchronize(c.stream));
+    // (from here on a failure must give the state back: the ring alone is gigabytes)
+    auto finish = [&]() -> int32_t {
+        // :366-374 zero-filled deltas: the whole ring starts zeroed
+        if (o->blocked) {
+            DZO_HIP(hipMemsetAsync(o->S, 0, o->ring_bytes, c.stream));
+            DZO_HIP(hipMemsetAsync(o->dx_lin, 0, (size_t)o->stride * es, c.stream));
+            DZO_HIP(hipMemsetAsync(o->dg_lin, 0, (size_t)o->stride * es, c.stream));
+        } else if (o->interleaved) {
+            DZO_HIP(hipMemsetAsync(o->S, 0, 2 * slab, c.stream));
+        } else {
+            DZO_HIP(hipMemsetAsync(o->S, 0, slab, c.stream));
+            DZO_HIP(hipMemsetAsync(o->Y, 0, slab, c.stream));
+        }
+        o->k = 0; o->newest = o->nslots - 1;   // spare() == 0
+        o->refresh_delta_ptrs();
+        if (o->blocked && tune("DZO_TUNE_POINT_RING", 1) != 0) {
+            // point ring: the start point and its gradient are point 0
+            o->points = true;
+            o->lazy_d = tune("DZO_TUNE_LAZY_D", 1) != 0;
+            o->xg_host_may_write = true;                      // (the caller owns x0 / g0 and may change them before the first step)
+            DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
+            DZO_HIP(hipGetLastError());
+        }
+        // :381-388
+        double gnorm = 0;
+        DZO_TRY(dot_blocking(c.stream, n, dtype, g_dev, g_dev, c.partials(), c.host, &gnorm));
+        gnorm = dtype == DZO_F32 ? (double)sqrtf((float)gnorm) : sqrt(gnorm);
+        c.is_stuck = (gnorm == 0.0);                          // :382 iszero
+        if (c.is_stuck) {
+            DZO_HIP(hipMemsetAsync(o->d, 0, (size_t)o->stride * es, c.stream));   // :384
+        } else {
+            const double sc = round_to_dtype(dtype, -initial_step_length / gnorm);
+            DZO_DISPATCH(dtype, launch_scal_oop<T>(c.stream, n, (T *)o->d, (T)sc, (const T *)g_dev));  // :386-387
+        }
+        DZO_HIP(hipStreamSynchronize(c.stream));
+        return DZO_OK;
+    };
+    rc = finish();
+    if (rc != DZO_OK) { o->x_user = nullptr; dzo_lbfgs_destroy(o); return rc; }   // (x_user cleared: nothing to settle)
     *out = o;
     return DZO_OK;
 }
 
 int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (!o) return DZO_OK;
+    DeviceScope scope(o->device);
     if (o->core.stream && o->x_user) (void)lbfgs_settle(o);   // the caller's arrays end up holding the final point / gradient
-    unsettled_remove(o);
+    unsettled_retire(o);                                  // (a dzo_synchronize on another thread may be settling this handle right now)
     if (o->core.stream) (void)hipStreamSynchronize(o->core.stream);
     if (o->S) (void)hipFree(o->S);
     if (o->Y && !o->interleaved && !o->blocked) (void)hipFree(o->Y);
@@ -2774,6 +2838,7 @@ int32_t dzo_lbfgs_create_callbacks(dzo_constraint_fn constraint, dzo_objective_f
     DZO_TRY(require_init());
     DZO_REQUIRE(objective && gradient && x_dev && out, DZO_ERR_INVALID, "null argument");
     DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    DZO_TRY(require_same_backend("LBFGSOptimizer", "src/DZOptimization.jl:410,420", x_dev, "initial_point", nullptr, ""));   // before any callback sees it
     if (constraint) DZO_REQUIRE(constraint(cb_ctx, x_dev) != 0, DZO_ERR_ASSERT,
                                 "@assert constraint_function!(initial_point) (src/DZOptimization.jl:412-414)");
     const double f0 = objective(cb_ctx, x_dev);           // :416
@@ -2790,6 +2855,7 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
                                  double initial_step_length, dzo_lbfgs_t *out) {
     DZO_TRY(require_init());
     DZO_REQUIRE(problem && x_dev && out, DZO_ERR_INVALID, "null argument");
+    DZO_TRY(require_same_backend("LBFGSOptimizer", "src/DZOptimization.jl:410,420", x_dev, "initial_point", nullptr, ""));
     if (problem->cons_on)                                 // :412-414 @assert constraint_function!(initial_point)
         DZO_TRY(dzo_box_clamp(problem->n, problem->dtype, x_dev, problem->cons_lo, problem->cons_hi));
     double f0 = 0;
@@ -2813,6 +2879,7 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
 int32_t dzo_lbfgs_set_callbacks(dzo_lbfgs_t o, dzo_constraint_fn constraint, dzo_objective_fn objective,
                                 dzo_gradient_fn gradient, void *cb_ctx) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     o->core.constraint = constraint; o->core.objective = objective; o->core.gradient = gradient;
     o->core.cb_ctx = cb_ctx;
     return DZO_OK;
@@ -2822,6 +2889,7 @@ int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t o, dzo_problem_t problem) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(!problem || (problem->n == o->core.n && problem->dtype == o->core.dtype), DZO_ERR_INVALID,
                 "problem size/dtype does not match the optimizer");
+    DeviceScope scope(o->device);
     (void)hipStreamSynchronize(o->core.stream);
     problem_view_destroy(o->core.problem);
     o->core.problem = nullptr;
@@ -2834,6 +2902,7 @@ int32_t dzo_lbfgs_set_problem(dzo_lbfgs_t o, dzo_problem_t problem) {
 int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t o, int32_t mode) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(mode == DZO_TWOLOOP_CHAIN || mode == DZO_TWOLOOP_GRAM, DZO_ERR_INVALID, "bad two-loop mode %d", mode);
+    DeviceScope scope(o->device);
     DZO_TRY(lbfgs_flush_rho(o));
     if (mode == DZO_TWOLOOP_CHAIN) DZO_TRY(lbfgs_unblock(o));   // the chain kernels walk the pairs as plain vectors
     if (mode == DZO_TWOLOOP_GRAM && o->mode != DZO_TWOLOOP_GRAM) o->gram_rebuild = true;
@@ -2843,17 +2912,20 @@ int32_t dzo_lbfgs_set_two_loop_mode(dzo_lbfgs_t o, int32_t mode) {
 
 int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t o, int64_t max_halvings) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     o->core.max_halvings = max_halvings;
     return DZO_OK;
 }
 
 int32_t dzo_lbfgs_step(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     return lbfgs_step(o);
 }
 
 int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     DZO_TRY(lbfgs_leave_points(o));                       // the standalone two-loop works on the pair ring
     // returns after the enqueue (include/dzo.h, asynchrony): step_direction is complete once a getter
@@ -2863,6 +2935,7 @@ int32_t dzo_lbfgs_direction(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     DZO_TRY(lbfgs_leave_points(o));                       // the host-driven step works on the contiguous arrays and the pair ring
     DZO_TRY(lbfgs_flush_rho(o));                          // a host-driven step follows: settle what the single pass deferred
     o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false;
@@ -2872,11 +2945,13 @@ int32_t dzo_lbfgs_begin_search(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_trial(dzo_lbfgs_t o, double step_size, int32_t *changed) {
     DZO_REQUIRE(o && changed, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
     return core_trial(o->core, step_size, o->d, false, changed, nullptr, nullptr);
 }
 
 int32_t dzo_lbfgs_accept(dzo_lbfgs_t o, double next_objective_value) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     DZO_TRY(core_accept(o->core, round_to_dtype(o->core.dtype, next_objective_value)));
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     return DZO_OK;
@@ -2884,6 +2959,7 @@ int32_t dzo_lbfgs_accept(dzo_lbfgs_t o, double next_objective_value) {
 
 int32_t dzo_lbfgs_reject(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     DZO_TRY(core_reject(o->core));
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     return DZO_OK;
@@ -2891,6 +2967,7 @@ int32_t dzo_lbfgs_reject(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_pre_gradient(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     OptCore &c = o->core;
     DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
     DZO_HIP(hipStreamSynchronize(c.stream));
@@ -2899,6 +2976,7 @@ int32_t dzo_lbfgs_pre_gradient(dzo_lbfgs_t o) {
 
 int32_t dzo_lbfgs_post_gradient(dzo_lbfgs_t o) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     DZO_TRY(lbfgs_post_gradient(o));
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     return DZO_OK;
@@ -2937,6 +3015,7 @@ int32_t dzo_lbfgs_get_s(dzo_lbfgs_t o, int32_t what, double *value) {
 
 int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t o, int32_t descent_check, int32_t steepest_descent_fallback) {
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
+    DeviceScope scope(o->device);
     o->descent_check = descent_check != 0;
     o->sd_fallback = steepest_descent_fallback != 0;
     return DZO_OK;
@@ -2948,6 +3027,7 @@ int32_t dzo_lbfgs_set_line_search(dzo_lbfgs_t o, int32_t kind, double c1, double
                 "unknown line search %d", kind);
     DZO_REQUIRE(!(c1 > 0 && c2 > 0) || c1 < c2, DZO_ERR_INVALID, "Wolfe constants need 0 < c1 < c2 < 1");
     DZO_REQUIRE(c2 < 1.0, DZO_ERR_INVALID, "Wolfe constants need 0 < c1 < c2 < 1");
+    DeviceScope scope(o->device);
     o->line_search = kind;
     if (c1 > 0) o->wolfe_c1 = round_to_dtype(o->core.dtype, c1);
     if (c2 > 0) o->wolfe_c2 = round_to_dtype(o->core.dtype, c2);
@@ -2970,6 +3050,7 @@ int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t o, int32_t is_stuck) {
 
 int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_dev) {
     DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
     DZO_TRY(lbfgs_settle(o));                             // current_point / current_gradient ARE the caller's arrays again
     if (what == 1 || what == 3) DZO_TRY(lbfgs_refresh_lin(o));   // blocked ring: delta_point / delta_gradient gathered on demand
     if (what == 4) DZO_TRY(lbfgs_materialize_d(o));              // point ring: step_direction formed on demand
@@ -3014,6 +3095,7 @@ int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_d
 
 int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t *count) {
     DZO_REQUIRE(o && count, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
     *count = o->k;
     if (!out) return DZO_OK;
     DZO_TRY(lbfgs_flush_rho(o));
@@ -3026,6 +3108,7 @@ int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t 
 
 int32_t dzo_lbfgs_get_alpha(dzo_lbfgs_t o, double *out, int32_t capacity, int32_t *count) {
     DZO_REQUIRE(o && count, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
     *count = o->n_alpha;
     if (!out) return DZO_OK;
     DZO_HIP(hipStreamSynchronize(o->core.stream));
@@ -3040,6 +3123,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(o, DZO_ERR_INVALID, "null optimizer");
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
+    DeviceScope scope(o->device);
     if (o->points) {                                     // installed PAIRS: the ring is a pair ring from here on
         DZO_TRY(lbfgs_materialize_d(o));
         DZO_TRY(lbfgs_points_settle(o));

@@ -293,6 +293,9 @@ int32_t dzo_line_search_eval(dzo_constraint_fn constraint, dzo_objective_fn obje
                     slope_ratio && n >= 1,
                 DZO_ERR_INVALID, "bad argument");
     DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
+    // :44-54: the evaluator's arrays share one backend
+    DZO_TRY(require_same_backend("LineSearchEvaluator", "src/DZOptimization.jl:44-54", x_dev, "current_point", d_dev, "step_direction"));
+    DZO_TRY(require_same_backend("LineSearchEvaluator", "src/DZOptimization.jl:44-54", trial_point_dev, "trial_point", trial_gradient_dev, "trial_gradient"));
     hipStream_t s = ctx().stream;
     // :69-70  trial = x; trial += t*d   (one fused rounding per element either way)
     DZO_DISPATCH(dtype, launch_axpy_oop<T>(s, n, (T *)trial_point_dev, (T)step_size, (const T *)d_dev, (const T *)x_dev));

@@ -630,7 +630,7 @@ end
 """`allreduce_min(comm, local_flags)`: the raw 4-byte collective (one flag per local rank)."""
 function allreduce_min(comm::ShardComm, local_flags::AbstractVector{<:Integer})
     fl = Cint.(collect(local_flags)); r = Ref{Cint}(0)
-    check(ccall((:dzo_flag_allreduce_min, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ref{Cint}), comm.handle, fl, r))
+    check(ccall((:dzo_flag_allreduce_min_n, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cint}, Cint, Ref{Cint}), comm.handle, fl, length(fl), r))
     return Int(r[])
 end
 step!(b::BatchedBFGSOptimizer, steps::Integer=1) =

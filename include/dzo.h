@@ -455,6 +455,8 @@ int32_t dzo_bfgs_batch_device(dzo_bfgs_batch_t b, int32_t *device);
  *                       one process per GPU: rank 0 creates the 128-byte id, the launcher carries
  *                       it to the other ranks, every rank joins with the device it selected (dzo_init)
  *   dzo_flag_allreduce_min   local_flags: one int32 per LOCAL rank; blocking
+ *   dzo_flag_allreduce_min_n the same with the number of flags passed: DZO_ERR_INVALID unless it equals the
+ *                       communicator's local rank count (what bindings with sized arrays should call)
  *   dzo_bfgs_batch_all_done  counts the live instances of every local shard (concurrently), then one
  *                       all-reduce: *all_done = 1 when every instance of every shard has_terminated.
  *                       comm may be NULL (no collective); otherwise batches[i] must live on the
@@ -468,6 +470,7 @@ int32_t dzo_comm_destroy(dzo_comm_t comm);
 /* any of the outputs may be NULL; collectives = all-reduces issued so far */
 int32_t dzo_comm_info(dzo_comm_t comm, int32_t *nranks, int32_t *nlocal, int32_t *first_rank, int64_t *collectives);
 int32_t dzo_flag_allreduce_min(dzo_comm_t comm, const int32_t *local_flags, int32_t *global_flag);
+int32_t dzo_flag_allreduce_min_n(dzo_comm_t comm, const int32_t *local_flags, int32_t nflags, int32_t *global_flag);
 int32_t dzo_bfgs_batch_all_done(dzo_comm_t comm_or_null, const dzo_bfgs_batch_t *batches, int32_t nbatches,
                                 int32_t *all_done);
 

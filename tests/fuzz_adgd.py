@@ -1,6 +1,7 @@
-"""GPU fuzz of the one-pass AdGD step against the oracle: random sizes (row boundaries of the 62-vector
-wave-rows included), random initial step lengths (rejected first trials included), both dtypes.
-Test infrastructure (uses oracle/); not collected by pytest -- run by hand:  python tests/fuzz_adgd.py"""
+"""GPU fuzz of the one-pass AdGD step against the oracle: random sizes (row boundaries of the 62-vector wave-rows
+included), random initial step lengths (rejected first trials included), both dtypes.  Test infrastructure (uses
+oracle/).  tests/test_gpu_fuzz.py runs `run()` with a fixed seed and 20 cases under pytest; by hand for more:
+FUZZ_CASES=80 FUZZ_SEED=4321 python tests/fuzz_adgd.py"""
 import os
 import sys
 
@@ -10,32 +11,36 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dzo_loader import dzo  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 4321)))
-
 
 def rel(a, b):
     return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-300)
 
 
-worst = {np.float64: 0.0, np.float32: 0.0}
-fused = rejected = 0
-for ex in range(int(os.environ.get("FUZZ_CASES", 80))):
-    dtype = np.float64 if rng.integers(0, 3) else np.float32
-    vecn = 16 // np.dtype(dtype).itemsize
-    base = int(rng.choice([4, 31, 61, 62, 63, 123, 124, 125, 186, 248, 500, 2047, 4099, 25000]))
-    n = base * vecn if rng.integers(0, 4) else base * vecn + int(rng.integers(1, vecn))     # some ragged (generic path)
-    step0 = float(rng.choice([1e-3, 0.1, 1.0, 30.0, 300.0]))
-    x0 = ((orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5) * 2.0).astype(dtype)
-    ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype=dtype), x0.copy(), step0)
-    opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
-    tol = 1e-9 if dtype == np.float64 else 2e-3          # free run: fp32 trajectories drift
-    for it in range(40 if dtype == np.float64 else 12):
-        opt.step(); ref.step()
-        if ref.is_stuck or opt.is_stuck:
-            break
-        e = rel(opt.current_point.to_host(), ref.current_point)
-        worst[dtype] = max(worst[dtype], e)
-        assert e <= tol, (ex, it, n, dtype, step0, e)
-        assert opt.iteration_count == ref.iteration_count, (ex, it, n)
-    fused += opt.fused_steps; rejected += opt.fused_rejections
-print("ok: worst per-step error", {k.__name__: v for k, v in worst.items()}, "fused steps", fused, "after a rejected trial", rejected)
+def run(cases=80, seed=4321):
+    rng = np.random.default_rng(seed)
+    worst = {np.float64: 0.0, np.float32: 0.0}
+    fused = rejected = 0
+    for ex in range(cases):
+        dtype = np.float64 if rng.integers(0, 3) else np.float32
+        vecn = 16 // np.dtype(dtype).itemsize
+        base = int(rng.choice([4, 31, 61, 62, 63, 123, 124, 125, 186, 248, 500, 2047, 4099, 25000]))
+        n = base * vecn if rng.integers(0, 4) else base * vecn + int(rng.integers(1, vecn))     # some ragged (generic path)
+        step0 = float(rng.choice([1e-3, 0.1, 1.0, 30.0, 300.0]))
+        x0 = ((orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5) * 2.0).astype(dtype)
+        ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype=dtype), x0.copy(), step0)
+        opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
+        tol = 1e-9 if dtype == np.float64 else 2e-3          # free run: fp32 trajectories drift
+        for it in range(40 if dtype == np.float64 else 12):
+            opt.step(); ref.step()
+            if ref.is_stuck or opt.is_stuck:
+                break
+            e = rel(opt.current_point.to_host(), ref.current_point)
+            worst[dtype] = max(worst[dtype], e)
+            assert e <= tol, (ex, it, n, dtype, step0, e)
+            assert opt.iteration_count == ref.iteration_count, (ex, it, n)
+        fused += opt.fused_steps; rejected += opt.fused_rejections
+    return {"worst": {k.__name__: v for k, v in worst.items()}, "fused_steps": fused, "after_a_rejected_trial": rejected}
+
+
+if __name__ == "__main__":
+    print("ok:", run(int(os.environ.get("FUZZ_CASES", 80)), int(os.environ.get("FUZZ_SEED", 4321))))

@@ -1,7 +1,7 @@
 """GPU fuzz of step!() on the point ring: random n (row boundaries of the 62-vector wave-rows included), history
 lengths, initial step lengths (rejected first trials, deep halvings) and both dtypes; the GPU optimizer runs free,
-the oracle is given its state before every step.  Test infrastructure (uses oracle/); not collected by pytest --
-run by hand:  python tests/fuzz_points.py"""
+the oracle is given its state before every step.  Test infrastructure (uses oracle/).  tests/test_gpu_fuzz.py runs
+`run()` with a fixed seed and 20 cases under pytest; by hand for more:  FUZZ_CASES=200 FUZZ_SEED=7 python tests/fuzz_points.py"""
 import os
 import sys
 
@@ -11,49 +11,53 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dzo_loader import dzo  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 2468)))
-
-
 def rel(a, b):
     return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-300)
 
 
-worst = {np.float64: 0.0, np.float32: 0.0}
-retries = steps_total = 0
-for ex in range(int(os.environ.get("FUZZ_CASES", 60))):
-    dtype = np.float64 if rng.integers(0, 3) else np.float32
-    vecn = 16 // np.dtype(dtype).itemsize
-    base = int(rng.choice([4, 31, 61, 62, 63, 123, 124, 125, 186, 248, 500, 2047, 4099, 25000]))
-    n = base * vecn
-    m = int(rng.integers(1, 21))
-    step0 = float(rng.choice([1e-2, 1.0, 1.0, 30.0, 3000.0]))
-    x0 = ((orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5) * 2.0).astype(dtype)
-    if dtype == np.float32:
-        orc.set_dot_mode(orc.DOT_WIDE)
-    try:
-        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0, m)
-        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), step0, m)
-        assert opt.ring_layout == 2, (n, m)
-        for it in range(int(rng.integers(3, 2 * m + 8))):
-            k = opt.history_count
-            S = np.stack([h.to_host() for h in opt.delta_point_history]) if k else np.zeros((0, n), dtype)
-            Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n), dtype)
-            ref.install_state(opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value,
-                              S, Y, opt.rho_history[:k], opt.iteration_count)
-            opt.step(); ref.step()
-            assert opt.is_stuck == ref.is_stuck, (ex, it, n, m, step0)
-            if ref.is_stuck:
-                break
-            if ref.last_trials > 30 and opt.last_trials != ref.last_trials:
-                break        # dozens of halvings: f_new - f is at rounding level, the two summation orders may decide differently
-            assert opt.last_trials == ref.last_trials, (ex, it, n, m, step0, opt.last_trials, ref.last_trials)
-            e = rel(opt.step_direction.to_host(), ref.step_direction)
-            worst[dtype] = max(worst[dtype], e)
-            assert e <= (1e-9 if dtype == np.float64 else 1e-3), (ex, it, n, m, step0, e)
-            assert rel(opt.current_point.to_host(), ref.current_point) <= (1e-12 if dtype == np.float64 else 1e-6)
-            steps_total += 1
-        retries += opt.single_pass_retries
-        assert opt.ring_layout == 2
-    finally:
-        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
-print("ok: worst per-step direction error", worst, "steps", steps_total, "second and later passes of a step", retries)
+def run(cases=60, seed=2468):
+    """`cases` random optimizers; every step compared with the oracle.  Returns the worst errors and the step count."""
+    rng = np.random.default_rng(seed)
+    worst = {np.float64: 0.0, np.float32: 0.0}
+    retries = steps_total = 0
+    for ex in range(cases):
+        dtype = np.float64 if rng.integers(0, 3) else np.float32
+        vecn = 16 // np.dtype(dtype).itemsize
+        base = int(rng.choice([4, 31, 61, 62, 63, 123, 124, 125, 186, 248, 500, 2047, 4099, 25000]))
+        n = base * vecn
+        m = int(rng.integers(1, 21))
+        step0 = float(rng.choice([1e-2, 1.0, 1.0, 30.0, 3000.0]))
+        x0 = ((orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5) * 2.0).astype(dtype)
+        if dtype == np.float32:
+            orc.set_dot_mode(orc.DOT_WIDE)
+        try:
+            ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0, m)
+            opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), step0, m)
+            assert opt.ring_layout == 2, (n, m)
+            for it in range(int(rng.integers(3, 2 * m + 8))):
+                k = opt.history_count
+                S = np.stack([h.to_host() for h in opt.delta_point_history]) if k else np.zeros((0, n), dtype)
+                Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n), dtype)
+                ref.install_state(opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value,
+                                  S, Y, opt.rho_history[:k], opt.iteration_count)
+                opt.step(); ref.step()
+                assert opt.is_stuck == ref.is_stuck, (ex, it, n, m, step0)
+                if ref.is_stuck:
+                    break
+                if ref.last_trials > 30 and opt.last_trials != ref.last_trials:
+                    break        # dozens of halvings: f_new - f is at rounding level, the two summation orders may decide differently
+                assert opt.last_trials == ref.last_trials, (ex, it, n, m, step0, opt.last_trials, ref.last_trials)
+                e = rel(opt.step_direction.to_host(), ref.step_direction)
+                worst[dtype] = max(worst[dtype], e)
+                assert e <= (1e-9 if dtype == np.float64 else 1e-3), (ex, it, n, m, step0, e)
+                assert rel(opt.current_point.to_host(), ref.current_point) <= (1e-12 if dtype == np.float64 else 1e-6)
+                steps_total += 1
+            retries += opt.single_pass_retries
+            assert opt.ring_layout == 2
+        finally:
+            orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+    return {"worst": {k.__name__: v for k, v in worst.items()}, "steps": steps_total, "later_passes": retries}
+
+
+if __name__ == "__main__":
+    print("ok:", run(int(os.environ.get("FUZZ_CASES", 60)), int(os.environ.get("FUZZ_SEED", 2468))))

@@ -1011,3 +1011,144 @@ def test_point_ring_turns_into_the_pair_ring_without_changing_a_bit(monkeypatch)
     for i in range(1, k):                                 # the converted pairs are the pairs the point ring handed out
         assert np.array_equal(opt.delta_point_history[i].to_host(), S[i - 1])
         assert np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i - 1])
+
+
+# ------------------------------------------------------------------------------ stuck state of the passes
+@pytest.mark.parametrize("layout", ["points", "pairs", "two_pass"])
+@pytest.mark.parametrize("n,m", [(16, 3), (372, 5)])
+def test_lbfgs_stuck_step_leaves_the_reference_deltas(n, m, layout, monkeypatch):
+    """take_backtracking_step! that ends stuck (src/DZOptimization.jl:128-131: the trial point equals the old point
+    everywhere) leaves delta_point = x_old (:118 copy!(delta_point, current_point)) and does not touch delta_gradient,
+    which still holds the previous step's value; x, g, f, the history and iteration_count are those of the last
+    accepted step.  Run to convergence on all three L-BFGS step implementations (point ring, pair ring, two-pass
+    kernels), the oracle following the GPU, and compare the fields of the stuck optimizer with the oracle's."""
+    if layout == "pairs":
+        monkeypatch.setenv("DZO_TUNE_POINT_RING", "0")
+    if layout == "two_pass":
+        monkeypatch.setenv("DZO_TUNE_SINGLE_PASS", "0")
+    x0 = orc.rosenbrock_chain_x0(n)
+    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1.0, m)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    assert opt.ring_layout == {"points": 2, "pairs": 1, "two_pass": 0}[layout]
+    for it in range(5000):
+        k = opt.history_count
+        S = np.stack([h.to_host() for h in opt.delta_point_history]) if k else np.zeros((0, n))
+        Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n))
+        x, g, f = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value
+        dg_before = opt.delta_gradient.to_host()
+        ref.install_state(x, g, f, S, Y, opt.rho_history[:k], opt.iteration_count)
+        opt.step(); ref.step()
+        if opt.is_stuck or ref.is_stuck:
+            break
+    assert opt.is_stuck and ref.is_stuck, (it, opt.is_stuck, ref.is_stuck, opt.last_trials, ref.last_trials)
+    assert it > m + 2                                      # a steady-state step, history full
+    assert opt.iteration_count == ref.iteration_count == it
+    assert np.array_equal(opt.current_point.to_host(), x) and np.array_equal(opt.current_gradient.to_host(), g)   # :151 restored
+    assert opt.current_objective_value == f
+    assert np.array_equal(opt.delta_point.to_host(), x)                    # :118
+    assert np.array_equal(ref.delta_point, x)
+    assert np.array_equal(opt.delta_gradient.to_host(), dg_before)         # untouched
+    assert np.array_equal(opt.delta_gradient.to_host(), S.shape[0] and Y[0])
+    assert opt.history_count == k
+    for i in range(k):                                     # the history is the one the step started from
+        assert np.array_equal(opt.delta_point_history[i].to_host(), S[i]) and np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i])
+    assert rel(opt.step_direction.to_host(), ref.step_direction) <= 1e-9   # the direction the stuck search walked along
+    opt.step()                                             # :456-458: a stuck optimizer does nothing
+    assert opt.iteration_count == it and np.array_equal(opt.delta_point.to_host(), x)
+
+
+# ------------------------------------------------------------------------------ backend asserts (a8)
+def test_constructors_assert_that_their_arrays_live_on_the_context_device():
+    """src/DZOptimization.jl:363-364, 376-378, 410, 420 (and AdGD :216-226, LineSearchEvaluator :44-54): `@assert backend ==
+    get_backend(...)` -- every array a constructor is given must live where it allocates the rest.  The C constructors
+    reject host pointers, pointers HIP does not know and (with more than one GPU visible) another device's memory with
+    DZO_ERR_ASSERT before touching them."""
+    import ctypes as C
+    import torch
+    n = 4096
+    L = dzo.lib()
+    x = dzo.DeviceArray.from_host(orc.rosenbrock_chain_x0(n))
+    g = dzo.DeviceArray.from_host(np.ones(n))
+    host = np.ones(n)
+    hostp = C.c_void_p(host.ctypes.data)
+    pinned = torch.ones(n, dtype=torch.float64).pin_memory()               # registered host memory is still not device memory
+    pinp = C.c_void_p(pinned.data_ptr())
+    bogus = C.c_void_p(0x1000)
+    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+    out = C.c_void_p()
+
+    def expect_assert(rc, what):
+        assert rc == 3, (what, rc)                                         # DZO_ERR_ASSERT
+        msg = L.dzo_last_error().decode()
+        assert "@assert backend == get_backend(" in msg and what in msg, msg
+        assert not out.value
+
+    for bad, label in ((hostp, "host"), (pinp, "pinned"), (bogus, "bogus")):
+        expect_assert(L.dzo_lbfgs_create(n, 5, dzo.F64, bad, C.c_void_p(g.ptr), 1.0, 1.0, C.byref(out)), "initial_point")
+        expect_assert(L.dzo_lbfgs_create(n, 5, dzo.F64, C.c_void_p(x.ptr), bad, 1.0, 1.0, C.byref(out)), "initial_gradient")
+        expect_assert(L.dzo_lbfgs_create_problem(prob.h, 5, bad, 1.0, C.byref(out)), "initial_point")
+        expect_assert(L.dzo_adgd_create(n, dzo.F64, bad, C.c_void_p(g.ptr), 1.0, 1.0, C.byref(out)), "initial_point")
+        expect_assert(L.dzo_adgd_create(n, dzo.F64, C.c_void_p(x.ptr), bad, 1.0, 1.0, C.byref(out)), "initial_gradient")
+        expect_assert(L.dzo_adgd_create_problem(prob.h, bad, 1.0, C.byref(out)), "initial_point")
+        expect_assert(L.dzo_bfgs_create_problem(prob.h, bad, 1.0, C.byref(out)), "initial_point")
+        expect_assert(L.dzo_gd_create_problem(prob.h, bad, 1.0, C.byref(out)), "initial_point")
+    # callbacks must not be called with an array that fails the assert (:410 comes before :412-416)
+    calls = []
+    with pytest.raises(AssertionError):
+        dzo.LBFGSOptimizer(None, lambda x_: calls.append(1) or 0.0, lambda g_, x_: calls.append(2), dzo.DeviceArray(n, np.float64, ptr=host.ctypes.data, owner=False), 1.0, 5)
+    assert not calls
+    # the same arrays on the device pass
+    assert L.dzo_lbfgs_create(n, 5, dzo.F64, C.c_void_p(x.ptr), C.c_void_p(g.ptr), 1.0, 1.0, C.byref(out)) == 0
+    L.dzo_lbfgs_destroy(out); out.value = None
+    if torch.cuda.device_count() > 1:                                      # a pointer from another GPU (the mistake the assert catches on a node)
+        other = torch.ones(n, dtype=torch.float64, device="cuda:1")
+        expect_assert(L.dzo_lbfgs_create(n, 5, dzo.F64, C.c_void_p(other.data_ptr()), C.c_void_p(g.ptr), 1.0, 1.0, C.byref(out)), "initial_point")
+        assert "device 1" in L.dzo_last_error().decode()
+
+
+# ------------------------------------------------------------------------------ the caller's arrays ARE the current point (:393)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_point_ring_adopts_what_the_host_wrote_into_the_aliased_arrays(dtype):
+    """The optimizer aliases the caller's x0 (src/DZOptimization.jl:393) and `current_gradient`: what the host writes into
+    them between two steps is what the next step starts from, while delta_point_history / delta_gradient_history are
+    separate arrays that such a write does not change.  On the point ring the caller's arrays are copies of point 0;
+    a write is detected before the next step and the run continues (on the pair ring) exactly as the oracle does
+    from the same fields."""
+    n, m = 4100 if dtype == np.float64 else 8200, 6
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)
+    try:
+        pr = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype)
+        xd = dzo.DeviceArray.from_host(x0)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, xd, 1.0, m)
+        for _ in range(m + 2):
+            opt.step()
+        assert opt.ring_layout == 2
+        # looking does not leave the point ring
+        S = np.stack([h.to_host() for h in opt.delta_point_history]); Y = np.stack([h.to_host() for h in opt.delta_gradient_history])
+        x = opt.current_point.to_host()
+        opt.step()
+        assert opt.ring_layout == 2
+        S = np.stack([h.to_host() for h in opt.delta_point_history]); Y = np.stack([h.to_host() for h in opt.delta_gradient_history])
+        rho, its = opt.rho_history.copy(), opt.iteration_count
+        # the host moves the point (and keeps f, g consistent with it, as a restart from a perturbed point would)
+        x = opt.current_point.to_host()
+        x_new = (x + dtype(1e-3) * np.cos(np.arange(n))).astype(dtype)
+        g_new, f_new = pr.grad(x_new), pr.eval(x_new)
+        xd.upload(x_new)                                  # through the caller's own handle of the aliased array
+        opt.current_gradient.upload(g_new)
+        opt.set_objective_value(f_new)
+        ref = orc.LBFGS(pr, x0.copy(), 1.0, m)
+        ref.install_state(x_new, g_new, f_new, S, Y, rho, its)
+        opt.step(); ref.step()
+        assert opt.ring_layout == 1                       # continued on the pair ring
+        assert opt.last_trials == ref.last_trials and opt.iteration_count == ref.iteration_count
+        tol_d = TOL_DIRECTION if dtype == np.float64 else 2e-4
+        assert rel(opt.step_direction.to_host().astype(np.float64), ref.step_direction.astype(np.float64)) <= tol_d
+        assert rel(opt.current_point.to_host().astype(np.float64), ref.current_point.astype(np.float64)) <= (1e-12 if dtype == np.float64 else 1e-6)
+        for i in range(1, opt.history_count):             # the stored pairs were not changed by the write
+            assert np.array_equal(opt.delta_point_history[i].to_host(), S[i - 1]) and np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i - 1])
+        assert np.array_equal(xd.to_host(), opt.current_point.to_host())   # still aliased
+    finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)

@@ -1,0 +1,181 @@
+"""The headline kernel at the sizes where it runs its real loop.
+
+lbfgs_point_pass_kernel launches at most CUs x 4 wave-rows of 62 16-byte vectors: a wave takes a second row only
+beyond n ~ 1.3e5 (fp64), fills its 16-row LDS staging burst beyond n ~ 2e6, and swaps its two register sets every
+row.  The parity tests of tests/test_gpu_lbfgs.py stop at n = 100 004, i.e. before any of that; these cases compare
+the point path with the oracle (src/DZOptimization.jl:430-451 two-loop, :454-509 step!, :107-154 backtracking) at
+n = 2.5e5 ... 1.2e7, for every instantiation K in {8, 12, 16, 20} x {fp32, fp64}, both arrangements of the tiles
+(tile-major, stream-major) and above the 32-bit-offset switch (n = 1.2e7, m = 20: tile-major fallback).
+
+How: installing pairs would turn the point ring into a pair ring, so the GPU optimizer runs FREE and the oracle is
+given the GPU's complete state (public getters; they do not leave the point layout) right before each checked step;
+both then take the step and everything the step produces is compared: step_direction (the on-demand materialize
+pass) <= 1e-10 relative (fp32: 2e-4 against the wide-accumulator oracle), the new point, gradient, objective value,
+delta_point / delta_gradient (exact run_and_test! equalities), the number of trials.  Checked steps: the first two
+with a full history (k = m, ring wrapped) and the first step after them whose first trial is REJECTED (found by a
+scout run of the same deterministic trajectory), which exercises the retry pass at scale.  A second run with
+initial_step_length = 300 checks steps 0..2 (FIRST instantiation, several halvings on the pass, k = 0, 1, 2).
+"""
+import numpy as np
+import pytest
+
+from dzo_loader import dzo
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_DIRECTION = 1e-10      # north_star: per-step output within 1e-10 relative of the CPU reference
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _make(n, m, dtype, step0=1.0):
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), step0, m)
+    return x0, opt
+
+
+def _state(opt, n, dtype):
+    k = opt.history_count
+    S = np.empty((k, n), dtype); Y = np.empty((k, n), dtype)
+    hs, hy = opt.delta_point_history, opt.delta_gradient_history
+    for i in range(k):
+        S[i] = hs[i].to_host(); Y[i] = hy[i].to_host()
+    return (opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value, S, Y,
+            opt.rho_history[:k].copy(), opt.iteration_count)
+
+
+def _checked_step(opt, ref, n, dtype, where):
+    """One step of both from the GPU's state; returns the number of trials."""
+    x, g, f, S, Y, rho, its = _state(opt, n, dtype)
+    ref.install_state(x, g, f, S, Y, rho, its)
+    del S, Y
+    opt.step(); ref.step()
+    assert opt.ring_layout == 2, where
+    assert not opt.is_stuck and not ref.is_stuck, where
+    assert opt.iteration_count == ref.iteration_count and opt.last_trials == ref.last_trials, (where, opt.last_trials, ref.last_trials)
+    f64 = dtype == np.float64
+    e = rel(opt.step_direction.to_host(), ref.step_direction)
+    assert e <= (TOL_DIRECTION if f64 else 2e-4), (where, "step_direction", e)
+    x1, g1 = opt.current_point.to_host(), opt.current_gradient.to_host()
+    assert rel(x1, ref.current_point) <= (1e-12 if f64 else 1e-6), where
+    assert rel(g1, ref.current_gradient) <= (1e-9 if f64 else 1e-3), where
+    assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-12 if f64 else 1e-5), where
+    # run_and_test! (legacy/DZOptimization.jl:1035-1046), exact; and the new pair is what the ring hands out
+    assert np.array_equal(opt.delta_point.to_host(), x1 - x), where
+    assert np.array_equal(opt.delta_gradient.to_host(), g1 - g), where
+    assert np.array_equal(opt.delta_point_history[0].to_host(), x1 - x), where
+    return opt.last_trials
+
+
+CASES = [
+    # dtype, n, m, tile arrangement forced (None = the library's choice), scout window
+    (np.float64, 250_000, 8, None),            # K = 8, tile-major (m < 9), 2 rows per wave
+    (np.float64, 250_000, 8, 1),               # K = 8, stream-major forced
+    (np.float64, 250_000, 12, None),           # K = 12, stream-major
+    (np.float64, 250_000, 12, 0),              # K = 12, tile-major forced
+    (np.float64, 250_000, 16, None),           # K = 16
+    (np.float64, 250_000, 16, 0),
+    (np.float64, 2_500_000, 20, None),         # K = 20, 20 rows per wave: full staging bursts
+    (np.float64, 2_500_000, 20, 0),
+    (np.float64, 10_000_000, 20, None),        # config 3 itself
+    (np.float32, 500_000, 10, None),           # fp32, K = 12
+    (np.float32, 500_000, 7, None),            # fp32, K = 8, tile-major
+    (np.float32, 1_000_000, 14, 0),            # fp32, K = 16, tile-major forced
+    (np.float32, 5_000_000, 20, None),         # fp32, K = 20, 20 rows per wave
+    (np.float64, 12_000_000, 20, None),        # ring > 4 GiB: 32-bit stream offsets do not fit -> tile-major fallback
+]
+
+
+@pytest.mark.parametrize("dtype,n,m,arrangement", CASES,
+                         ids=[f"{np.dtype(d).name}-n{n}-m{m}-{'auto' if a is None else ('stream' if a else 'tile')}" for d, n, m, a in CASES])
+def test_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n, m, arrangement, monkeypatch):
+    if arrangement is not None:
+        monkeypatch.setenv("DZO_TUNE_STREAM_MAJOR", str(arrangement))
+    orc.set_threads(8)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)                    # the device sums in fp64
+    try:
+        # ---- scout: the same (deterministic) trajectory without looking, to find a step with a rejected first trial
+        window = m + 40
+        _, scout = _make(n, m, dtype)
+        want_layout = {None: None, 0: 1, 1: 2}[arrangement]
+        if want_layout is not None:
+            assert scout.tile_arrangement == want_layout
+        if n == 12_000_000:
+            assert scout.tile_arrangement == 1            # above the 32-bit-offset switch
+        assert scout.ring_layout == 2
+        trials = []
+        for _ in range(window):
+            scout.step()
+            assert not scout.is_stuck
+            trials.append(scout.last_trials)
+        f_scout = scout.current_objective_value
+        assert scout.single_pass_steps == window and scout.ring_layout == 2
+        scout.close()
+        rejected = next((i for i in range(m + 2, window) if trials[i] > 1), None)
+        checked = [m, m + 1] + ([rejected] if rejected is not None else [])
+        # ---- the checked run
+        x0, opt = _make(n, m, dtype)
+        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), 1.0, m)
+        it = 0
+        for target in checked:
+            while it < target:
+                opt.step(); it += 1
+                assert opt.last_trials == trials[it - 1], (it, "the trajectory is not reproducible")
+            t = _checked_step(opt, ref, n, dtype, (n, m, "step", target))
+            assert t == trials[target]
+            it += 1
+        if rejected is not None:
+            assert trials[rejected] >= 2 and opt.single_pass_retries >= 1
+        # looking at the state must not have changed the trajectory: finish the window and compare with the scout
+        if n <= 2_500_000:
+            while it < window:
+                opt.step(); it += 1
+            assert opt.current_objective_value == f_scout
+        opt.close(); ref.close()
+    finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+        orc.set_threads(1)
+
+
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 2_500_000, 20), (np.float32, 5_000_000, 20), (np.float64, 10_000_000, 20)],
+                         ids=["float64-n2500000", "float32-n5000000", "float64-n10000000"])
+def test_first_steps_with_deep_halvings_at_scale(dtype, n, m):
+    """A large initial_step_length (300 at n = 4100, scaled with sqrt(n) so that the first trial's per-element move stays the
+    same): the first step!() needs several halvings, all of them passes of the FIRST
+    instantiation (d read from the constructor's step_direction, :463); steps 1 and 2 run the K = 20 kernel with k = 1, 2
+    (the points beyond k alias point k)."""
+    orc.set_threads(8)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)
+    try:
+        step0 = float(np.float32(300.0 * np.sqrt(n / 4100.0)))
+        x0, opt = _make(n, m, dtype, step0=step0)
+        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0, m)
+        # :386-387 the constructor's direction
+        assert rel(opt.step_direction.to_host(), ref.step_direction) <= (1e-13 if dtype == np.float64 else 1e-6)
+        seen = []
+        for it in range(3):
+            x, g, f, S, Y, rho, its = _state(opt, n, dtype)
+            ref.install_state(x, g, f, S, Y, rho, its)
+            opt.step(); ref.step()
+            assert not opt.is_stuck and not ref.is_stuck
+            assert opt.last_trials == ref.last_trials, (it, opt.last_trials, ref.last_trials)
+            seen.append(opt.last_trials)
+            if it > 0:                                    # (step 0 walks along the constructor's direction: nothing is formed)
+                assert rel(opt.step_direction.to_host(), ref.step_direction) <= (TOL_DIRECTION if dtype == np.float64 else 2e-4), it
+            x1 = opt.current_point.to_host()
+            assert rel(x1, ref.current_point) <= (1e-12 if dtype == np.float64 else 1e-6), it
+            assert np.array_equal(opt.delta_point.to_host(), x1 - x), it
+            assert np.array_equal(opt.current_gradient.to_host() - g, opt.delta_gradient.to_host()), it
+            assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-12 if dtype == np.float64 else 1e-5)
+        assert seen[0] >= 3, seen                         # deep halvings happened, on passes
+        assert opt.ring_layout == 2 and opt.single_pass_steps == 3
+        opt.close(); ref.close()
+    finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+        orc.set_threads(1)
