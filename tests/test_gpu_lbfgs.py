@@ -648,6 +648,12 @@ def test_full_size_step_run_config3_invariants():
             finally:
                 orc.set_threads(1)
             assert np.array_equal(opt.delta_point_history[0].to_host(), x - x_old)
+            # step_direction (formed on demand by one more pass over the ring) is the direction the step really walked
+            # along: x = fma(t, d, x_old) with t = 2^-(trials - 1) (:124; t d is exact, so numpy rounds once as the fma does);
+            # its values against the oracle at this size: tests/test_gpu_lbfgs_scale.py
+            d = opt.step_direction.to_host()
+            assert np.array_equal(x, x_old + 0.5 ** (opt.last_trials - 1) * d)
+            assert float(d @ g_old) < 0.0                                        # a descent direction
     assert opt.iteration_count == 120 and opt.history_count == m
     assert trials <= 2 * 120
 
@@ -1015,46 +1021,67 @@ def test_point_ring_turns_into_the_pair_ring_without_changing_a_bit(monkeypatch)
 
 # ------------------------------------------------------------------------------ stuck state of the passes
 @pytest.mark.parametrize("layout", ["points", "pairs", "two_pass"])
-@pytest.mark.parametrize("n,m", [(16, 3), (372, 5)])
+@pytest.mark.parametrize("n,m", [(16, 3), (372, 5), (250_000, 8)])
 def test_lbfgs_stuck_step_leaves_the_reference_deltas(n, m, layout, monkeypatch):
     """take_backtracking_step! that ends stuck (src/DZOptimization.jl:128-131: the trial point equals the old point
     everywhere) leaves delta_point = x_old (:118 copy!(delta_point, current_point)) and does not touch delta_gradient,
     which still holds the previous step's value; x, g, f, the history and iteration_count are those of the last
-    accepted step.  Run to convergence on all three L-BFGS step implementations (point ring, pair ring, two-pass
-    kernels), the oracle following the GPU, and compare the fields of the stuck optimizer with the oracle's."""
+    accepted step.  Run until stuck on all three L-BFGS step implementations (point ring, pair ring, two-pass
+    kernels), the oracle following the GPU, and compare the fields of the stuck optimizer with the state the step
+    started from and with the oracle's.  (n = 250 000, m = 8 with the standard start is a run whose 14th step finds
+    no decrease in 60 halvings: a stuck step with a full history and several rows per wave.)"""
     if layout == "pairs":
         monkeypatch.setenv("DZO_TUNE_POINT_RING", "0")
     if layout == "two_pass":
         monkeypatch.setenv("DZO_TUNE_SINGLE_PASS", "0")
-    x0 = orc.rosenbrock_chain_x0(n)
-    ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1.0, m)
-    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
-    assert opt.ring_layout == {"points": 2, "pairs": 1, "two_pass": 0}[layout]
-    for it in range(5000):
-        k = opt.history_count
-        S = np.stack([h.to_host() for h in opt.delta_point_history]) if k else np.zeros((0, n))
-        Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n))
-        x, g, f = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value
-        dg_before = opt.delta_gradient.to_host()
-        ref.install_state(x, g, f, S, Y, opt.rho_history[:k], opt.iteration_count)
-        opt.step(); ref.step()
-        if opt.is_stuck or ref.is_stuck:
-            break
-    assert opt.is_stuck and ref.is_stuck, (it, opt.is_stuck, ref.is_stuck, opt.last_trials, ref.last_trials)
-    assert it > m + 2                                      # a steady-state step, history full
-    assert opt.iteration_count == ref.iteration_count == it
-    assert np.array_equal(opt.current_point.to_host(), x) and np.array_equal(opt.current_gradient.to_host(), g)   # :151 restored
-    assert opt.current_objective_value == f
-    assert np.array_equal(opt.delta_point.to_host(), x)                    # :118
-    assert np.array_equal(ref.delta_point, x)
-    assert np.array_equal(opt.delta_gradient.to_host(), dg_before)         # untouched
-    assert np.array_equal(opt.delta_gradient.to_host(), S.shape[0] and Y[0])
-    assert opt.history_count == k
-    for i in range(k):                                     # the history is the one the step started from
-        assert np.array_equal(opt.delta_point_history[i].to_host(), S[i]) and np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i])
-    assert rel(opt.step_direction.to_host(), ref.step_direction) <= 1e-9   # the direction the stuck search walked along
-    opt.step()                                             # :456-458: a stuck optimizer does nothing
-    assert opt.iteration_count == it and np.array_equal(opt.delta_point.to_host(), x)
+    orc.set_threads(8)
+    try:
+        x0 = orc.rosenbrock_chain_x0(n)
+        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1.0, m)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        assert opt.ring_layout == {"points": 2, "pairs": 1, "two_pass": 0}[layout]
+        for it in range(5000):
+            k = opt.history_count
+            S = np.stack([h.to_host() for h in opt.delta_point_history]) if k else np.zeros((0, n))
+            Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n))
+            x, g, f = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value
+            dg_before = opt.delta_gradient.to_host()
+            ref.install_state(x, g, f, S, Y, opt.rho_history[:k], opt.iteration_count)
+            ref.delta_gradient[:] = dg_before                  # (a field the step may or may not touch: installed as well)
+            opt.step(); ref.step()
+            if opt.is_stuck:
+                break
+            # (after dozens of halvings f_new - f is at rounding level: the oracle may call stuck what the device's
+            # summation order still accepts; the run goes on from the device's state)
+            assert not ref.is_stuck or ref.last_trials > 30, (it, ref.last_trials)
+        assert opt.is_stuck, it
+        assert it > m + 2                                      # a steady-state step, history full
+        assert opt.iteration_count == it
+        # ---- the device's fields against the state the stuck step started from
+        assert np.array_equal(opt.current_point.to_host(), x) and np.array_equal(opt.current_gradient.to_host(), g)   # :151 restored
+        assert opt.current_objective_value == f
+        assert np.array_equal(opt.delta_point.to_host(), x)                    # :118
+        assert np.array_equal(opt.delta_gradient.to_host(), dg_before)         # untouched ...
+        assert np.array_equal(dg_before, Y[0])                                 # ... i.e. still the last accepted step's
+        assert opt.history_count == k
+        for i in range(k):                                     # the history is the one the step started from
+            assert np.array_equal(opt.delta_point_history[i].to_host(), S[i]) and np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i])
+        # ---- and that this IS what the reference's loop leaves (the oracle, stuck on the same step unless the decision
+        # was at rounding level: then it is stepped on until it is)
+        for _ in range(4):
+            if ref.is_stuck:
+                break
+            ref.step()
+        assert ref.is_stuck
+        assert np.array_equal(ref.delta_point, ref.current_point)              # :118, :128-131
+        if ref.iteration_count == it:                          # same step: same fields
+            assert np.array_equal(ref.current_point, x) and np.array_equal(ref.delta_point, x)
+            assert np.array_equal(ref.delta_gradient, Y[0])
+            assert rel(opt.step_direction.to_host(), ref.step_direction) <= 1e-9   # the direction the stuck search walked along
+        opt.step()                                             # :456-458: a stuck optimizer does nothing
+        assert opt.iteration_count == it and np.array_equal(opt.delta_point.to_host(), x)
+    finally:
+        orc.set_threads(1)
 
 
 # ------------------------------------------------------------------------------ backend asserts (a8)

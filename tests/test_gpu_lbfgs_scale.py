@@ -13,7 +13,8 @@ both then take the step and everything the step produces is compared: step_direc
 pass) <= 1e-10 relative (fp32: 2e-4 against the wide-accumulator oracle), the new point, gradient, objective value,
 delta_point / delta_gradient (exact run_and_test! equalities), the number of trials.  Checked steps: the first two
 with a full history (k = m, ring wrapped) and the first step after them whose first trial is REJECTED (found by a
-scout run of the same deterministic trajectory), which exercises the retry pass at scale.  A second run with
+scout run of the same deterministic trajectory), which exercises the retry pass at scale; fp32 runs that end before
+the history is full (fp32 cannot resolve the decrease of f ~ 1e8 for long) are checked on their last safe steps.  A second run with
 initial_step_length = 300 checks steps 0..2 (FIRST instantiation, several halvings on the pass, k = 0, 1, 2).
 """
 import numpy as np
@@ -72,22 +73,54 @@ def _checked_step(opt, ref, n, dtype, where):
 
 
 CASES = [
-    # dtype, n, m, tile arrangement forced (None = the library's choice), scout window
-    (np.float64, 250_000, 8, None),            # K = 8, tile-major (m < 9), 2 rows per wave
-    (np.float64, 250_000, 8, 1),               # K = 8, stream-major forced
-    (np.float64, 250_000, 12, None),           # K = 12, stream-major
-    (np.float64, 250_000, 12, 0),              # K = 12, tile-major forced
-    (np.float64, 250_000, 16, None),           # K = 16
-    (np.float64, 250_000, 16, 0),
+    # dtype, n, m, tile arrangement forced (None = the library's choice)
+    (np.float64, 400_000, 8, None),            # K = 8, tile-major (m < 9), 3 rows per wave
+    (np.float64, 400_000, 8, 1),               # K = 8, stream-major forced
+    (np.float64, 400_000, 12, None),           # K = 12, stream-major
+    (np.float64, 400_000, 12, 0),              # K = 12, tile-major forced
+    (np.float64, 400_000, 16, None),           # K = 16
+    (np.float64, 400_000, 16, 0),
     (np.float64, 2_500_000, 20, None),         # K = 20, 20 rows per wave: full staging bursts
     (np.float64, 2_500_000, 20, 0),
     (np.float64, 10_000_000, 20, None),        # config 3 itself
-    (np.float32, 500_000, 10, None),           # fp32, K = 12
     (np.float32, 500_000, 7, None),            # fp32, K = 8, tile-major
+    (np.float32, 500_000, 10, None),           # fp32, K = 12
     (np.float32, 1_000_000, 14, 0),            # fp32, K = 16, tile-major forced
+    (np.float32, 1_000_000, 14, None),         # fp32, K = 16, stream-major
     (np.float32, 5_000_000, 20, None),         # fp32, K = 20, 20 rows per wave
     (np.float64, 12_000_000, 20, None),        # ring > 4 GiB: 32-bit stream offsets do not fit -> tile-major fallback
 ]
+
+
+def _scout(n, m, dtype, arrangement):
+    """The longest free run among a few initial step lengths (the first that survives the window): returns
+    (step0, trials per step, f at the end, steps taken).  The reference's backtracking search has no curvature condition
+    and fp32 cannot resolve the decrease of an objective of size 1e8 for long, so runs may end stuck after 10-20 steps
+    (e.g. n = 250 000 fp64 at step 13 on every implementation here and on the oracle; fp32 at n = 5e6 at step 11)."""
+    window = m + 30
+    best = None
+    for step0 in (1.0, 0.5, 4.0, 0.25):
+        _, scout = _make(n, m, dtype, step0=step0)
+        want_layout = {None: None, 0: 1, 1: 2}[arrangement]
+        if want_layout is not None:
+            assert scout.tile_arrangement == want_layout
+        if n == 12_000_000:
+            assert scout.tile_arrangement == 1            # above the 32-bit-offset switch
+        assert scout.ring_layout == 2
+        trials = []
+        for _ in range(window):
+            scout.step()
+            if scout.is_stuck:
+                break
+            trials.append(scout.last_trials)
+        f_end = scout.current_objective_value
+        assert scout.ring_layout == 2
+        scout.close()
+        if best is None or len(trials) > len(best[1]):
+            best = (step0, trials, f_end)
+        if len(trials) == window:
+            break
+    return best
 
 
 @pytest.mark.parametrize("dtype,n,m,arrangement", CASES,
@@ -99,28 +132,21 @@ def test_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n, m, arrang
     if dtype == np.float32:
         orc.set_dot_mode(orc.DOT_WIDE)                    # the device sums in fp64
     try:
-        # ---- scout: the same (deterministic) trajectory without looking, to find a step with a rejected first trial
-        window = m + 40
-        _, scout = _make(n, m, dtype)
-        want_layout = {None: None, 0: 1, 1: 2}[arrangement]
-        if want_layout is not None:
-            assert scout.tile_arrangement == want_layout
-        if n == 12_000_000:
-            assert scout.tile_arrangement == 1            # above the 32-bit-offset switch
-        assert scout.ring_layout == 2
-        trials = []
-        for _ in range(window):
-            scout.step()
-            assert not scout.is_stuck
-            trials.append(scout.last_trials)
-        f_scout = scout.current_objective_value
-        assert scout.single_pass_steps == window and scout.ring_layout == 2
-        scout.close()
-        rejected = next((i for i in range(m + 2, window) if trials[i] > 1), None)
-        checked = [m, m + 1] + ([rejected] if rejected is not None else [])
+        # ---- scout: the same (deterministic) trajectory without looking
+        step0, trials, f_scout = _scout(n, m, dtype, arrangement)
+        L = len(trials)
+        if L >= m + 3:                                    # full history: the first two steps with k = m, then a rejected first trial
+            rejected = next((i for i in range(m + 2, L - 2) if 1 < trials[i] <= 20), None)
+            checked = [m, m + 1] + ([rejected] if rejected is not None else [])
+        else:                                             # the run ends early: the last steps that are safely before its end
+            assert L >= 9, (L, "run too short to check anything")
+            rejected = None
+            checked = [L - 6, L - 5, L - 4]
+        if dtype == np.float64:
+            assert L >= m + 3                             # every fp64 case reaches its steady state
         # ---- the checked run
-        x0, opt = _make(n, m, dtype)
-        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), 1.0, m)
+        x0, opt = _make(n, m, dtype, step0=step0)
+        ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0, m)
         it = 0
         for target in checked:
             while it < target:
@@ -131,9 +157,9 @@ def test_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n, m, arrang
             it += 1
         if rejected is not None:
             assert trials[rejected] >= 2 and opt.single_pass_retries >= 1
-        # looking at the state must not have changed the trajectory: finish the window and compare with the scout
+        # looking at the state must not have changed the trajectory: finish the run and compare with the scout
         if n <= 2_500_000:
-            while it < window:
+            while it < L:
                 opt.step(); it += 1
             assert opt.current_objective_value == f_scout
         opt.close(); ref.close()
