@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
             xn[j] = dfma(t, go[j], xo[j]);                                   // :124
             diff |= owner && !is_equal(xn[j], xo[j]);                      // :128
         }
-        const T xprev = __shfl_up(xn[N - 1], 1, 64);
-        const T xnext = __shfl_down(xn[0], 1, 64);
+        const T xprev = lane_prev<T>(xn[N - 1]);
+        const T xnext = lane_next<T>(xn[0]);
         T gn[N], sn[N], yn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {

@@ -249,6 +249,21 @@ __device__ __forceinline__ double sum_xor32(double v) {
     return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
 }
 
+// Neighbour lanes without LDS: the value of lane - 1 (lane 0 keeps its own) / lane + 1 (lane 63 keeps its own) -- what
+// __shfl_up(v, 1) / __shfl_down(v, 1) return, but as one DPP move per dword (wave_shr:1 / wave_shl:1, whole-wave shifts
+// of the gfx9 family) instead of ds_bpermute's LDS round trip.  The stencil kernels run one wave per SIMD and cannot hide
+// that latency (three exchanges per wave-row in the point pass).
+template <typename T> __device__ __forceinline__ T lane_prev(T v);
+template <typename T> __device__ __forceinline__ T lane_next(T v);
+template <> __device__ __forceinline__ double lane_prev<double>(double v) { return dpp_f64<0x138, 0xF>(v, v); }   // wave_shr:1
+template <> __device__ __forceinline__ double lane_next<double>(double v) { return dpp_f64<0x130, 0xF>(v, v); }   // wave_shl:1
+template <> __device__ __forceinline__ float lane_prev<float>(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+template <> __device__ __forceinline__ float lane_next<float>(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
 // wave64 sum in every lane without touching LDS (DPP + permlane swaps; fixed order)
 __device__ __forceinline__ double wave_sum_all_dpp(double v) {
     v += lane_xor1(v);
@@ -258,6 +273,93 @@ __device__ __forceinline__ double wave_sum_all_dpp(double v) {
     v = sum_xor16(v);
     return sum_xor32(v);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming transposed reduction: wave-wide sums of MANY values (the 5 (K + 1) dot-product partials of a wave-row of
+// the point pass) at ~5 instructions per value instead of a 9-exchange butterfly + 10 v_readlane + 5 masked adds
+// per five of them.
+//
+// combine<L>(a, b) takes two per-lane values and returns ONE register in which the lanes with bit (5 - L) clear hold
+// a[l] + a[l ^ bit] and the lanes with that bit set hold b[l] + b[l ^ bit]: one level of a reduction tree for two
+// values at the price of one.  Levels 0 and 1 are the gfx950 v_permlane32/16_swap (which exchange half-waves / odd
+// and even rows BETWEEN two registers: no select needed), levels 2 and 3 bank-masked DPP row shifts by 8 and 4 (the
+// `old` operand supplies the lanes that keep their own value: no select either), levels 4 and 5 quad_perm exchanges
+// behind a select.  Pushing values through a binary counter of pending subtrees (push<v>) sends 64 values through
+// 32 + 16 + 8 + 4 + 2 + 1 combines; afterwards lane l holds the complete wave-wide sum of value bitrev6(l).
+// No LDS, fixed association order -> deterministic.
+template <int L> __device__ __forceinline__ double tree_combine(double a, double b, int lane) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    if constexpr (L == 0 || L == 1) {
+        const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+        const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+        u2 rl, rh;
+        if constexpr (L == 0) { rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false); rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false); }
+        else { rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false); rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false); }
+        // .x = [a.low half | b.low half], .y = [a.high half | b.high half]  (halves of the wave / of each row pair)
+        return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
+    } else if constexpr (L == 2) {
+        const double r1 = dpp_f64<0x108, 0x3>(b, a);     // row_shl:8 into banks 0, 1: a[l + 8]; the other lanes keep b[l]
+        const double r2 = dpp_f64<0x118, 0xC>(a, b);     // row_shr:8 into banks 2, 3: b[l - 8]; the other lanes keep a[l]
+        return r1 + r2;
+    } else if constexpr (L == 3) {
+        const double r1 = dpp_f64<0x104, 0x5>(b, a);     // row_shl:4 into banks 0, 2
+        const double r2 = dpp_f64<0x114, 0xA>(a, b);     // row_shr:4 into banks 1, 3
+        return r1 + r2;
+    } else if constexpr (L == 4) {
+        const bool hi = (lane & 2) != 0;
+        return (hi ? b : a) + lane_xor2(hi ? a : b);
+    } else {
+        const bool hi = (lane & 1) != 0;
+        return (hi ? b : a) + lane_xor1(hi ? a : b);
+    }
+}
+
+template <int NVALUES> struct TreeSum {
+    static constexpr int kGroups = (NVALUES + 63) / 64;
+    double lv[6];
+    double acc[kGroups];           // per lane: the running total (over the wave-rows) of value 64 g + bitrev6(lane)
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) acc[g] = 0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) lv[b] = 0;
+    }
+    template <int B> __device__ __forceinline__ double level(double a, double b, int lane) { return tree_combine<B>(a, b, lane); }
+    // value number V of the current wave-row (call with V = 0, 1, ..., NVALUES - 1 in this order, then finish_row)
+    template <int V> __device__ __forceinline__ void push(double x, int lane) {
+        constexpr int w = V & 63;
+        if constexpr ((w & 1) == 0) { lv[0] = x; return; }
+        x = tree_combine<0>(lv[0], x, lane);
+        if constexpr ((w & 2) == 0) { lv[1] = x; return; }
+        x = tree_combine<1>(lv[1], x, lane);
+        if constexpr ((w & 4) == 0) { lv[2] = x; return; }
+        x = tree_combine<2>(lv[2], x, lane);
+        if constexpr ((w & 8) == 0) { lv[3] = x; return; }
+        x = tree_combine<3>(lv[3], x, lane);
+        if constexpr ((w & 16) == 0) { lv[4] = x; return; }
+        x = tree_combine<4>(lv[4], x, lane);
+        if constexpr ((w & 32) == 0) { lv[5] = x; return; }
+        x = tree_combine<5>(lv[5], x, lane);
+        acc[V >> 6] += x;
+    }
+    // the last group of a row is incomplete when NVALUES is not a multiple of 64: its pending subtrees go up the
+    // remaining levels against zeros (a value keeps the lane its number says)
+    __device__ __forceinline__ void finish_row(int lane) {
+        constexpr int rem = NVALUES & 63;
+        if constexpr (rem != 0) {
+            double x = 0;
+            bool have = false;
+#define DZO_TS_LEVEL(B)                                                                        \
+            if constexpr ((rem >> B) & 1) { x = tree_combine<B>(lv[B], have ? x : 0.0, lane); have = true; } \
+            else if (have) { x = tree_combine<B>(x, 0.0, lane); }
+            DZO_TS_LEVEL(0) DZO_TS_LEVEL(1) DZO_TS_LEVEL(2) DZO_TS_LEVEL(3) DZO_TS_LEVEL(4) DZO_TS_LEVEL(5)
+#undef DZO_TS_LEVEL
+            acc[kGroups - 1] += x;
+        }
+    }
+    // the value whose total this lane holds in acc[g]
+    static __device__ __forceinline__ int value_of(int g, int lane) { return 64 * g + (int)(__builtin_bitreverse32((unsigned)lane) >> 26); }
+};
 
 // Wave-wide sums of EIGHT values with 10 cross-lane exchanges instead of 8 x 6 (transposed butterfly,
 // like wave_sum5 in dzo_lbfgs.hip): three halving steps leave ONE value per lane, three plain steps

@@ -149,6 +149,7 @@ struct dzo_lbfgs_s {
     // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
     const void *stage_kern = nullptr; size_t stage_bytes = 0; bool stage_small = false;   // dynamic-LDS attribute of the point pass
     bool lazy_d = true;             // DZO_TUNE_LAZY_D
+    int point_sets = 2;             // DZO_TUNE_POINT_SETS: register sets per wave of the point pass (1: two waves per SIMD)
     bool d_stale = false;
     int dview_k = 0, dview_newest = 0;
     template <typename T> T *s_slot(int slot) const {
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             T xh[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) xh[j] = dfma(p.t_half, q[j], xo[j]);
-            const T xhnext = __shfl_down(xh[0], 1, 64);
+            const T xhnext = lane_next<T>(xh[0]);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
@@ -964,8 +965,8 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
             }
         }
         // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
-        const T xprev = __shfl_up(xn[N - 1], 1, 64);
-        const T xnext = __shfl_down(xn[0], 1, 64);
+        const T xprev = lane_prev<T>(xn[N - 1]);
+        const T xnext = lane_next<T>(xn[0]);
         T gn[N], sn[N], yn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -1106,8 +1107,23 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
 // (the spare slot takes the trial), so a rejected trial just runs the pass again with a smaller t.
 // FIRST: the first step! walks along the step_direction the constructor left (d0 = -(step / |g|) g, :386-387 -- a
 // public field the caller may have changed): d is read instead of formed and not written back.
-template <typename T, int K, bool FIRST = false>
-__global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams<T> p) {
+#ifndef DZO_PP_REFILL
+#define DZO_PP_REFILL 1      // point pass: 1 = a register set is refilled tile by tile inside the dot-product loop; 0 = whole-set requests
+#endif
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>());
+    }
+}
+
+// SETS: 2 = two register sets of K + 1 points and gradients per wave (one wave per SIMD: 2 x 42 x 4 registers at K = 20);
+// 1 = ONE set and two waves per SIMD (256 registers per wave): a wave's instruction stream is in order, so whenever one
+// of its loads cannot issue (the memory pipeline is backed up -- the steady state of a bandwidth-bound sweep) or an
+// instruction waits for a result, the SIMD idles unless a second wave is there to take the slot.
+template <typename T, int K, bool FIRST = false, int SETS = 2>
+__global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_kernel(FusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
     constexpr int kOwn = kRowOwn, kLead = kRowLead;
     __shared__ T a_s[kFusedMaxK], c_s[kFusedMaxK];
@@ -1138,9 +1154,11 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
     const int64_t nvec = p.n / N;
     const int64_t rows = (nvec + kOwn - 1) / kOwn;
     const int64_t stride = (int64_t)gridDim.x * kWaves;
-    double acc[kGramValues];
-#pragma unroll
-    for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
+    // the 5 (K + 1) dot-product partials of a wave-row go through a streaming transposed reduction (TreeSum,
+    // dzo_common.h): ~5 VALU instructions per value, and the wave-wide total of value v accumulates in ONE lane
+    // (a 9-exchange butterfly + 10 v_readlane + 5 masked adds per pair was half of this kernel's VALU work)
+    TreeSum<kGramValues * (K + 1)> dots;
+    dots.init();
     double fobj = 0, fobj_h = 0;
     bool diff = false;
     auto byte_offset = [&](int64_t row) -> uint32_t {           // of the lane's vector in the contiguous d
@@ -1197,13 +1215,22 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
     };
     // K + 1 points and K + 1 gradients of a row; two register sets (as lbfgs_single_pass_kernel)
     auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N]) {
+        // (the order compute() refills a set in: the waits the compiler derives for the loop are then the same on
+        // the first trip as on every other)
         char *rb = rowbase(row);
 #pragma unroll
-        for (int j = 0; j <= K; ++j) load16_nt(tl(rb, p.soff[j] + p.ystride), gv[j]);
-#pragma unroll
-        for (int j = K; j >= 0; --j) load16_nt(tl(rb, p.soff[j]), xv[j]);
+        for (int j = 0; j <= K; ++j) {
+            load16_nt(tl(rb, p.soff[j] + p.ystride), gv[j]);
+            load16_nt(tl(rb, p.soff[j]), xv[j]);
+        }
+        if constexpr (DZO_PP_REFILL != 0) __builtin_amdgcn_sched_barrier(0);   // set by set: nothing of the next set moves up into this one
     };
-    auto compute = [&](int64_t row, uint32_t boff, const T (&xv)[K + 1][N], const T (&gv)[K + 1][N]) {
+    // refill: the row this register set serves next (two rows ahead).  Its tiles are requested from inside the
+    // dot-product loop, point i once pair i -- the last reader of that point's registers -- is done, instead of
+    // whole-set requests in front of the other set's compute (issue(next); compute(cur)): -10 us at config 3.
+    auto compute = [&](int64_t row, uint32_t boff, T (&xv)[K + 1][N], T (&gv)[K + 1][N], int64_t refill_row) {
+        char *nrb = rowbase(refill_row);
+        constexpr bool kRefill = DZO_PP_REFILL != 0;
         const int64_t v = row * kOwn - kLead + lane;
         const bool valid = v >= 0 && v < nvec;
         const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
@@ -1244,7 +1271,7 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
             T xh[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) xh[j] = dfma(p.t_half, q[j], xv[0][j]);
-            const T xhnext = __shfl_down(xh[0], 1, 64);
+            const T xhnext = lane_next<T>(xh[0]);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
@@ -1252,8 +1279,8 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
             }
         }
         // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
-        const T xprev = __shfl_up(xn[N - 1], 1, 64);
-        const T xnext = __shfl_down(xn[0], 1, 64);
+        const T xprev = lane_prev<T>(xn[N - 1]);
+        const T xnext = lane_next<T>(xn[0]);
         T gn[N], sn[N], yn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -1280,8 +1307,9 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
 #pragma unroll
             for (int j = 0; j < N; ++j) { gn[j] = (T)0; sn[j] = (T)0; yn[j] = (T)0; }   // halos add nothing to the dots
         }
-        // ---- dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1)
-        {
+        // ---- dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1); value 5 j + c of the row
+        const bool want_dots = !(p.debug_skip & 1);
+        if (want_dots) {
             double t5[kGramValues] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -1292,16 +1320,12 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
                 t5[3] = __builtin_fma(yx, sx, t5[3]);
                 t5[4] = __builtin_fma(sx, yx, t5[4]);
             }
-            double tot[kGramValues];
-            wave_sum5(t5, lane, tot);
-            if (lane == 0) {
-#pragma unroll
-                for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
-            }
+            dots.template push<0>(t5[0], lane); dots.template push<1>(t5[1], lane); dots.template push<2>(t5[2], lane);
+            dots.template push<3>(t5[3], lane); dots.template push<4>(t5[4], lane);
         }
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            if (i + 1 < kn && !(p.debug_skip & 1)) {
+        auto pair_dots = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (want_dots) {
                 double t5[kGramValues] = {0, 0, 0, 0, 0};
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
@@ -1319,49 +1343,84 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_point_pass_kernel(FusedParams
                     t5[3] = __builtin_fma(yx, (double)sq, t5[3]);
                     t5[4] = __builtin_fma(sx, (double)yq, t5[4]);
                 }
-                double tot[kGramValues];
-                if (p.debug_skip & 8) { for (int c = 0; c < kGramValues; ++c) tot[c] = t5[c]; }   // (ablation: no butterfly)
-                else wave_sum5(t5, lane, tot);
-                if (lane == i + 1) {
-#pragma unroll
-                    for (int c = 0; c < kGramValues; ++c) acc[c] += tot[c];
-                }
+                constexpr int v0 = kGramValues * (i + 1);
+                dots.template push<v0 + 0>(t5[0], lane); dots.template push<v0 + 1>(t5[1], lane); dots.template push<v0 + 2>(t5[2], lane);
+                dots.template push<v0 + 3>(t5[3], lane); dots.template push<v0 + 4>(t5[4], lane);
             }
+            // point i is dead: its registers take the same tiles of the row two ahead
+            if constexpr (kRefill) {
+                load16_nt(tl(nrb, p.soff[i] + p.ystride), gv[i]);
+                load16_nt(tl(nrb, p.soff[i]), xv[i]);
+            }
+        };
+        static_for<K>(pair_dots);
+        if constexpr (kRefill) {
+            load16_nt(tl(nrb, p.soff[K] + p.ystride), gv[K]);
+            load16_nt(tl(nrb, p.soff[K]), xv[K]);
         }
+        if (want_dots) dots.finish_row(lane);
+        if constexpr (kRefill) __builtin_amdgcn_sched_barrier(0);   // (the other set's compute starts below this set's last request)
     };
     T xA[K + 1][N], gA[K + 1][N];
-    T xB[K + 1][N], gB[K + 1][N];
+    T xB[SETS == 2 ? K + 1 : 1][N], gB[SETS == 2 ? K + 1 : 1][N];
     int64_t row = (int64_t)blockIdx.x * kWaves + wave;
-    auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };
-    uint32_t boff = byte_offset(in_range(row));
-    issue(in_range(row), xA, gA);
-    while (row < rows) {
-        int64_t nrow = row + stride;
-        uint32_t nboff = byte_offset(in_range(nrow));
-        issue(in_range(nrow), xB, gB);
-        compute(row, boff, xA, gA);
-        if (staged >= stage_rows) flush_stage();
-        row = nrow; boff = nboff;
-        if (row >= rows) break;
-        nrow = row + stride;
-        nboff = byte_offset(in_range(nrow));
-        issue(in_range(nrow), xA, gA);
-        compute(row, boff, xB, gB);
-        if (staged >= stage_rows) flush_stage();
-        row = nrow; boff = nboff;
+    auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };   // (past the end: the last row again, unconditionally)
+    if constexpr (SETS == 1) {
+        issue(in_range(row), xA, gA);
+        while (row < rows) {
+            compute(row, byte_offset(row), xA, gA, in_range(row + stride));
+            if (staged >= stage_rows) flush_stage();
+            row += stride;
+        }
+    } else if constexpr (DZO_PP_REFILL != 0) {
+        // (Where the refill requests end up is the compiler's business: with the exit between the two halves it sinks
+        // the first half's refills below the second compute(), next to the other set's.  Forcing them to stay where
+        // they are written -- no exit in the middle, -mllvm -disable-machine-sink -- gave exact per-set waits and the
+        // same kernel time, 640-648 against 623-644 us over two boxes: the sweep is bound by its memory shape, not by
+        // the wave's waits.  SQ counters of that build: 44 % of the wave cycles issuing, 43 % issue stalls, 13 % in
+        // s_waitcnt; the round-2 kernel: 69 / 10 / 21 % with 1.85 x the vector instructions.)
+        issue(in_range(row), xA, gA);
+        issue(in_range(row + stride), xB, gB);
+        while (row < rows) {
+            compute(row, byte_offset(row), xA, gA, in_range(row + 2 * stride));
+            if (staged >= stage_rows) flush_stage();
+            row += stride;
+            if (row >= rows) break;
+            compute(row, byte_offset(row), xB, gB, in_range(row + 2 * stride));
+            if (staged >= stage_rows) flush_stage();
+            row += stride;
+        }
+    } else {                                                     // whole-set requests one row ahead (the round-2 loop)
+        issue(in_range(row), xA, gA);
+        while (row < rows) {
+            issue(in_range(row + stride), xB, gB);
+            compute(row, byte_offset(row), xA, gA, 0);
+            if (staged >= stage_rows) flush_stage();
+            row += stride;
+            if (row >= rows) break;
+            issue(in_range(row + stride), xA, gA);
+            compute(row, byte_offset(row), xB, gB, 0);
+            if (staged >= stage_rows) flush_stage();
+            row += stride;
+        }
     }
     flush_stage();
-    if (lane < kn) {
+    {
+        // lane l holds the totals of values 64 g + bitrev6(l); value 5 j + c = dot c of (post-push) pair j
+        double *wflat = &wacc[0][0][0];
+        constexpr int kValues = kGramValues * (K + 1);
 #pragma unroll
-        for (int c = 0; c < kGramValues; ++c) wacc[wave][lane][c] = acc[c];
+        for (int g = 0; g < TreeSum<kValues>::kGroups; ++g) {
+            const int v = TreeSum<kValues>::value_of(g, lane);
+            if (v < kValues) wflat[wave * (kGramValues * (kFusedMaxK + 1)) + v] = dots.acc[g];
+        }
     }
     __syncthreads();
-    if (wave == 0 && lane < kn) {
-#pragma unroll
-        for (int c = 0; c < kGramValues; ++c) {
-            const double r = (wacc[0][lane][c] + wacc[1][lane][c]) + (wacc[2][lane][c] + wacc[3][lane][c]);
-            p.gram_partials[(int64_t)(lane * kGramValues + c) * gridDim.x + blockIdx.x] = r;
-        }
+    for (int v = threadIdx.x; v < kGramValues * kn; v += kBlock) {
+        const double *wflat = &wacc[0][0][0];
+        constexpr int ws = kGramValues * (kFusedMaxK + 1);
+        const double r = (wflat[v] + wflat[ws + v]) + (wflat[2 * ws + v] + wflat[3 * ws + v]);
+        p.gram_partials[(int64_t)v * gridDim.x + blockIdx.x] = r;
     }
     block_raise_flag(diff, p.changed, &lds_flag);
     const double fo = block_sum(fobj, lds);
@@ -2389,6 +2448,20 @@ template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedP
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// the instantiation of the point pass for this optimizer: the smallest K that holds m pairs; one or two register sets
+// (DZO_TUNE_POINT_SETS; see the kernel)
+template <typename T> static void (*point_pass_kernel_for(dzo_lbfgs_s *o, bool first))(FusedParams<T>) {
+    if (first) return lbfgs_point_pass_kernel<T, 8, true>;
+    if (o->point_sets == 1 && o->m <= 16)                   // (K = 20: 168 registers of tiles + the arithmetic do not fit 256 -- it would spill)
+        return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
+               : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1>
+               : lbfgs_point_pass_kernel<T, 16, false, 1>;
+    return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
+           : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12>
+           : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
+           : lbfgs_point_pass_kernel<T, 20>;
+}
+
 // step_direction of the last step, on demand: the same pass once more over the view of the ring that step started
 // from (its points are all still there: the push only rotated the ring, and the slot the next pass will overwrite is
 // that view's oldest point), with the scalars that step used, writing d and nothing else.
@@ -2410,10 +2483,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.changed = c.flag();
     fp.debug_skip = 1 | 64;                               // no pair dots, no tile stores (and with them no halo copies)
     fp.stage_rows = 1;
-    void (*kern)(FusedParams<T>) = o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
-                                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12>
-                                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
-                                   : lbfgs_point_pass_kernel<T, 20>;
+    void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, false);
     const int grid = points_grid<T>(o, kern);
     {
         DZO_TIMED("lbfgs_direction_on_demand", s);
@@ -2456,11 +2526,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
     fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
-    void (*kern)(FusedParams<T>) = k == 0 ? lbfgs_point_pass_kernel<T, 8, true>
-                                   : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
-                                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12>
-                                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
-                                   : lbfgs_point_pass_kernel<T, 20>;
+    void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, k == 0);
     const int grid = points_grid<T>(o, kern);
     fp.store_d = o->lazy_d ? 0 : 1;
     {
@@ -2471,9 +2537,11 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     }
     // rows of new tiles a wave collects in LDS before it writes them (2 KiB per row and wave; the whole 160-KiB LDS
     // of a CU is this one block's)
-    fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", 16);
+    // (two blocks per CU with one register set per wave: half the LDS each)
+    const bool one_set = o->point_sets == 1 && o->m <= 16 && k > 0;
+    fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", one_set ? 8 : 16);
     if (fp.stage_rows < 1) fp.stage_rows = 1;
-    if (fp.stage_rows > 18) fp.stage_rows = 18;
+    if (fp.stage_rows > (one_set ? 9 : 18)) fp.stage_rows = one_set ? 9 : 18;
     size_t stage_bytes = (size_t)kWaves * fp.stage_rows * 2 * kTileBytes;
     if (o->stage_kern != (const void *)kern || o->stage_bytes != stage_bytes) {   // (once per kernel and size)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess) {
@@ -2787,6 +2855,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
             // point ring: the start point and its gradient are point 0
             o->points = true;
             o->lazy_d = tune("DZO_TUNE_LAZY_D", 1) != 0;
+            o->point_sets = tune("DZO_TUNE_POINT_SETS", 2) == 1 ? 1 : 2;
             o->xg_host_may_write = true;                      // (the caller owns x0 / g0 and may change them before the first step)
             DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
             DZO_HIP(hipGetLastError());

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(kBlock) void rosen_accept_grad_delta_kernel(int64_t
             const int64_t v = base + (int64_t)u * kBlock + threadIdx.x;
             const int64_t i = v * N;
             // neighbours: previous lane's last element, next lane's first element
-            T xprev = __shfl_up(xv[u][N - 1], 1, 64);
-            T xnext = __shfl_down(xv[u][0], 1, 64);
+            T xprev = lane_prev<T>(xv[u][N - 1]);
+            T xnext = lane_next<T>(xv[u][0]);
             if (ok[u]) {
                 if (lane == 0) xprev = i > 0 ? x[i - 1] : (T)0;
                 if (lane == 63 || v + 1 >= nvec) xnext = (i + N < n) ? x[i + N] : (T)0;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void rosen_trial_eval_kernel(int64_t n, T *
                 xn[j] = dfma(t, dv[u][j], xo[u][j]);                 // :124
                 diff |= ok[u] && !is_equal(xn[j], xo[u][j]);         // :128
             }
-            const T xnext = __shfl_down(xn[0], 1, 64);
+            const T xnext = lane_next<T>(xn[0]);
             // the row's last vector (lane 63, or the last vector of x) leaves its final term to the edge kernel
             const bool has_next = lane != 63 && v + 1 < nvec;
             if (ok[u]) {
