@@ -149,6 +149,8 @@ struct dzo_lbfgs_s {
     // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
     const void *stage_kern = nullptr; size_t stage_bytes = 0; bool stage_small = false;   // dynamic-LDS attribute of the point pass
     bool lazy_d = true;             // DZO_TUNE_LAZY_D
+    bool fused_finish = false;      // DZO_TUNE_FUSED_FINISH: reduce + finish of a Gram pass in one launch when the partials are few (measured slower)
+    int64_t fused_finish_max = 65536;   // DZO_TUNE_FUSED_FINISH_MAX: ... at most this many partial sums
     int point_sets = 2;             // DZO_TUNE_POINT_SETS: register sets per wave of the point pass (1: two waves per SIMD)
     bool d_stale = false;
     int dview_k = 0, dview_newest = 0;
@@ -451,7 +453,7 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     const int k = p.k, ld = k + 1;
     // logical k x k views of the caches (entries of non-pivot pairs were computed by the
     // passes in which THEY were the pivot)
-    for (int e = threadIdx.x; e < k * k; e += kBlock) {
+    for (int e = threadIdx.x; e < k * k; e += (int)blockDim.x) {
         const int i = e / k, j = e % k;
         yy[i * ld + j] = p.Gyy[p.map.slot[i] * p.m1 + p.map.slot[j]];
         sy[i * ld + j] = p.Gsy[p.map.slot[i] * p.m1 + p.map.slot[j]];
@@ -483,7 +485,7 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     double alpha_i = 0;
     for (int j = 0; j < k; ++j) {                                  // :439 newest -> oldest
         const double cand = acc / rho_i;                           // :440 (lane j's value counts)
-        const double aj = __shfl(cand, j, 64);
+        const double aj = readlane_f64(cand, j);                    // (uniform j: v_readlane, no LDS round trip)
         if (lane == j) alpha_i = cand;
         if (on && lane > j) acc = __builtin_fma(-aj, sy[lane * ld + j], acc);
     }
@@ -493,14 +495,14 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     // y_i.q_k with q_k = g - sum_j alpha_j y_j
     double base = on ? vals[lane * kGramValues + 1] : 0.0;         // y_i.g
     for (int j = 0; j < k; ++j) {
-        const double aj = __shfl(alpha_i, j, 64);
+        const double aj = readlane_f64(alpha_i, j);
         if (on) base = __builtin_fma(-aj, yy[lane * ld + j], base);
     }
     acc = scale * base;
     double c_i = 0;
     for (int l = k - 1; l >= 0; --l) {                             // :446 oldest -> newest
         const double cand = alpha_i + acc / rho_i;                 // :447-448
-        const double cl = __shfl(cand, l, 64);
+        const double cl = readlane_f64(cand, l);
         if (lane == l) c_i = cand;
         if (on && lane < l) acc = __builtin_fma(-cl, sy[l * ld + lane], acc);
     }
@@ -521,6 +523,79 @@ __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p)
     const int k = p.k;
     double *vals = fin_lds, *yy = vals + kGramValues * k, *sy = yy + k * (k + 1);
     for (int v = threadIdx.x; v < kGramValues * k; v += kBlock) vals[v] = p.partials[v];
+    __syncthreads();
+    gram_finish_body(p, vals, yy, sy);
+}
+
+// Reduce + finish in ONE launch of one 1024-thread block, for the sizes where the scalar stage's two launches cost
+// as much as a pass over the data (config 4: n = 1e6, k = 10: 6.7 + 8.4 us and a kernel boundary against two passes
+// of 15 us).  A WAVE sums a value's partials (16 values at a time), emulating gram_reduce_kernel's 256-thread block
+// bit for bit: lane l plays threads l, l + 64, l + 128, l + 192 (each with its four strided accumulators), the four
+// wave sums are taken in block_sum's order -- so an optimizer gets the same scalars whichever form runs.  (The
+// round-2 attempt let the finish block's 256 threads walk all 50 x 768 partials value by value: 25.5 us.)
+// MEASURED (round 3, config 4, rocprofv3): 22.0 us for this kernel against 6.4 + 8.3 us for the two launches, 51.6
+// against 38.8-39.9 us of wall per direction -- one CU pulls 307 KB of partials in twelve dependent rounds of loads.
+// Off by default (DZO_TUNE_FUSED_FINISH=1 selects it); the same trace shows 2.9 us of GPU-side gaps per direction, i.e.
+// the launches were never the cost: round 2's 70.8 us per direction were 8 HIP event records per direction in the timed
+// loop (the bench now times without events and takes the per-kernel numbers from a second, untimed stretch).
+constexpr int kFusedFinishThreads = 1024;
+__device__ __forceinline__ double wave_sum_down_dpp(double v) {   // lane 0: bit-identical to wave_sum() (same pairing, no LDS)
+    v = sum_xor32(v);
+    v = sum_xor16(v);
+    v += lane_xor8(v);
+    v += lane_xor4(v);
+    v += lane_xor2(v);
+    v += lane_xor1(v);
+    return v;
+}
+__global__ __launch_bounds__(kFusedFinishThreads) void gram_reduce_finish_kernel(GramFinishParams p, const double *__restrict__ partials, int grid,
+                                                                                 double *__restrict__ vals_out, int nvals,
+                                                                                 const double *__restrict__ rho_partials, int rho_count,
+                                                                                 double *__restrict__ rho_dst, int rho_to_f32) {
+    if (p.gate && *p.gate != 1) return;
+    extern __shared__ __attribute__((aligned(16))) double fin_lds[];
+    __shared__ double rlds[kWaves];
+    const int k = p.k;
+    double *vals = fin_lds, *yy = vals + kGramValues * k, *sy = yy + k * (k + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kW = kFusedFinishThreads / 64;
+    // pending rho of the pair the previous step pushed (gram_reduce_body's extra block; reduce_partials_all's order)
+    if (rho_count > 0) {
+        double v = 0;
+        if (threadIdx.x < kBlock) {
+            for (int i = threadIdx.x; i < rho_count; i += kBlock) v += rho_partials[i];
+            v = wave_sum_all(v);
+            if (lane == 0) rlds[wave] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double r = ((rlds[0] + rlds[1]) + rlds[2]) + rlds[3];
+            rho_dst[0] = rho_to_f32 ? (double)(float)r : r;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int v = wave; v < nvals; v += kW) {
+        const double *src = partials + (int64_t)v * grid;
+        double W[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = lane + 64 * q;                            // the thread of gram_reduce_body this lane plays
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int b = t; b < grid; b += 4 * kBlock) {
+                a0 += src[b];
+                if (b + kBlock < grid) a1 += src[b + kBlock];
+                if (b + 2 * kBlock < grid) a2 += src[b + 2 * kBlock];
+                if (b + 3 * kBlock < grid) a3 += src[b + 3 * kBlock];
+            }
+            W[q] = wave_sum_down_dpp((a0 + a1) + (a2 + a3));
+        }
+        if (lane == 0) {
+            const double r = ((W[0] + W[1]) + W[2]) + W[3];          // block_sum: r = 0; r += lds[w]
+            vals[v] = r;
+            vals_out[v] = r;
+        }
+    }
     __syncthreads();
     gram_finish_body(p, vals, yy, sy);
 }
@@ -1720,10 +1795,23 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         if (gu == 1) GL(1); else if (gu == 2) GL(2); else GL(4);      // (8 vectors per lane spills: not offered)
 #undef GL
         const int pcount = lgrid;
+        const int nvals = kGramValues * k;
+        const bool rho = o->rho_pending;
+        if (o->fused_finish && (int64_t)nvals * pcount <= o->fused_finish_max) {
+            // small problem: the scalar stage in one launch (see gram_reduce_finish_kernel)
+            const GramFinishParams fp = gram_finish_params(o, pivot, recurrence, vals, false, nullptr);
+            {
+                DZO_TIMED("lbfgs_gram_reduce_finish", s);
+                hipLaunchKernelGGL(gram_reduce_finish_kernel, dim3(1), dim3(kFusedFinishThreads), gram_finish_lds_bytes(k), s, fp,
+                                   (const double *)o->gram_partials, pcount, vals, nvals, (const double *)c.partials(),
+                                   rho ? o->rho_pending_count : 0, o->rho + o->rho_pending_slot, c.dtype == DZO_F32 ? 1 : 0);
+            }
+            o->rho_pending = false;
+            DZO_HIP(hipGetLastError());
+            return DZO_OK;
+        }
         {
             DZO_TIMED("lbfgs_gram_reduce", s);
-            const int nvals = kGramValues * k;
-            const bool rho = o->rho_pending;
             hipLaunchKernelGGL(gram_reduce_kernel, dim3(nvals + (rho ? 1 : 0)), dim3(kBlock), 0, s, o->gram_partials, pcount,
                                vals, nvals, (const double *)c.partials(), o->rho_pending_count, o->rho + o->rho_pending_slot,
                                c.dtype == DZO_F32 ? 1 : 0);
@@ -2795,6 +2883,8 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     ALLOC(o->d_alloc, (size_t)o->stride * es + 4096);
     o->d = (char *)o->d_alloc + 3 * 1024;             // off the allocator's alignment grid (see xbak / gbak)
     o->gram_u = tune("DZO_TUNE_GRAM_U", 4);
+    o->fused_finish = tune("DZO_TUNE_FUSED_FINISH", 0) != 0;
+    o->fused_finish_max = tune("DZO_TUNE_FUSED_FINISH_MAX", 65536);
     o->speculate = tune("DZO_TUNE_SPECULATE", 1) != 0;
     o->gram_variant = tune("DZO_TUNE_GRAM_VARIANT", 1);
     o->gram_peel = tune("DZO_TUNE_GRAM_PEEL", 1);

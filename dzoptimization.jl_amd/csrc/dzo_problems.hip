@@ -291,7 +291,15 @@ __global__ __launch_bounds__(kBlock) void finish_scaled_sum_kernel(const double 
                                                                    double scale, double *__restrict__ result) {
     __shared__ double lds[kWaves];
     double v = 0;
-    for (int64_t i = threadIdx.x; i < count; i += kBlock) v += partials[i];
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kBlock < count; i += 8 * kBlock) {           // (loads first, adds in the plain loop's order)
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = partials[i + (int64_t)u * kBlock];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; i < count; i += kBlock) v += partials[i];
     double r = block_sum(v, lds);
     if (threadIdx.x == 0) result[0] = scale * r;
 }
@@ -426,7 +434,22 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__res
                                                              double *__restrict__ out, int32_t *__restrict__ flags, double ticket) {
     __shared__ double lds[kWaves];
     double v[6] = {0, 0, 0, 0, 0, 0};
-    for (int64_t i = threadIdx.x; i < count; i += kBlock) {
+    // (one block pulling 6 x count values through one CU is bound by load latency: eight strided steps of loads are
+    // in flight before the first add; the adds keep the order of the plain loop, so every value is what
+    // finish_phi_kernel gives for the same partials -- 9.2 -> about 3 us at n = 4096)
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kBlock < count; i += 8 * kBlock) {
+        double t[8][6];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t[u][r] = partials[(int64_t)r * count + i + (int64_t)u * kBlock];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) v[r] += t[u][r];
+    }
+    for (; i < count; i += kBlock) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) v[r] += partials[(int64_t)r * count + i];
     }
@@ -450,7 +473,15 @@ __global__ __launch_bounds__(kBlock) void finish_phi_kernel(const double *__rest
                                                             double *__restrict__ out, int32_t *__restrict__ flags) {
     __shared__ double lds[kWaves];
     double v = 0;
-    for (int64_t i = threadIdx.x; i < count; i += kBlock) v += partials[i];
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kBlock < count; i += 8 * kBlock) {           // (loads first, adds in the plain loop's order: see finish_phi6_kernel)
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = partials[i + (int64_t)u * kBlock];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; i < count; i += kBlock) v += partials[i];
     const double r = block_sum(v, lds);
     if (threadIdx.x == 0) {
         out[0] = scale * r;
