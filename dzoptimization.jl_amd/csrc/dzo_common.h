@@ -190,19 +190,6 @@ template <typename T> __device__ __forceinline__ void store16_nt(T *p, const T (
     }
 }
 
-// wave64 sum, result valid in lane 0 (fixed order -> deterministic)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-// wave64 sum, result in every lane
-__device__ __forceinline__ double wave_sum_all(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, src_lane);
@@ -248,6 +235,21 @@ __device__ __forceinline__ double sum_xor32(double v) {
     const u2 rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double((int)rh.x, (int)rl.x) + __hiloint2double((int)rh.y, (int)rl.y);
 }
+
+// wave64 sums in the association order of the classic shuffle trees (offsets 32, 16, 8, 4, 2, 1), without LDS:
+// every step adds the SAME two operands the __shfl_down / __shfl_xor form adds (a + b == b + a bit for bit), so the
+// results are those of the shuffle forms -- which compile to ds_bpermute, six dependent LDS round trips per sum.
+// wave_sum: result valid in lane 0.  wave_sum_all: the same value in every lane.  All 64 lanes must be active.
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v = sum_xor32(v);
+    v = sum_xor16(v);
+    v += lane_xor8(v);
+    v += lane_xor4(v);
+    v += lane_xor2(v);
+    v += lane_xor1(v);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_all(v); }
 
 // Neighbour lanes without LDS: the value of lane - 1 (lane 0 keeps its own) / lane + 1 (lane 63 keeps its own) -- what
 // __shfl_up(v, 1) / __shfl_down(v, 1) return, but as one DPP move per dword (wave_shr:1 / wave_shl:1, whole-wave shifts
@@ -393,6 +395,28 @@ __device__ __forceinline__ double block_sum(double v, double *lds) {
     }
     __syncthreads();
     return r;
+}
+
+// R block sums behind ONE pair of barriers (block_sum called R times pays 2 R); `lds` holds R * kWaves doubles.  Every
+// sum is bit-identical to block_sum of the same value.  Results valid in thread 0.
+template <int R> __device__ __forceinline__ void block_sum_multi(const double (&v)[R], double *lds, double (&out)[R]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double w = wave_sum(v[r]);
+        if (lane == 0) lds[r * kWaves + wave] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double t = 0;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) t += lds[r * kWaves + w];
+        }
+        out[r] = t;
+    }
+    __syncthreads();
 }
 
 // Every thread of every block obtains the same sum of `count` per-block partials, read in

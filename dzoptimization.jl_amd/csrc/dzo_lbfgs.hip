@@ -539,15 +539,6 @@ __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p)
 // the launches were never the cost: round 2's 70.8 us per direction were 8 HIP event records per direction in the timed
 // loop (the bench now times without events and takes the per-kernel numbers from a second, untimed stretch).
 constexpr int kFusedFinishThreads = 1024;
-__device__ __forceinline__ double wave_sum_down_dpp(double v) {   // lane 0: bit-identical to wave_sum() (same pairing, no LDS)
-    v = sum_xor32(v);
-    v = sum_xor16(v);
-    v += lane_xor8(v);
-    v += lane_xor4(v);
-    v += lane_xor2(v);
-    v += lane_xor1(v);
-    return v;
-}
 __global__ __launch_bounds__(kFusedFinishThreads) void gram_reduce_finish_kernel(GramFinishParams p, const double *__restrict__ partials, int grid,
                                                                                  double *__restrict__ vals_out, int nvals,
                                                                                  const double *__restrict__ rho_partials, int rho_count,
@@ -588,7 +579,7 @@ __global__ __launch_bounds__(kFusedFinishThreads) void gram_reduce_finish_kernel
                 if (b + 2 * kBlock < grid) a2 += src[b + 2 * kBlock];
                 if (b + 3 * kBlock < grid) a3 += src[b + 3 * kBlock];
             }
-            W[q] = wave_sum_down_dpp((a0 + a1) + (a2 + a3));
+            W[q] = wave_sum((a0 + a1) + (a2 + a3));
         }
         if (lane == 0) {
             const double r = ((W[0] + W[1]) + W[2]) + W[3];          // block_sum: r = 0; r += lds[w]

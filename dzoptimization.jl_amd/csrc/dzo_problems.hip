@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
                                                                 PhiDir<T> a, PhiDir<T> b,
                                                                 double *__restrict__ partials, int32_t *__restrict__ flags) {
     constexpr int N = Vec16<T>::N;
-    __shared__ double lds[kWaves];
+    __shared__ double lds6[6 * kWaves];
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
         const T *col = A + j * n;
         double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -400,8 +400,7 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
             }
         }
         double c[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) c[r] = ((r < 3 ? a.active[r] : b.active[r - 3]) != 0) ? block_sum(acc[r], lds) : 0.0;
+        block_sum_multi<6>(acc, lds6, c);                  // (inactive requests sum zeros; each value = block_sum of it)
         if (threadIdx.x == 0) {
             const T xo = x[j];
 #pragma unroll
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
 // out[8..] at 3q; flags re-armed
 __global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__restrict__ partials, int64_t count, double scale,
                                                              double *__restrict__ out, int32_t *__restrict__ flags, double ticket) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds6[6 * kWaves];
     double v[6] = {0, 0, 0, 0, 0, 0};
     // (one block pulling 6 x count values through one CU is bound by load latency: eight strided steps of loads are
     // in flight before the first add; the adds keep the order of the plain loop, so every value is what
@@ -454,8 +453,7 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__res
         for (int r = 0; r < 6; ++r) v[r] += partials[(int64_t)r * count + i];
     }
     double sres[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) sres[r] = block_sum(v[r], lds);
+    block_sum_multi<6>(v, lds6, sres);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) out[r] = scale * sres[r];
