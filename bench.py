@@ -769,7 +769,7 @@ def main():
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            symbol = {"lbfgs_single_pass": ("lbfgs_point_pass_kernel<double, 20, false>" if opt.ring_layout == 2 and m > 16 else
+            symbol = {"lbfgs_single_pass": ("lbfgs_point_pass_kernel<double, 20, false, 2>" if opt.ring_layout == 2 and m > 16 else
                                             "lbfgs_point_pass_kernel" if opt.ring_layout == 2 else "lbfgs_single_pass_kernel"),
                       "lbfgs_gram_pass": "gram_pass_lanes_kernel", "lbfgs_combine": "combine_kernel",
                       "lbfgs_chain_link": "chain_link_kernel"}[dom]

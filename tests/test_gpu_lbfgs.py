@@ -1179,3 +1179,22 @@ def test_point_ring_adopts_what_the_host_wrote_into_the_aliased_arrays(dtype):
         assert np.array_equal(xd.to_host(), opt.current_point.to_host())   # still aliased
     finally:
         orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+
+
+def test_fused_reduce_finish_launch_gives_the_same_scalars_bit_for_bit(monkeypatch):
+    """DZO_TUNE_FUSED_FINISH=1: the scalar stage of a Gram pass (sum of the per-block partials + the two-loop on scalars)
+    in one 1024-thread launch instead of two launches (measured slower at config 4, off by default).  Its waves emulate
+    the 256-thread reduction kernel's summation order, so alpha, rho and the direction must be the SAME BITS."""
+    n, k, m = 100_003, 10, 10
+
+    def direction(fused):
+        monkeypatch.setenv("DZO_TUNE_FUSED_FINISH", str(fused))
+        opt, g, S, Y, rho, keep = _frozen(n, k, m, np.float32)
+        d = opt.compute_step_direction().to_host()
+        d2 = opt.compute_step_direction().to_host()
+        assert np.array_equal(d, d2)
+        return d, opt.alpha_history.copy()
+    d0, a0 = direction(0)
+    d1, a1 = direction(1)
+    assert np.array_equal(a0, a1)
+    assert np.array_equal(d0, d1)

@@ -205,3 +205,32 @@ def test_first_steps_with_deep_halvings_at_scale(dtype, n, m):
     finally:
         orc.set_dot_mode(orc.DOT_SEQUENTIAL)
         orc.set_threads(1)
+
+
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 400_000, 16), (np.float32, 500_000, 7), (np.float64, 400_000, 12)],
+                         ids=["float64-m16", "float32-m7", "float64-m12"])
+def test_one_register_set_variant_of_the_point_pass_runs_the_same_trajectory(dtype, n, m, monkeypatch):
+    """DZO_TUNE_POINT_SETS=1 selects the point pass with ONE register set per wave and two waves per SIMD (K <= 16; measured
+    slower than the two-set form at config-3-like sizes, kept as a knob).  Same arithmetic per element and the same
+    reduction tree per wave-row, but a different grid, i.e. a different order of the per-block partial sums: the
+    trajectory must agree with the default variant to reduction-order accuracy, step by step, trial counts included."""
+    def run(sets):
+        monkeypatch.setenv("DZO_TUNE_POINT_SETS", str(sets))
+        _, opt = _make(n, m, dtype, step0=0.5)
+        fs, tr = [], []
+        for _ in range(m + 6):
+            opt.step()
+            if opt.is_stuck:
+                break
+            fs.append(opt.current_objective_value); tr.append(opt.last_trials)
+        x = opt.current_point.to_host()
+        assert opt.ring_layout == 2 and opt.single_pass_steps >= len(fs)
+        opt.close()
+        return fs, tr, x
+    f2, t2, x2 = run(2)
+    f1, t1, x1 = run(1)
+    assert len(f1) == len(f2) >= m + 2 or len(f1) == len(f2)
+    assert t1 == t2
+    tol = 1e-9 if dtype == np.float64 else 1e-3
+    assert np.allclose(f1, f2, rtol=tol, atol=0)
+    assert rel(x1, x2) <= (1e-7 if dtype == np.float64 else 1e-2)
