@@ -151,9 +151,13 @@ def _barrier(world):
     torch.cuda.synchronize()
 
 
-def _kernel_bytes(name, n, k, esize, layout=1):
+def _kernel_bytes(name, n, k, esize, layout=1, regrad=False):
     """ALGORITHMIC bytes per launch (DESIGN.md section d)."""
     if name in ("lbfgs_single_pass", "lbfgs_single_pass_retry"):
+        if layout == 2 and regrad:
+            # point ring, gradients recomputed in registers from the points (3-point stencil): reads the k + 1 POINTS,
+            # writes the trial point and its gradient into the spare slot
+            return (k + 3) * n * esize
         if layout == 2:
             # point ring: reads the k + 1 points and k + 1 gradients (2k + 2), writes the trial point and its gradient
             # into the spare slot (2); step_direction is formed on demand, the pairs in registers
@@ -754,7 +758,7 @@ def main():
     kernels = {}
     for name, (launches, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
         avg_us = 1e3 * ms / launches
-        b = _kernel_bytes(name, n, k, esize, opt.ring_layout)
+        b = _kernel_bytes(name, n, k, esize, opt.ring_layout, opt.pass_recomputes_gradients)
         kernels[name] = {"launches": launches, "avg_us": round(avg_us, 2),
                          "algorithmic_GBps": None if b is None else round(b / (avg_us * 1e-6) / 1e9, 1)}
     roofline = None
@@ -769,14 +773,14 @@ def main():
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            symbol = {"lbfgs_single_pass": ("lbfgs_point_pass_kernel<double, 20, false, 2>" if opt.ring_layout == 2 and m > 16 else
+            symbol = {"lbfgs_single_pass": (f"lbfgs_point_pass_kernel<double, 20, false, {opt.pass_register_sets}>" if opt.ring_layout == 2 and m > 16 else
                                             "lbfgs_point_pass_kernel" if opt.ring_layout == 2 else "lbfgs_single_pass_kernel"),
                       "lbfgs_gram_pass": "gram_pass_lanes_kernel", "lbfgs_combine": "combine_kernel",
                       "lbfgs_chain_link": "chain_link_kernel"}[dom]
             roofline = {"bound": "hbm", "kernel": symbol, "hip_event_name": dom,
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize, opt.ring_layout),
+                        "algorithmic_bytes_per_launch": _kernel_bytes(dom, n, k, esize, opt.ring_layout, opt.pass_recomputes_gradients),
                         "avg_launch_us": kernels[dom]["avg_us"]}
             roofline["traffic_source"] = (None if traffic is None else
                                           "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -799,8 +803,10 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])",
                    "n": n, "m": m, "history_full": k == m,
-                   "two_loop": (("single_pass on the point ring (one sweep over the last k+1 points and gradients per trial of a "
-                                 "step, pairs formed in registers)" if opt.ring_layout == 2 else
+                   "two_loop": ((("single_pass on the point ring (one sweep over the last k+1 POINTS per trial of a step; their gradients "
+                                  "are recomputed in registers from the points, pairs formed in registers)" if opt.pass_recomputes_gradients else
+                                  "single_pass on the point ring (one sweep over the last k+1 points and gradients per trial of a "
+                                  "step, pairs formed in registers)") if opt.ring_layout == 2 else
                                  "single_pass on the pair ring (one sweep over the history per trial; gram + combine only after "
                                  "a step that needed t <= 1/4)") if "lbfgs_single_pass" in table else args.mode),
                    "history_layout": ({0: "slabs", 1: "tiles of pairs", 2: "tiles of points"}[opt.ring_layout] +

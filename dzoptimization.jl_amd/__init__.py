@@ -640,6 +640,8 @@ class LBFGSOptimizer(_OptBase):
     single_pass_retries = property(lambda s: s._i(13))    # rejected first trials continued by a second pass at t/2
     ring_layout = property(lambda s: s._i(14))            # 0 slabs, 1 tile-major pairs, 2 tile-major points (the point ring)
     tile_arrangement = property(lambda s: s._i(15))       # 0 no tiles (slabs), 1 tile-major, 2 stream-major
+    pass_recomputes_gradients = property(lambda s: bool(s._i(16)))   # point pass: gradients of the ring's points recomputed from the point tiles
+    pass_register_sets = property(lambda s: s._i(17))     # point pass: register sets per wave (1 = two waves per SIMD)
 
     def compute_step_direction(self, sync=True):
         """``compute_lbfgs_step_direction!`` (:430-451).  ``sync=False`` only enqueues the kernels (the

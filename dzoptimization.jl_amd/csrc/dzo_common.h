@@ -266,6 +266,19 @@ template <> __device__ __forceinline__ float lane_next<float>(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// the same with a value for the lane that has no neighbour (lane 0 / lane 63 keep `edge`: the DPP's `old` operand).
+// (A v_writelane after the plain shift measured 84 instructions MORE per wave-row of the point pass at K = 20.)
+template <typename T> __device__ __forceinline__ T lane_prev_or(T v, T edge);
+template <typename T> __device__ __forceinline__ T lane_next_or(T v, T edge);
+template <> __device__ __forceinline__ double lane_prev_or<double>(double v, double edge) { return dpp_f64<0x138, 0xF>(edge, v); }
+template <> __device__ __forceinline__ double lane_next_or<double>(double v, double edge) { return dpp_f64<0x130, 0xF>(edge, v); }
+template <> __device__ __forceinline__ float lane_prev_or<float>(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+template <> __device__ __forceinline__ float lane_next_or<float>(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
 // wave64 sum in every lane without touching LDS (DPP + permlane swaps; fixed order)
 __device__ __forceinline__ double wave_sum_all_dpp(double v) {
     v += lane_xor1(v);

@@ -151,7 +151,7 @@ struct dzo_lbfgs_s {
     bool lazy_d = true;             // DZO_TUNE_LAZY_D
     bool fused_finish = false;      // DZO_TUNE_FUSED_FINISH: reduce + finish of a Gram pass in one launch when the partials are few (measured slower)
     int64_t fused_finish_max = 65536;   // DZO_TUNE_FUSED_FINISH_MAX: ... at most this many partial sums
-    int point_sets = 2;             // DZO_TUNE_POINT_SETS: register sets per wave of the point pass (1: two waves per SIMD)
+    int point_sets = 1;             // DZO_TUNE_POINT_SETS: register sets per wave of the point pass (1: two waves per SIMD; the default where it fits)
     bool d_stale = false;
     int dview_k = 0, dview_newest = 0;
     template <typename T> T *s_slot(int slot) const {
@@ -1173,6 +1173,9 @@ __global__ __launch_bounds__(kBlock, 1) void lbfgs_single_pass_kernel(FusedParam
 // (the spare slot takes the trial), so a rejected trial just runs the pass again with a smaller t.
 // FIRST: the first step! walks along the step_direction the constructor left (d0 = -(step / |g|) g, :386-387 -- a
 // public field the caller may have changed): d is read instead of formed and not written back.
+#ifndef DZO_PP_REGRAD
+#define DZO_PP_REGRAD 1      // point pass: 1 = every lane recomputes the points' gradients from the point tiles (they are not streamed)
+#endif
 #ifndef DZO_PP_REFILL
 #define DZO_PP_REFILL 1      // point pass: 1 = a register set is refilled tile by tile inside the dot-product loop; 0 = whole-set requests
 #endif
@@ -1214,7 +1217,24 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         a_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.alpha[threadIdx.x]) : (T)0;
         c_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.coef[threadIdx.x]) : (T)0;
     }
+    // REGRAD: the gradients of the K + 1 points are not streamed at all.  G_j is a 3-point stencil of X_j and a tile of
+    // X_j carries the neighbours of all its 62 owned vectors; the two halo lanes lack one neighbour element each, which
+    // ONE gathered load per wave-row supplies for all points at once (lane j: the element before the tile of point j,
+    // from the previous ring row's tile; lane 32 + j: the element after it, from the next ring row's).  Every lane then
+    // evaluates rosen_grad_elem -- the function that produced the stored gradients, so the same bits -- and the pass
+    // reads K + 1 tiles per row instead of 2 (K + 1), for K + 1 stencil evaluations.
+    constexpr bool kRegrad = DZO_PP_REGRAD != 0 && !FIRST;      // (the first step, once per optimizer, streams its one gradient)
+    __shared__ uint32_t s_off[kFusedMaxK + 1];
+    if constexpr (kRegrad) {
+#pragma unroll
+        for (int j = 0; j <= K; ++j) if (threadIdx.x == j) s_off[j] = p.soff[j];
+    }
     __syncthreads();
+    uint32_t hoff = 0;                         // this lane's piece of the gather, relative to the row base of the neighbouring ring row
+    if constexpr (kRegrad) {
+        const int hj = (lane & 31) <= K ? (lane & 31) : K;
+        hoff = s_off[hj] + (lane < 32 ? (uint32_t)(61 * 16 + (N - 1) * sizeof(T)) : (uint32_t)(2 * 16));
+    }
     const bool scaled = k > 0;
     const T scale = scaled ? (T)p.scale[0] : (T)1;
     const int64_t nvec = p.n / N;
@@ -1280,27 +1300,56 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         staged = 0;
     };
     // K + 1 points and K + 1 gradients of a row; two register sets (as lbfgs_single_pass_kernel)
-    auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N]) {
+    auto load_halo = [&](int64_t row, T &hx) {                   // (kRegrad) the two elements the halo lanes' stencils lack, all points at once
+        int64_t r = lane < 32 ? row - 1 : row + 1;               // (per lane: the previous / the next ring row; clamped, the value is unused there)
+        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+        const char *nb = reinterpret_cast<const char *>(p.ring) + (uint64_t)r * p.rowbytes;
+        hx = __builtin_nontemporal_load(reinterpret_cast<const T *>(nb + hoff));
+    };
+    auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N], T &hx) {
         // (the order compute() refills a set in: the waits the compiler derives for the loop are then the same on
         // the first trip as on every other)
         char *rb = rowbase(row);
 #pragma unroll
         for (int j = 0; j <= K; ++j) {
-            load16_nt(tl(rb, p.soff[j] + p.ystride), gv[j]);
+            if constexpr (!kRegrad) load16_nt(tl(rb, p.soff[j] + p.ystride), gv[j]);
+            else {                                               // (defined on entry to the loop; compute() overwrites it)
+#pragma unroll
+                for (int e = 0; e < N; ++e) gv[j][e] = (T)0;
+            }
             load16_nt(tl(rb, p.soff[j]), xv[j]);
         }
+        if constexpr (kRegrad) load_halo(row, hx);
         if constexpr (DZO_PP_REFILL != 0) __builtin_amdgcn_sched_barrier(0);   // set by set: nothing of the next set moves up into this one
     };
     // refill: the row this register set serves next (two rows ahead).  Its tiles are requested from inside the
     // dot-product loop, point i once pair i -- the last reader of that point's registers -- is done, instead of
     // whole-set requests in front of the other set's compute (issue(next); compute(cur)): -10 us at config 3.
-    auto compute = [&](int64_t row, uint32_t boff, T (&xv)[K + 1][N], T (&gv)[K + 1][N], int64_t refill_row) {
+    auto compute = [&](int64_t row, uint32_t boff, T (&xv)[K + 1][N], T (&gv)[K + 1][N], T &hx, int64_t refill_row) {
         char *nrb = rowbase(refill_row);
         constexpr bool kRefill = DZO_PP_REFILL != 0;
         const int64_t v = row * kOwn - kLead + lane;
         const bool valid = v >= 0 && v < nvec;
         const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
         const int64_t e0 = v * N;
+        if constexpr (kRegrad) {
+            // the gradients of this row's K + 1 points, every lane (halo lanes included)
+#pragma unroll
+            for (int j = 0; j <= K; ++j) {
+                T hl, hr;                                        // the elements before / after the tile of point j (wave-uniform)
+                if constexpr (sizeof(T) == 8) { hl = readlane_f64(hx, j); hr = readlane_f64(hx, 32 + j); }
+                else { hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hx), j)); hr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hx), 32 + j)); }
+                const T xp = lane_prev_or<T>(xv[j][N - 1], hl);  // lane 0 has no lane - 1: it takes hl
+                const T xq = lane_next_or<T>(xv[j][0], hr);      // lane 63: hr
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const T xl = e > 0 ? xv[j][(e + N - 1) % N] : xp;
+                    const T xr = e + 1 < N ? xv[j][(e + 1) % N] : xq;
+                    gv[j][e] = rosen_grad_elem<T>(e0 + e, p.n, xl, xv[j][e], xr);
+                }
+                __builtin_amdgcn_sched_barrier(0);               // point by point (the temporaries of 21 stencils at once do not fit)
+            }
+        }
         // ---- d = the reference's elementwise recurrence (:438-449)
         T q[N];
         if constexpr (FIRST) {
@@ -1415,26 +1464,28 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             }
             // point i is dead: its registers take the same tiles of the row two ahead
             if constexpr (kRefill) {
-                load16_nt(tl(nrb, p.soff[i] + p.ystride), gv[i]);
+                if constexpr (!kRegrad) load16_nt(tl(nrb, p.soff[i] + p.ystride), gv[i]);
                 load16_nt(tl(nrb, p.soff[i]), xv[i]);
             }
         };
         static_for<K>(pair_dots);
         if constexpr (kRefill) {
-            load16_nt(tl(nrb, p.soff[K] + p.ystride), gv[K]);
+            if constexpr (!kRegrad) load16_nt(tl(nrb, p.soff[K] + p.ystride), gv[K]);
             load16_nt(tl(nrb, p.soff[K]), xv[K]);
+            if constexpr (kRegrad) load_halo(refill_row, hx);
         }
         if (want_dots) dots.finish_row(lane);
         if constexpr (kRefill) __builtin_amdgcn_sched_barrier(0);   // (the other set's compute starts below this set's last request)
     };
     T xA[K + 1][N], gA[K + 1][N];
     T xB[SETS == 2 ? K + 1 : 1][N], gB[SETS == 2 ? K + 1 : 1][N];
+    T hxA = (T)0, hxB = (T)0;
     int64_t row = (int64_t)blockIdx.x * kWaves + wave;
     auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };   // (past the end: the last row again, unconditionally)
     if constexpr (SETS == 1) {
-        issue(in_range(row), xA, gA);
+        issue(in_range(row), xA, gA, hxA);
         while (row < rows) {
-            compute(row, byte_offset(row), xA, gA, in_range(row + stride));
+            compute(row, byte_offset(row), xA, gA, hxA, in_range(row + stride));
             if (staged >= stage_rows) flush_stage();
             row += stride;
         }
@@ -1445,27 +1496,27 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         // same kernel time, 640-648 against 623-644 us over two boxes: the sweep is bound by its memory shape, not by
         // the wave's waits.  SQ counters of that build: 44 % of the wave cycles issuing, 43 % issue stalls, 13 % in
         // s_waitcnt; the round-2 kernel: 69 / 10 / 21 % with 1.85 x the vector instructions.)
-        issue(in_range(row), xA, gA);
-        issue(in_range(row + stride), xB, gB);
+        issue(in_range(row), xA, gA, hxA);
+        issue(in_range(row + stride), xB, gB, hxB);
         while (row < rows) {
-            compute(row, byte_offset(row), xA, gA, in_range(row + 2 * stride));
+            compute(row, byte_offset(row), xA, gA, hxA, in_range(row + 2 * stride));
             if (staged >= stage_rows) flush_stage();
             row += stride;
             if (row >= rows) break;
-            compute(row, byte_offset(row), xB, gB, in_range(row + 2 * stride));
+            compute(row, byte_offset(row), xB, gB, hxB, in_range(row + 2 * stride));
             if (staged >= stage_rows) flush_stage();
             row += stride;
         }
     } else {                                                     // whole-set requests one row ahead (the round-2 loop)
-        issue(in_range(row), xA, gA);
+        issue(in_range(row), xA, gA, hxA);
         while (row < rows) {
-            issue(in_range(row + stride), xB, gB);
-            compute(row, byte_offset(row), xA, gA, 0);
+            issue(in_range(row + stride), xB, gB, hxB);
+            compute(row, byte_offset(row), xA, gA, hxA, 0);
             if (staged >= stage_rows) flush_stage();
             row += stride;
             if (row >= rows) break;
-            issue(in_range(row + stride), xA, gA);
-            compute(row, byte_offset(row), xB, gB, 0);
+            issue(in_range(row + stride), xA, gA, hxA);
+            compute(row, byte_offset(row), xB, gB, hxB, 0);
             if (staged >= stage_rows) flush_stage();
             row += stride;
         }
@@ -2527,14 +2578,23 @@ template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedP
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// one register set per wave (two waves per SIMD)?  DZO_TUNE_POINT_SETS=1 (the default), where the instantiation fits 256 registers
+template <typename T> static bool point_one_set(const dzo_lbfgs_s *o) { return o->point_sets == 1 && (sizeof(T) == 8 || o->m <= 12); }
+
 // the instantiation of the point pass for this optimizer: the smallest K that holds m pairs; one or two register sets
 // (DZO_TUNE_POINT_SETS; see the kernel)
 template <typename T> static void (*point_pass_kernel_for(dzo_lbfgs_s *o, bool first))(FusedParams<T>) {
     if (first) return lbfgs_point_pass_kernel<T, 8, true>;
-    if (o->point_sets == 1 && o->m <= 16)                   // (K = 20: 168 registers of tiles + the arithmetic do not fit 256 -- it would spill)
-        return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
-               : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1>
-               : lbfgs_point_pass_kernel<T, 16, false, 1>;
+    if (point_one_set<T>(o)) {
+        if constexpr (sizeof(T) == 8) {
+            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
+                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1>
+                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1>
+                   : lbfgs_point_pass_kernel<T, 20, false, 1>;
+        } else {                                             // (fp32, K > 12: the fp64 copies for the dots do not fit 256 registers)
+            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1> : lbfgs_point_pass_kernel<T, 12, false, 1>;
+        }
+    }
     return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8>
            : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12>
            : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16>
@@ -2617,7 +2677,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     // rows of new tiles a wave collects in LDS before it writes them (2 KiB per row and wave; the whole 160-KiB LDS
     // of a CU is this one block's)
     // (two blocks per CU with one register set per wave: half the LDS each)
-    const bool one_set = o->point_sets == 1 && o->m <= 16 && k > 0;
+    const bool one_set = point_one_set<T>(o) && k > 0;
     fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", one_set ? 8 : 16);
     if (fp.stage_rows < 1) fp.stage_rows = 1;
     if (fp.stage_rows > (one_set ? 9 : 18)) fp.stage_rows = one_set ? 9 : 18;
@@ -2936,7 +2996,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
             // point ring: the start point and its gradient are point 0
             o->points = true;
             o->lazy_d = tune("DZO_TUNE_LAZY_D", 1) != 0;
-            o->point_sets = tune("DZO_TUNE_POINT_SETS", 2) == 1 ? 1 : 2;
+            o->point_sets = tune("DZO_TUNE_POINT_SETS", 1) == 1 ? 1 : 2;
             o->xg_host_may_write = true;                      // (the caller owns x0 / g0 and may change them before the first step)
             DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
             DZO_HIP(hipGetLastError());
@@ -3151,6 +3211,8 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 13: *value = o->single_pass_retries; break;
     case 14: *value = o->points ? 2 : (o->blocked ? 1 : 0); break;   // history layout: 0 slabs, 1 tiles of pairs, 2 tiles of points
     case 15: *value = o->blocked ? (o->tile_stride == kTileBytes ? 1 : 2) : 0; break;   // arrangement of the tiles: 1 tile-major, 2 stream-major
+    case 16: *value = (o->points && DZO_PP_REGRAD != 0) ? 1 : 0; break;   // point pass: 1 = the points' gradients are recomputed from the point tiles, not streamed
+    case 17: { int sets = 0; if (o->points) { DZO_DISPATCH(o->core.dtype, sets = point_one_set<T>(o) ? 1 : 2); } *value = sets; break; }   // register sets per wave of the point pass
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;

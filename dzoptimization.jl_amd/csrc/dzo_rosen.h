@@ -27,4 +27,13 @@ template <typename T> __device__ __forceinline__ T rosen_grad_elem(int64_t i, in
     return gi;
 }
 
+// the same for an element that has both neighbours (0 < i < n - 1): identical operations, no index tests
+template <typename T> __device__ __forceinline__ T rosen_grad_interior(T xp, T xi, T xn) {
+    const T t2 = dfma(-xi, xi, xn);
+    const T t1 = (T)1 - xi;
+    const T gi = dfma((T)-400 * xi, t2, (T)-2 * t1);
+    const T t2p = dfma(-xp, xp, xi);
+    return dfma((T)200, t2p, gi);
+}
+
 }  // namespace dzo

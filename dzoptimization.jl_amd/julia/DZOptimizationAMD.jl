@@ -370,6 +370,8 @@ function Base.getproperty(o::LBFGSOptimizer{T}, s::Symbol) where {T}
     s === :single_pass_retries && return Int(_lb_i(o, 13))
     s === :ring_layout && return Int(_lb_i(o, 14))
     s === :tile_arrangement && return Int(_lb_i(o, 15))
+    s === :pass_recomputes_gradients && return _lb_i(o, 16) != 0
+    s === :pass_register_sets && return Int(_lb_i(o, 17))
     return getfield(o, s)
 end
 

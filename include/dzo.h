@@ -220,7 +220,9 @@ int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
  * trial rejected; field 13: how many of the rejected ones were continued by the same pass at
  * t/2; field 14: layout of the history in HBM -- 0 slabs, 1 tiles of pairs, 2 tiles of points
  * (DESIGN.md "point ring"); field 15: arrangement of the tiles -- 1 tile-major, 2 stream-major
- * (informational);
+ * (informational); field 16: 1 when the pass over the point ring recomputes the points' gradients from the
+ * point tiles instead of streaming them; field 17: register sets per wave of that pass (1 = two waves per
+ * SIMD, 2 = one), 0 when the optimizer is not on the point ring (both informational);
  * dzo_lbfgs_get_s field 2: last_step_length. */
 int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t opt, int32_t descent_check, int32_t steepest_descent_fallback);
 
