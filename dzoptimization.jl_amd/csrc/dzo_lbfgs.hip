@@ -898,7 +898,7 @@ template <typename T> struct FusedParams {
     int nt_tiles;                              // point ring: non-temporal stores for the new point's tiles (when they do not fit the Infinity Cache)
     int stage_rows;                            // point ring: rows whose new tiles a wave collects in LDS before it writes them in one burst
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
-    int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 8 = no wave butterflies (point pass), 64 = no tile stores
+    int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
 };
 
 // PLAIN: ablation build with plain instead of non-temporal history loads (DZO_TUNE_SP_DEBUG bit 256,
@@ -1280,20 +1280,21 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             if (own) {
                 char *xt = rowbase(r) + p.new_off;
                 char *gt = xt + p.ystride;
+                const bool with_g = !(p.debug_skip & 128);       // (ablation: the gradient tile is not written)
                 if (p.nt_tiles) {
                     store16_nt(reinterpret_cast<T *>(xt + toff), xs);
-                    store16_nt(reinterpret_cast<T *>(gt + toff), gs);
+                    if (with_g) store16_nt(reinterpret_cast<T *>(gt + toff), gs);
                 } else {
                     store16(reinterpret_cast<T *>(xt + toff), xs);
-                    store16(reinterpret_cast<T *>(gt + toff), gs);
+                    if (with_g) store16(reinterpret_cast<T *>(gt + toff), gs);
                 }
                 if (lane == kLead && r > 0) {
                     store16(reinterpret_cast<T *>(xt - (int64_t)p.rowbytes + 63 * 16), xs);
-                    store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gs);
+                    if (with_g) store16(reinterpret_cast<T *>(gt - (int64_t)p.rowbytes + 63 * 16), gs);
                 }
                 if (lane == kLead + kOwn - 1 && r + 1 < rows) {
                     store16(reinterpret_cast<T *>(xt + p.rowbytes), xs);
-                    store16(reinterpret_cast<T *>(gt + p.rowbytes), gs);
+                    if (with_g) store16(reinterpret_cast<T *>(gt + p.rowbytes), gs);
                 }
             }
         }
