@@ -156,8 +156,8 @@ def _kernel_bytes(name, n, k, esize, layout=1, regrad=False):
     if name in ("lbfgs_single_pass", "lbfgs_single_pass_retry"):
         if layout == 2 and regrad:
             # point ring, gradients recomputed in registers from the points (3-point stencil): reads the k + 1 POINTS,
-            # writes the trial point and its gradient into the spare slot
-            return (k + 3) * n * esize
+            # writes the trial point into the spare slot (gradient tiles are formed on demand, when the host asks)
+            return (k + 2) * n * esize
         if layout == 2:
             # point ring: reads the k + 1 points and k + 1 gradients (2k + 2), writes the trial point and its gradient
             # into the spare slot (2); step_direction is formed on demand, the pairs in registers

@@ -139,6 +139,10 @@ struct dzo_lbfgs_s {
     // place (lbfgs_leave_points) and continues on the kernels above.
     bool points = false;
     bool xg_lin_stale = false;      // point 0 is newer than the contiguous x_user / g_user
+    // The passes recompute the gradients of the ring's points from the point tiles and write only the new POINT; the
+    // gradient tiles of a slot are formed on demand (lbfgs_ensure_g) when the host asks for current_gradient /
+    // delta_gradient / a Y[i], or the ring is turned into the pair ring.  Bit j: slot j's gradient tiles are valid.
+    uint32_t g_valid = 0;
     // The caller's arrays ARE current_point / current_gradient (:393): what the host writes into them between two
     // steps must be what the next step starts from.  On the point ring they are copies of point 0, so whenever the
     // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
@@ -1207,7 +1211,11 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int stage_rows = p.stage_rows;
-    char *stage = stage_lds + (size_t)wave * stage_rows * (2 * kTileBytes);
+    // (a pass that recomputes the gradients never reads a gradient tile: it does not write one either -- the host forms
+    // the tiles of a point's gradient when somebody asks for them, lbfgs_ensure_g)
+    constexpr bool kWriteG = !(DZO_PP_REGRAD != 0 && !FIRST);
+    constexpr int kStageTiles = kWriteG ? 2 : 1;
+    char *stage = stage_lds + (size_t)wave * stage_rows * (kStageTiles * kTileBytes);
     int staged = 0;
     int64_t stage_row0 = 0;                    // the row in slot 0 of the batch being collected
     const int k = p.k, kn = p.k_next;          // k <= K
@@ -1274,13 +1282,13 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             const int64_t v = r * kOwn - kLead + lane;
             const bool own = v >= 0 && v < nvec && lane >= kLead && lane < kLead + kOwn;
             T xs[N], gs[N];
-            const char *sl = stage + (size_t)b * (2 * kTileBytes) + toff;
+            const char *sl = stage + (size_t)b * (kStageTiles * kTileBytes) + toff;
             load16(reinterpret_cast<const T *>(sl), xs);
-            load16(reinterpret_cast<const T *>(sl + kTileBytes), gs);
+            if constexpr (kWriteG) load16(reinterpret_cast<const T *>(sl + kTileBytes), gs);
             if (own) {
                 char *xt = rowbase(r) + p.new_off;
                 char *gt = xt + p.ystride;
-                const bool with_g = !(p.debug_skip & 128);       // (ablation: the gradient tile is not written)
+                const bool with_g = kWriteG;
                 if (p.nt_tiles) {
                     store16_nt(reinterpret_cast<T *>(xt + toff), xs);
                     if (with_g) store16_nt(reinterpret_cast<T *>(gt + toff), gs);
@@ -1413,9 +1421,9 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
                 // the trial point and its gradient into this wave's LDS slice (every lane: the slice is private to
                 // the wave, no barrier); they reach the spare slot's tiles in flush_stage()
                 if (staged == 0) stage_row0 = row;
-                char *sl = stage + (size_t)staged * (2 * kTileBytes) + toff;
+                char *sl = stage + (size_t)staged * (kStageTiles * kTileBytes) + toff;
                 store16(reinterpret_cast<T *>(sl), xn);
-                store16(reinterpret_cast<T *>(sl + kTileBytes), gn);
+                if constexpr (kWriteG) store16(reinterpret_cast<T *>(sl + kTileBytes), gn);
                 staged += 1;
             }
         }
@@ -1561,6 +1569,28 @@ __global__ __launch_bounds__(kBlock) void ring_diff_kernel(int64_t rows, T *__re
 #pragma unroll
         for (int j = 0; j < N; ++j) va[j] = va[j] - vb[j];
         store16(pa, va);
+    }
+}
+
+// the gradient tiles of a point from its point tiles (point ring; the passes do not write them): every tile position,
+// halo copies included, evaluates rosen_grad_elem on its vector -- the bits the pass had in registers
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t nvec, const T *__restrict__ xs, T *__restrict__ gs, int64_t rowbytes) {
+    constexpr int N = Vec16<T>::N;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = id >> 6;
+        const int pos = (int)(id & 63);
+        const int64_t v = row * kRowOwn - kRowLead + pos;
+        if (v < 0 || v >= nvec) continue;
+        T x[N], g[N];
+        load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(xs) + row * rowbytes + pos * 16), x);
+        const T xl = v > 0 ? hist_ptr<true>(xs, v - 1, rowbytes)[N - 1] : (T)0;
+        const T xr = v + 1 < nvec ? hist_ptr<true>(xs, v + 1, rowbytes)[0] : (T)0;
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+            g[e] = rosen_grad_elem<T>(v * N + e, n, e > 0 ? x[(e + N - 1) % N] : xl, x[e], e + 1 < N ? x[(e + 1) % N] : xr);
+        store16(reinterpret_cast<T *>(reinterpret_cast<char *>(gs) + row * rowbytes + pos * 16), g);
     }
 }
 
@@ -2051,9 +2081,23 @@ template <typename T> static void ring_diff(dzo_lbfgs_s *o, void *a, const void 
     hipLaunchKernelGGL(ring_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->ring_rows, (T *)a, (const T *)b, o->rowbytes);
 }
 
+// point ring: make sure the gradient tiles of `slot` hold the gradient of the point in its point tiles
+static int32_t lbfgs_ensure_g(dzo_lbfgs_s *o, int slot) {
+    if (!o->points || (o->g_valid >> slot & 1u)) return DZO_OK;
+    OptCore &c = o->core;
+    DZO_TIMED("lbfgs_ring_regrad", c.stream);
+    const int grid = stream_grid(o->ring_rows * 64, 1);
+    DZO_DISPATCH(c.dtype, hipLaunchKernelGGL(ring_regrad_kernel<T>, dim3(grid), dim3(kBlock), 0, c.stream, c.n, c.n / Vec16<T>::N,
+                                             (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes));
+    DZO_HIP(hipGetLastError());
+    o->g_valid |= 1u << slot;
+    return DZO_OK;
+}
+
 // point ring: current_point / current_gradient into the caller's arrays (the optimizer aliases them, :393)
 static int32_t lbfgs_points_settle(dzo_lbfgs_s *o) {
     if (!o->points || !o->xg_lin_stale) return DZO_OK;
+    DZO_TRY(lbfgs_ensure_g(o, o->newest));
     DZO_TIMED("lbfgs_ring_gather", o->core.stream);
     DZO_DISPATCH(o->core.dtype, (ring_gather<T>(o, o->s_slot_v(o->newest), o->x_user), ring_gather<T>(o, o->y_slot_v(o->newest), o->g_user)));
     DZO_HIP(hipGetLastError());
@@ -2068,8 +2112,9 @@ static int32_t lbfgs_refresh_lin(dzo_lbfgs_s *o) {
     if (!o->blocked || !o->lin_stale) return DZO_OK;
     if (o->points) {                                      // pair 0 = point 0 - point 1
         if (o->k < 1) { o->lin_stale = false; return DZO_OK; }
-        DZO_TIMED("lbfgs_ring_gather", o->core.stream);
         const int a = o->slot_of(0), b = o->slot_of(1);
+        DZO_TRY(lbfgs_ensure_g(o, a)); DZO_TRY(lbfgs_ensure_g(o, b));
+        DZO_TIMED("lbfgs_ring_gather", o->core.stream);
         DZO_DISPATCH(o->core.dtype, (ring_gather_diff<T>(o, o->s_slot_v(a), o->s_slot_v(b), o->dx_lin),
                                      ring_gather_diff<T>(o, o->y_slot_v(a), o->y_slot_v(b), o->dg_lin)));
         DZO_HIP(hipGetLastError());
@@ -2097,6 +2142,7 @@ static int32_t lbfgs_leave_points(dzo_lbfgs_s *o) {
     DZO_TRY(lbfgs_materialize_d(o));                      // step_direction, delta_point / delta_gradient and the caller's
     DZO_TRY(lbfgs_points_settle(o));                      // arrays while the points still exist
     DZO_TRY(lbfgs_refresh_lin(o));
+    for (int i = 0; i <= o->k; ++i) DZO_TRY(lbfgs_ensure_g(o, o->slot_of(i)));   // the gradients of all k + 1 points
     {
         DZO_TIMED("lbfgs_ring_to_pairs", c.stream);
         for (int i = 0; i < o->k; ++i) {
@@ -2679,10 +2725,12 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     // of a CU is this one block's)
     // (two blocks per CU with one register set per wave: half the LDS each)
     const bool one_set = point_one_set<T>(o) && k > 0;
-    fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", one_set ? 8 : 16);
+    const int stage_tiles = (k == 0 || DZO_PP_REGRAD == 0) ? 2 : 1;      // tiles staged per row: the point, and its gradient where the kernel writes it
+    const int stage_max = (one_set ? 72 : 144) / (4 * stage_tiles);        // KiB of LDS per block / (waves x KiB per staged row)
+    fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", 16);
     if (fp.stage_rows < 1) fp.stage_rows = 1;
-    if (fp.stage_rows > (one_set ? 9 : 18)) fp.stage_rows = one_set ? 9 : 18;
-    size_t stage_bytes = (size_t)kWaves * fp.stage_rows * 2 * kTileBytes;
+    if (fp.stage_rows > stage_max) fp.stage_rows = stage_max;
+    size_t stage_bytes = (size_t)kWaves * fp.stage_rows * stage_tiles * kTileBytes;
     if (o->stage_kern != (const void *)kern || o->stage_bytes != stage_bytes) {   // (once per kernel and size)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess) {
             (void)hipGetLastError();                      // a device that does not grant it: stay within the default 64 KiB
@@ -2690,9 +2738,9 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         }
         o->stage_kern = (const void *)kern; o->stage_bytes = stage_bytes;
     }
-    if (o->stage_small && fp.stage_rows > 7) {
-        fp.stage_rows = 7;
-        stage_bytes = (size_t)kWaves * fp.stage_rows * 2 * kTileBytes;
+    if (o->stage_small && fp.stage_rows > 14 / stage_tiles) {
+        fp.stage_rows = 14 / stage_tiles;
+        stage_bytes = (size_t)kWaves * fp.stage_rows * stage_tiles * kTileBytes;
     }
     o->d_stale = false;                                   // (whatever was pending belonged to the previous step)
     const int view_k = k, view_newest = o->newest;
@@ -2736,6 +2784,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
             direction_pending();
             // delta_point = x_old (:118), delta_gradient still the previous step's
             if (o->k > 0) {
+                DZO_TRY(lbfgs_ensure_g(o, o->slot_of(0))); DZO_TRY(lbfgs_ensure_g(o, o->slot_of(1)));
                 ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
             }
             ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin);
@@ -2748,6 +2797,12 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         if (status == 1) {                                // :139-146, and the pass already did :478-480
             c.df = round_to_dtype(c.dtype, f_new - c.f);
             c.f = f_new;
+            {
+                // the spare slot becomes point 0: its gradient tiles are the new gradient only if this launch wrote them
+                // (the first step's kernel and builds that stream the gradients do; the recomputing pass does not)
+                const bool wrote_g = (k == 0) || DZO_PP_REGRAD == 0;
+                if (wrote_g) o->g_valid |= 1u << o->spare(); else o->g_valid &= ~(1u << o->spare());
+            }
             DZO_TRY(lbfgs_finish_push(o, 0, true, true, true));   // rho by the gated gram_finish; the pass wrote the new point's tiles
             o->spec_scalars = true;
             o->gram_ready = false;
@@ -2775,7 +2830,10 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
             c.is_stuck = true;
             direction_pending();
             ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin);
-            if (o->k > 0) ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
+            if (o->k > 0) {
+                DZO_TRY(lbfgs_ensure_g(o, o->slot_of(0))); DZO_TRY(lbfgs_ensure_g(o, o->slot_of(1)));
+                ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
+            }
             DZO_HIP(hipGetLastError());
             o->lin_stale = false;
             return DZO_OK;
@@ -2794,6 +2852,7 @@ static int32_t lbfgs_adopt_host_writes(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     o->xg_host_may_write = false;
     if (o->xg_lin_stale) return DZO_OK;                   // (the arrays do not hold a gathered copy at all)
+    DZO_TRY(lbfgs_ensure_g(o, o->newest));
     DZO_HIP(hipMemsetAsync(o->xg_differs, 0, sizeof(int32_t), c.stream));
     DZO_DISPATCH(c.dtype, (ring_compare<T>(o, o->s_slot_v(o->newest), o->x_user), ring_compare<T>(o, o->y_slot_v(o->newest), o->g_user)));
     DZO_HIP(hipGetLastError());
@@ -3000,6 +3059,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
             o->point_sets = tune("DZO_TUNE_POINT_SETS", 1) == 1 ? 1 : 2;
             o->xg_host_may_write = true;                      // (the caller owns x0 / g0 and may change them before the first step)
             DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
+            o->g_valid = 1u << o->newest;
             DZO_HIP(hipGetLastError());
         }
         // :381-388
@@ -3279,6 +3339,7 @@ int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_d
         void *dst = (char *)o->export_slab + ((what == 5 ? 0 : (size_t)o->m) + (size_t)idx) * vb;
         const void *src = what == 5 ? o->s_slot_v(o->slot_of(idx)) : o->y_slot_v(o->slot_of(idx));
         if (o->points) {                                  // pair idx = point idx - point idx+1
+            if (what == 6) { DZO_TRY(lbfgs_ensure_g(o, o->slot_of(idx))); DZO_TRY(lbfgs_ensure_g(o, o->slot_of(idx + 1))); }
             const void *older = what == 5 ? o->s_slot_v(o->slot_of(idx + 1)) : o->y_slot_v(o->slot_of(idx + 1));
             DZO_DISPATCH(o->core.dtype, ring_gather_diff<T>(o, src, older, dst));
         } else {
