@@ -37,6 +37,6 @@ python3 bench.py > profiles/${TAG}_bench_line.json 2> $OUT/bench.err
 echo "bench line done"
 for w in bfgs_dense bfgs_batched lbfgs_lse_f32; do python3 bench.py --workload $w > profiles/${TAG}_bench_$w.json 2> $OUT/bench_$w.err; echo "$w done"; done
 python3 bench.py --workload adgd --steps 200 --warmup 10 > profiles/${TAG}_bench_adgd.json 2> $OUT/bench_adgd.err
-BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 20 --warmup 3 > profiles/${TAG}_bench_gloo_rehearsal_2ranks_1gpu.json 2> $OUT/bench_gloo.err || true
+BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 20 --warmup 3 2> $OUT/bench_gloo.err | grep '^{' > profiles/${TAG}_bench_gloo_rehearsal_2ranks_1gpu.json || true   # (gloo prints its connection banner on stdout)
 mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* profiles/pmc_latest.json gpurun_out/profiles_$TAG/
 ls -la gpurun_out/profiles_$TAG
