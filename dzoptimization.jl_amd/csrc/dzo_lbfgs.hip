@@ -143,7 +143,6 @@ struct dzo_lbfgs_s {
     // gradient tiles of a slot are formed on demand (lbfgs_ensure_g) when the host asks for current_gradient /
     // delta_gradient / a Y[i], or the ring is turned into the pair ring.  Bit j: slot j's gradient tiles are valid.
     uint32_t g_valid = 0;
-    void *edges = nullptr;          // edge array of the point ring (FusedParams::edges): rows x 2 x kEdgeSlots elements
     // The caller's arrays ARE current_point / current_gradient (:393): what the host writes into them between two
     // steps must be what the next step starts from.  On the point ring they are copies of point 0, so whenever the
     // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
@@ -876,8 +875,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
 // each side.  62 uses the whole wave.  (56 owned vectors = seven whole 128-B lines per stream, so
 // that rows start on line boundaries, measured slower: 770 vs 757 us -- 11 % more rows and
 // redundant halo loads cost more than the partial first / last line of every row.)
-constexpr int kFusedMaxK = 20;
-constexpr int kEdgeSlots = 24;                 // entries per line of the point ring's edge array (>= m + 2 slots)                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
+constexpr int kFusedMaxK = 20;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
 
 template <typename T> struct FusedParams {
     int64_t n;
@@ -904,13 +902,6 @@ template <typename T> struct FusedParams {
     int nt_tiles;                              // point ring: non-temporal stores for the new point's tiles (when they do not fit the Infinity Cache)
     int stage_rows;                            // point ring: rows whose new tiles a wave collects in LDS before it writes them in one burst
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
-    // point ring, edge elements: edges[(2 r + w) * kEdgeSlots + slot] = what the neighbours of ring row r need of the point in
-    // `slot` -- w = 0: the last element of the row's tile position 61 (left neighbour of the NEXT row's lane 0),
-    // w = 1: the first element of position 2 (right neighbour of the PREVIOUS row's lane 63).  One contiguous 22-entry line
-    // per (row, w): the gather of a wave-row reads two such lines instead of 42 scattered elements of 42 tiles.
-    T *edges;
-    uint8_t slot[kFusedMaxK + 1];              // logical point j -> ring slot (for the edge array)
-    uint8_t new_slot;                          // the spare slot (takes the trial point)
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
 };
 
@@ -1235,23 +1226,15 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         c_s[threadIdx.x] = threadIdx.x < k ? (T)(-p.coef[threadIdx.x]) : (T)0;
     }
     // REGRAD: the gradients of the K + 1 points are not streamed at all.  G_j is a 3-point stencil of X_j and a tile of
-    // X_j carries the neighbours of all its 62 owned vectors; the two halo lanes lack one neighbour element each, which
-    // ONE gathered load per wave-row supplies for all points at once (lane j: the element before the tile of point j,
-    // from the previous ring row's tile; lane 32 + j: the element after it, from the next ring row's).  Every lane then
-    // evaluates rosen_grad_elem -- the function that produced the stored gradients, so the same bits -- and the pass
-    // reads K + 1 tiles per row instead of 2 (K + 1), for K + 1 stencil evaluations.
+    // X_j carries the neighbours of all its 62 owned vectors, so every lane evaluates rosen_grad_elem -- the function that
+    // produced the stored gradients, on the same operands, so the same bits -- and the pass reads K + 1 tiles per row
+    // instead of 2 (K + 1), for K + 1 stencil evaluations.  The two HALO lanes lack the neighbour on their outer side,
+    // and do not need it: all anybody takes from lane 0 is the LAST element of its trial point (the left neighbour of
+    // lane 1's first element) and from lane 63 the FIRST (right neighbour of lane 62's last), i.e. of their gradients
+    // only the inner element, whose stencil lies inside the tile.  Their outer elements carry finite garbage that
+    // nothing reads (halo lanes store nothing and add zeros to every sum).
     constexpr bool kRegrad = DZO_PP_REGRAD != 0 && !FIRST;      // (the first step, once per optimizer, streams its one gradient)
-    __shared__ uint32_t s_slot[kFusedMaxK + 1];
-    if constexpr (kRegrad) {
-#pragma unroll
-        for (int j = 0; j <= K; ++j) if (threadIdx.x == j) s_slot[j] = p.slot[j];
-    }
     __syncthreads();
-    uint32_t hoff = 0;                         // this lane's entry of the gather within an edge line (left lines for lanes < 32, right lines above)
-    if constexpr (kRegrad) {
-        const int hj = (lane & 31) <= K ? (lane & 31) : K;
-        hoff = (lane < 32 ? 0u : (uint32_t)kEdgeSlots) + s_slot[hj];
-    }
     const bool scaled = k > 0;
     const T scale = scaled ? (T)p.scale[0] : (T)1;
     const int64_t nvec = p.n / N;
@@ -1318,12 +1301,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         staged = 0;
     };
     // K + 1 points and K + 1 gradients of a row; two register sets (as lbfgs_single_pass_kernel)
-    auto load_halo = [&](int64_t row, T &hx) {                   // (kRegrad) the two elements the halo lanes' stencils lack, all points at once
-        int64_t r = lane < 32 ? row - 1 : row + 1;               // (per lane: the previous / the next ring row; clamped, the value is unused there)
-        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
-        hx = (p.debug_skip & 512) ? (T)0 : p.edges[r * (2 * kEdgeSlots) + hoff];   // (512: ablation, no gather)
-    };
-    auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N], T &hx) {
+    auto issue = [&](int64_t row, T (&xv)[K + 1][N], T (&gv)[K + 1][N]) {
         // (the order compute() refills a set in: the waits the compiler derives for the loop are then the same on
         // the first trip as on every other)
         char *rb = rowbase(row);
@@ -1336,13 +1314,12 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             }
             load16_nt(tl(rb, p.soff[j]), xv[j]);
         }
-        if constexpr (kRegrad) load_halo(row, hx);
         if constexpr (DZO_PP_REFILL != 0) __builtin_amdgcn_sched_barrier(0);   // set by set: nothing of the next set moves up into this one
     };
     // refill: the row this register set serves next (two rows ahead).  Its tiles are requested from inside the
     // dot-product loop, point i once pair i -- the last reader of that point's registers -- is done, instead of
     // whole-set requests in front of the other set's compute (issue(next); compute(cur)): -10 us at config 3.
-    auto compute = [&](int64_t row, uint32_t boff, T (&xv)[K + 1][N], T (&gv)[K + 1][N], T &hx, int64_t refill_row) {
+    auto compute = [&](int64_t row, uint32_t boff, T (&xv)[K + 1][N], T (&gv)[K + 1][N], int64_t refill_row) {
         char *nrb = rowbase(refill_row);
         constexpr bool kRefill = DZO_PP_REFILL != 0;
         const int64_t v = row * kOwn - kLead + lane;
@@ -1350,14 +1327,11 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
         const int64_t e0 = v * N;
         if constexpr (kRegrad) {
-            // the gradients of this row's K + 1 points, every lane (halo lanes included)
+            // the gradients of this row's K + 1 points, every lane (a halo lane's outer element: see above)
 #pragma unroll
             for (int j = 0; j <= K; ++j) {
-                T hl, hr;                                        // the elements before / after the tile of point j (wave-uniform)
-                if constexpr (sizeof(T) == 8) { hl = readlane_f64(hx, j); hr = readlane_f64(hx, 32 + j); }
-                else { hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hx), j)); hr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hx), 32 + j)); }
-                const T xp = lane_prev_or<T>(xv[j][N - 1], hl);  // lane 0 has no lane - 1: it takes hl
-                const T xq = lane_next_or<T>(xv[j][0], hr);      // lane 63: hr
+                const T xp = lane_prev<T>(xv[j][N - 1]);
+                const T xq = lane_next<T>(xv[j][0]);
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     const T xl = e > 0 ? xv[j][(e + N - 1) % N] : xp;
@@ -1397,11 +1371,6 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         for (int j = 0; j < N; ++j) {
             xn[j] = dfma(p.t, q[j], xv[0][j]);
             diff |= owner && !is_equal(xn[j], xv[0][j]);
-        }
-        // ---- the new point's edge elements for the neighbouring rows' gathers
-        if (owner && !(p.debug_skip & (2 | 64))) {              // (with the tile stores: the on-demand direction pass writes neither)
-            if (lane == 61) p.edges[row * (2 * kEdgeSlots) + p.new_slot] = xn[N - 1];
-            if (lane == 2) p.edges[row * (2 * kEdgeSlots) + kEdgeSlots + p.new_slot] = xn[0];
         }
         // ---- the objective at HALF the step rides along (:152's next candidate)
         {
@@ -1494,20 +1463,18 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         if constexpr (kRefill) {
             if constexpr (!kRegrad) load16_nt(tl(nrb, p.soff[K] + p.ystride), gv[K]);
             load16_nt(tl(nrb, p.soff[K]), xv[K]);
-            if constexpr (kRegrad) load_halo(refill_row, hx);
         }
         if (want_dots) dots.finish_row(lane);
         if constexpr (kRefill) __builtin_amdgcn_sched_barrier(0);   // (the other set's compute starts below this set's last request)
     };
     T xA[K + 1][N], gA[K + 1][N];
     T xB[SETS == 2 ? K + 1 : 1][N], gB[SETS == 2 ? K + 1 : 1][N];
-    T hxA = (T)0, hxB = (T)0;
     int64_t row = (int64_t)blockIdx.x * kWaves + wave;
     auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };   // (past the end: the last row again, unconditionally)
     if constexpr (SETS == 1) {
-        issue(in_range(row), xA, gA, hxA);
+        issue(in_range(row), xA, gA);
         while (row < rows) {
-            compute(row, byte_offset(row), xA, gA, hxA, in_range(row + stride));
+            compute(row, byte_offset(row), xA, gA, in_range(row + stride));
             if (staged >= stage_rows) flush_stage();
             row += stride;
         }
@@ -1518,27 +1485,27 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         // same kernel time, 640-648 against 623-644 us over two boxes: the sweep is bound by its memory shape, not by
         // the wave's waits.  SQ counters of that build: 44 % of the wave cycles issuing, 43 % issue stalls, 13 % in
         // s_waitcnt; the round-2 kernel: 69 / 10 / 21 % with 1.85 x the vector instructions.)
-        issue(in_range(row), xA, gA, hxA);
-        issue(in_range(row + stride), xB, gB, hxB);
+        issue(in_range(row), xA, gA);
+        issue(in_range(row + stride), xB, gB);
         while (row < rows) {
-            compute(row, byte_offset(row), xA, gA, hxA, in_range(row + 2 * stride));
+            compute(row, byte_offset(row), xA, gA, in_range(row + 2 * stride));
             if (staged >= stage_rows) flush_stage();
             row += stride;
             if (row >= rows) break;
-            compute(row, byte_offset(row), xB, gB, hxB, in_range(row + 2 * stride));
+            compute(row, byte_offset(row), xB, gB, in_range(row + 2 * stride));
             if (staged >= stage_rows) flush_stage();
             row += stride;
         }
     } else {                                                     // whole-set requests one row ahead (the round-2 loop)
-        issue(in_range(row), xA, gA, hxA);
+        issue(in_range(row), xA, gA);
         while (row < rows) {
-            issue(in_range(row + stride), xB, gB, hxB);
-            compute(row, byte_offset(row), xA, gA, hxA, 0);
+            issue(in_range(row + stride), xB, gB);
+            compute(row, byte_offset(row), xA, gA, 0);
             if (staged >= stage_rows) flush_stage();
             row += stride;
             if (row >= rows) break;
-            issue(in_range(row + stride), xA, gA, hxA);
-            compute(row, byte_offset(row), xB, gB, hxB, 0);
+            issue(in_range(row + stride), xA, gA);
+            compute(row, byte_offset(row), xB, gB, 0);
             if (staged >= stage_rows) flush_stage();
             row += stride;
         }
@@ -1582,19 +1549,6 @@ __global__ __launch_bounds__(kBlock) void ring_diff_kernel(int64_t rows, T *__re
 #pragma unroll
         for (int j = 0; j < N; ++j) va[j] = va[j] - vb[j];
         store16(pa, va);
-    }
-}
-
-// the edge-array entries of one slot from its point tiles (constructor: the start point)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void ring_edges_kernel(int64_t nvec, const T *__restrict__ xs, int64_t rowbytes, T *__restrict__ edges, int slot) {
-    constexpr int N = Vec16<T>::N;
-    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
-    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += (int64_t)gridDim.x * kBlock) {
-        const char *t = reinterpret_cast<const char *>(xs) + row * rowbytes;
-        const int64_t v0 = row * kRowOwn - kRowLead;
-        if (v0 + 61 < nvec) edges[row * (2 * kEdgeSlots) + slot] = reinterpret_cast<const T *>(t + 61 * 16)[N - 1];
-        if (v0 + 2 < nvec) edges[row * (2 * kEdgeSlots) + kEdgeSlots + slot] = reinterpret_cast<const T *>(t + 2 * 16)[0];
     }
 }
 
@@ -2689,11 +2643,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); fp.ystride = (uint32_t)o->tile_stride;   // (never written: no tile stores in this mode)
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     auto old_slot = [&](int j) { return ((o->dview_newest - j) % o->nslots + o->nslots) % o->nslots; };
-    for (int j = 0; j <= kFusedMaxK; ++j) {
-        fp.soff[j] = (uint32_t)((uint64_t)(2 * old_slot(j < k ? j : k)) * (uint64_t)o->tile_stride);
-        fp.slot[j] = (uint8_t)old_slot(j < k ? j : k);
-    }
-    fp.edges = (T *)o->edges; fp.new_slot = (uint8_t)o->spare();   // (not written here: no tile stores, no edge stores -- the view's oldest point IS the spare slot)
+    for (int j = 0; j <= kFusedMaxK; ++j) fp.soff[j] = (uint32_t)((uint64_t)(2 * old_slot(j < k ? j : k)) * (uint64_t)o->tile_stride);
     fp.gram_partials = o->gram_partials;                  // (consumed by the step's gated gram_finish; scratch here)
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
@@ -2736,11 +2686,8 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.ring = (T *)o->S; fp.rowbytes = (uint32_t)o->rowbytes;
     fp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); fp.ystride = (uint32_t)o->tile_stride;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
-    for (int j = 0; j <= kFusedMaxK; ++j) {               // points beyond k: point k again (those pairs are zero)
+    for (int j = 0; j <= kFusedMaxK; ++j)                 // points beyond k: point k again (those pairs are zero)
         fp.soff[j] = (uint32_t)((uint64_t)(2 * o->slot_of(j < k ? j : k)) * (uint64_t)o->tile_stride);
-        fp.slot[j] = (uint8_t)o->slot_of(j < k ? j : k);
-    }
-    fp.edges = (T *)o->edges; fp.new_slot = (uint8_t)o->spare();
     fp.gram_partials = o->gram_partials;
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
@@ -3015,7 +2962,6 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         o->pair_stride = 0;
         ALLOC(o->dx_lin, (size_t)o->stride * es);
         ALLOC(o->dg_lin, (size_t)o->stride * es);
-        ALLOC(o->edges, (size_t)o->ring_rows * 2 * kEdgeSlots * es);
     } else if (o->interleaved) {
         ALLOC(o->S, 2 * slab);
         o->Y = (char *)o->S + (size_t)o->stride * es;
@@ -3094,10 +3040,6 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
             o->xg_host_may_write = true;                      // (the caller owns x0 / g0 and may change them before the first step)
             DZO_DISPATCH(dtype, (ring_scatter<T>(o, x_dev, o->s_slot_v(o->newest)), ring_scatter<T>(o, g_dev, o->y_slot_v(o->newest))));
             o->g_valid = 1u << o->newest;
-            DZO_HIP(hipMemsetAsync(o->edges, 0, (size_t)o->ring_rows * 2 * kEdgeSlots * es, c.stream));
-            DZO_DISPATCH(dtype, hipLaunchKernelGGL(ring_edges_kernel<T>, dim3(stream_grid(o->ring_rows, 1)), dim3(kBlock), 0, c.stream, n / (16 / (int64_t)es),
-                                                   (const T *)o->s_slot_v(o->newest), o->rowbytes, (T *)o->edges, o->newest));
-            DZO_HIP(hipGetLastError());
             DZO_HIP(hipGetLastError());
         }
         // :381-388
@@ -3132,7 +3074,6 @@ int32_t dzo_lbfgs_destroy(dzo_lbfgs_t o) {
     if (o->twin_slab) (void)hipFree(o->twin_slab);
     if (o->dx_lin) (void)hipFree(o->dx_lin);
     if (o->dg_lin) (void)hipFree(o->dg_lin);
-    if (o->edges) (void)hipFree(o->edges);
     if (o->export_slab) (void)hipFree(o->export_slab);
     if (o->xt) (void)hipFree(o->xt);
     if (o->gt) (void)hipFree(o->gt);
