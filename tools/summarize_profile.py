@@ -87,7 +87,7 @@ def main():
                 out["lbfgs_combine"] = out[long_name]
             if long_name.startswith("lbfgs_single_pass_kernel<double") and "lbfgs_single_pass" not in out:
                 out["lbfgs_single_pass"] = out[long_name]
-            if long_name.startswith("lbfgs_point_pass_kernel<double") and ", true" not in long_name:
+            if long_name.startswith("lbfgs_point_pass_kernel<double") and not long_name.startswith("lbfgs_point_pass_kernel<double, 8, true"):
                 # (the default optimizer's pass; bench.py's profiling label.  `<double, 8, true, ...>` is the first step's variant)
                 if "lbfgs_single_pass" not in out or out[long_name]["launches_fetch_pass"] > out["lbfgs_single_pass"]["launches_fetch_pass"]:
                     out["lbfgs_single_pass"] = out[long_name]
