@@ -266,6 +266,27 @@ template <> __device__ __forceinline__ float lane_next<float>(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// the same where the lane without a neighbour may receive anything: it gets 0 (bound_ctrl), and the shift needs no copy
+// of the source to serve as the DPP's `old` operand (4 moves per fp64 value pair in the point pass's stencils)
+template <typename T> __device__ __forceinline__ T lane_prev0(T v);
+template <typename T> __device__ __forceinline__ T lane_next0(T v);
+template <> __device__ __forceinline__ double lane_prev0<double>(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <> __device__ __forceinline__ double lane_next0<double>(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <> __device__ __forceinline__ float lane_prev0<float>(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+template <> __device__ __forceinline__ float lane_next0<float>(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+
 // the same with a value for the lane that has no neighbour (lane 0 / lane 63 keep `edge`: the DPP's `old` operand).
 // (A v_writelane after the plain shift measured 84 instructions MORE per wave-row of the point pass at K = 20.)
 template <typename T> __device__ __forceinline__ T lane_prev_or(T v, T edge);

@@ -1342,8 +1342,8 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             // the gradients of this row's K + 1 points, every lane (a halo lane's outer element: see above)
 #pragma unroll
             for (int j = 0; j <= K; ++j) {
-                const T xp = lane_prev<T>(xv[j][N - 1]);
-                const T xq = lane_next<T>(xv[j][0]);
+                const T xp = lane_prev0<T>(xv[j][N - 1]);
+                const T xq = lane_next0<T>(xv[j][0]);
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     const T xl = e > 0 ? xv[j][(e + N - 1) % N] : xp;
@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             T xh[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) xh[j] = dfma(p.t_half, q[j], xv[0][j]);
-            const T xhnext = lane_next<T>(xh[0]);
+            const T xhnext = lane_next0<T>(xh[0]);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
@@ -1398,8 +1398,8 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             }
         }
         // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
-        const T xprev = lane_prev<T>(xn[N - 1]);
-        const T xnext = lane_next<T>(xn[0]);
+        const T xprev = lane_prev0<T>(xn[N - 1]);
+        const T xnext = lane_next0<T>(xn[0]);
         T gn[N], sn[N], yn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {

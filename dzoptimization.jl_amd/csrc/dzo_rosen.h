@@ -30,8 +30,10 @@ template <typename T> __device__ __forceinline__ T rosen_grad_elem(int64_t i, in
 // the same for an element that has both neighbours (0 < i < n - 1): identical operations, no index tests
 template <typename T> __device__ __forceinline__ T rosen_grad_interior(T xp, T xi, T xn) {
     const T t2 = dfma(-xi, xi, xn);
-    const T t1 = (T)1 - xi;
-    const T gi = dfma((T)-400 * xi, t2, (T)-2 * t1);
+    // -2 (1 - xi) as ONE fma: 2 xi - 2 is the same real number, and rounding commutes with the factor 2, so
+    // round(2 xi - 2) == -2 round(1 - xi) bit for bit (no overflow / subnormals anywhere near xi = 1)
+    const T m2 = dfma((T)2, xi, (T)-2);
+    const T gi = dfma((T)-400 * xi, t2, m2);
     const T t2p = dfma(-xp, xp, xi);
     return dfma((T)200, t2p, gi);
 }
