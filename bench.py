@@ -523,7 +523,7 @@ def secondary_workload(args):
         tab = dzo.profile_table()
         kern = {kk: {"launches": v[0], "avg_us": round(1e3 * v[1] / v[0], 2)} for kk, v in tab.items()}
         us = 1e3 * tab["adgd_fused_step"][1] / tab["adgd_fused_step"][0] if "adgd_fused_step" in tab else None
-        ach = None if us is None else 4 * n * 8 / (us * 1e-6) / 1e9
+        ach = None if us is None else 2 * n * 8 / (us * 1e-6) / 1e9
         out.update({"metric": "step!() calls/sec, AdGD n=10^7 fp64 (SURVEY 8(f) rank 1)",
                     "value": round(world * args.steps / el, 2), "unit": "step!() calls/s",
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
@@ -536,7 +536,7 @@ def secondary_workload(args):
                     "roofline": {"bound": "hbm", "kernel": "adgd_fused_step", "achieved": None if ach is None else round(ach, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
                                  "traffic": None, "avg_launch_us": None if us is None else round(us, 2),
-                                 "note": "4 n T per pass: reads x, g; writes the trial point and its gradient into the next of three buffer pairs; delta_point / delta_gradient enter only the two norms (the vectors are formed on demand)"},
+                                 "note": "2 n T per pass: reads x, writes the trial point into the next of three buffers; g_old is recomputed in registers from x_old (3-point stencil), g_new is not written (gradient arrays, delta_point / delta_gradient are formed on demand; the deltas enter only the two norms)"},
                     "kernels": kern})
     else:  # lbfgs_lse_f32 (config 4)
         n = 1_000_000 if args.n == 10_000_000 else args.n

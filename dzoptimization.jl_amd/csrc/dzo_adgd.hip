@@ -39,6 +39,7 @@ struct dzo_adgd_s {
     void *xbuf[3] = {nullptr, nullptr, nullptr}, *gbuf[3] = {nullptr, nullptr, nullptr};
     int cur = 0;                     // core.x == xbuf[cur], core.g == gbuf[cur]
     bool dx_lazy = false, dg_lazy = false;   // delta_point / delta_gradient = pair cur - pair (cur + 2) % 3, not formed yet
+    bool g_valid[3] = {true, true, true};    // gbuf[i] holds the gradient of xbuf[i] (the one-pass step writes points only)
     void *x_user = nullptr, *g_user = nullptr;
     bool unsettled = false;
     int device = 0;
@@ -76,8 +77,12 @@ namespace dzo {
 //   delta_point = x_new - x_old                       :145
 //   delta_gradient = g_new - g_old                    :306, :308
 //   partial sums of |delta_point|^2, |delta_gradient|^2   (:292, :294 of the next step)
-// 2 reads + 2 writes per element (the deltas enter the two sums only; the vectors are formed on demand from the
-// buffer pairs, see dzo_adgd_s) instead of the 16 element passes of the separate kernels.
+// 1 read + 1 write per element: g_old is the 3-point stencil of x_old, which the wave-row already holds, so it is
+// recomputed (rosen_grad_elem: the function that produced the stored gradient, so the same bits) instead of read, and
+// g_new is not written -- no pass reads a gradient array any more; the host forms current_gradient / delta_gradient from
+// the point buffers when somebody asks (adgd_ensure_g).  The halo lanes lack their outer neighbour and do not need it:
+// lane 1 takes only the LAST element of lane 0's trial point and lane 62 the FIRST of lane 63's, and the stencils of
+// those inner elements lie inside the row.  (Round 2's pass read and wrote the gradients: 4 n T.)
 constexpr int kAdgdOwn = 62;
 
 template <typename T> struct AdgdFusedParams {
@@ -107,9 +112,7 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
     const T t = (T)(-p.st->t);
     const int sel = p.st->sel;
     const T *__restrict__ xin = sel == 0 ? p.x0 : (sel == 1 ? p.x1 : p.x2);
-    const T *__restrict__ gin = sel == 0 ? p.g0 : (sel == 1 ? p.g1 : p.g2);
     T *__restrict__ xout = sel == 0 ? p.x1 : (sel == 1 ? p.x2 : p.x0);
-    T *__restrict__ gout = sel == 0 ? p.g1 : (sel == 1 ? p.g2 : p.g0);
     for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < rows; row += (int64_t)gridDim.x * kWaves) {
         const int64_t v = row * kAdgdOwn - 1 + lane;
         const bool valid = v >= 0 && v < nvec;
@@ -118,15 +121,21 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
         const int64_t e0 = v * N;
         T xo[N], go[N];
         load16(xin + vc * N, xo);                                            // halo lanes read their neighbours directly
-        load16(gin + vc * N, go);
+        {
+            const T xop = lane_prev0<T>(xo[N - 1]);
+            const T xoq = lane_next0<T>(xo[0]);
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                go[j] = rosen_grad_elem<T>(e0 + j, p.n, j > 0 ? xo[(j + N - 1) % N] : xop, xo[j], j + 1 < N ? xo[(j + 1) % N] : xoq);
+        }
         T xn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             xn[j] = dfma(t, go[j], xo[j]);                                   // :124
             diff |= owner && !is_equal(xn[j], xo[j]);                      // :128
         }
-        const T xprev = lane_prev<T>(xn[N - 1]);
-        const T xnext = lane_next<T>(xn[0]);
+        const T xprev = lane_prev0<T>(xn[N - 1]);
+        const T xnext = lane_next0<T>(xn[0]);
         T gn[N], sn[N], yn[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -142,8 +151,8 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
             }
         }
         if (owner) {
-            if (p.nt_stores) { store16_nt(xout + v * N, xn); store16_nt(gout + v * N, gn); }
-            else { store16(xout + v * N, xn); store16(gout + v * N, gn); }
+            if (p.nt_stores) store16_nt(xout + v * N, xn);
+            else store16(xout + v * N, xn);
         }
     }
     block_raise_flag(diff, p.changed, &lds_flag);
@@ -246,6 +255,16 @@ static int32_t adgd_cancel_pipeline(dzo_adgd_s *o) {
     return DZO_OK;
 }
 
+// gbuf[i] <- gradient of xbuf[i] when the one-pass step left it unwritten (the objective's own gradient kernel: the
+// same rosen_grad_elem the pass evaluates in registers)
+static int32_t adgd_ensure_g(dzo_adgd_s *o, int i) {
+    if (o->g_valid[i] || !o->xbuf[i]) return DZO_OK;
+    OptCore &c = o->core;
+    DZO_TRY(problem_grad_async(c.problem, c.stream, o->gbuf[i], o->xbuf[i]));
+    o->g_valid[i] = true;
+    return DZO_OK;
+}
+
 // delta_point / delta_gradient as vectors (after steps on the fused pass they exist only as pair cur - pair cur-1)
 static int32_t adgd_materialize_deltas(dzo_adgd_s *o) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
@@ -255,7 +274,10 @@ static int32_t adgd_materialize_deltas(dzo_adgd_s *o) {
     const int prev = (o->cur + 2) % 3;
     // fma(-1, old, new) = new - old, rounded once: the value of :145 / :308
     if (o->dx_lazy) DZO_DISPATCH(c.dtype, launch_axpy_oop<T>(c.stream, c.n, (T *)o->dx_buf, (T)-1, (const T *)o->xbuf[prev], (const T *)o->xbuf[o->cur]));
-    if (o->dg_lazy) DZO_DISPATCH(c.dtype, launch_axpy_oop<T>(c.stream, c.n, (T *)o->dg_buf, (T)-1, (const T *)o->gbuf[prev], (const T *)o->gbuf[o->cur]));
+    if (o->dg_lazy) {
+        DZO_TRY(adgd_ensure_g(o, prev)); DZO_TRY(adgd_ensure_g(o, o->cur));
+        DZO_DISPATCH(c.dtype, launch_axpy_oop<T>(c.stream, c.n, (T *)o->dg_buf, (T)-1, (const T *)o->gbuf[prev], (const T *)o->gbuf[o->cur]));
+    }
     DZO_HIP(hipGetLastError());
     o->dx_lazy = o->dg_lazy = false;
     return DZO_OK;
@@ -266,12 +288,15 @@ static int32_t adgd_settle(dzo_adgd_s *o) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
     DZO_TRY(adgd_cancel_pipeline(o));
+    if (o->cur == 0 && o->twin) DZO_TRY(adgd_ensure_g(o, 0));            // (the live pair is the caller's: its gradient array must be current)
     if (o->cur != 0) {
         DZO_TRY(adgd_materialize_deltas(o));                                 // (pair 0 may be the old point the deltas are formed from)
+        DZO_TRY(adgd_ensure_g(o, o->cur));
         const size_t bytes = (size_t)c.n * dtype_size(c.dtype);
         DZO_HIP(hipMemcpyAsync(o->x_user, c.x, bytes, hipMemcpyDeviceToDevice, c.stream));
         DZO_HIP(hipMemcpyAsync(o->g_user, c.g, bytes, hipMemcpyDeviceToDevice, c.stream));
         o->cur = 0; c.x = o->x_user; c.g = o->g_user;
+        o->g_valid[0] = true;
     }
     adgd_mark_unsettled(o);
     return DZO_OK;
@@ -421,8 +446,9 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
             c.f = f_new;                                                     // :144
             o->norm2[0] = out[5]; o->norm2[1] = out[6];
             o->norms_ready = true;
-            o->cur = (o->cur + 1) % 3;                                       // the trial point and its gradient are the current ones now
-            c.x = o->xbuf[o->cur]; c.g = o->gbuf[o->cur];
+            o->cur = (o->cur + 1) % 3;                                       // the trial point is the current one now; its gradient exists
+            c.x = o->xbuf[o->cur]; c.g = o->gbuf[o->cur];                    // in no array yet (adgd_ensure_g)
+            o->g_valid[o->cur] = false;
             o->dx_lazy = o->dg_lazy = true;                                  // = pair cur - pair cur-1 (:145, :308), formed on demand
             adgd_mark_unsettled(o);
             o->fused_steps += 1;
@@ -494,6 +520,7 @@ static int32_t adgd_step(dzo_adgd_s *o) {
         }
     }
     DZO_TRY(adgd_materialize_deltas(o));                             // (the generic kernels work on the vectors)
+    DZO_TRY(adgd_ensure_g(o, o->cur));                               // (... and on a gradient ARRAY)
     DZO_TRY(core_backtracking_step(c, -next, c.g));                  // :301
     if (c.is_stuck) return DZO_OK;                                   // :302-304
     DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(dt), hipMemcpyDeviceToDevice, c.stream));  // :306
