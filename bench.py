@@ -773,8 +773,7 @@ def main():
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            split = "lbfgs_single_pass_edges" in table       # rows 1 .. rows-2 on the instantiation without index tests, the two edge rows in a one-block launch
-            symbol = {"lbfgs_single_pass": (f"lbfgs_point_pass_kernel<double, 20, false, {opt.pass_register_sets}, {'true' if split else 'false'}>" if opt.ring_layout == 2 and m > 16 else
+            symbol = {"lbfgs_single_pass": (f"lbfgs_point_pass_kernel<double, 20, false, {opt.pass_register_sets}>" if opt.ring_layout == 2 and m > 16 else
                                             "lbfgs_point_pass_kernel" if opt.ring_layout == 2 else "lbfgs_single_pass_kernel"),
                       "lbfgs_gram_pass": "gram_pass_lanes_kernel", "lbfgs_combine": "combine_kernel",
                       "lbfgs_chain_link": "chain_link_kernel"}[dom]
@@ -786,14 +785,6 @@ def main():
             roofline["traffic_source"] = (None if traffic is None else
                                           "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                           "command (separate runs, gfx950 x2 read correction), not measured in this process")
-            if split:
-                eus = 1e3 * table["lbfgs_single_pass_edges"][1] / table["lbfgs_single_pass_edges"][0]
-                both = kernels[dom]["avg_us"] + eus
-                roofline["edge_rows_launch"] = {"hip_event_name": "lbfgs_single_pass_edges", "avg_us": round(eus, 2),
-                                                "note": "the first and the last wave-row of the sweep (index-tested instantiation, one block), "
-                                                        "launched behind the dominant kernel; its partial sums are one more column of the same reduction"}
-                roofline["per_trial_us"] = round(both, 2)
-                roofline["frac_per_trial"] = round(roofline["algorithmic_bytes_per_launch"] / (both * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             if "lbfgs_single_pass" in table:
                 roofline["single_pass"] = {"launches": table["lbfgs_single_pass"][0],
                                            "retry_passes": table.get("lbfgs_single_pass_retry", (0, 0))[0],

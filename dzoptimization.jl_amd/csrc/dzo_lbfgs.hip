@@ -151,7 +151,7 @@ struct dzo_lbfgs_s {
     int32_t *xg_differs = nullptr;  // device flag of that comparison
     // step_direction is not written by the passes (nothing on the point ring reads it: every trial recomputes it in
     // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
-    const void *stage_kern = nullptr, *stage_kern2 = nullptr; size_t stage_bytes = 0; bool stage_small = false;   // dynamic-LDS attribute of the point pass
+    const void *stage_kern = nullptr; size_t stage_bytes = 0; bool stage_small = false;   // dynamic-LDS attribute of the point pass
     bool lazy_d = true;             // DZO_TUNE_LAZY_D
     bool fused_finish = false;      // DZO_TUNE_FUSED_FINISH: reduce + finish of a Gram pass in one launch when the partials are few (measured slower)
     int64_t fused_finish_max = 65536;   // DZO_TUNE_FUSED_FINISH_MAX: ... at most this many partial sums
@@ -902,9 +902,6 @@ template <typename T> struct FusedParams {
     int nt_tiles;                              // point ring: non-temporal stores for the new point's tiles (when they do not fit the Infinity Cache)
     int stage_rows;                            // point ring: rows whose new tiles a wave collects in LDS before it writes them in one burst
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
-    int64_t row_begin, row_end;                // point pass: the wave-rows of this launch (row_end == 0: all)
-    int pstride, pcol0;                        // point pass: stride of the per-block partial sums (0: gridDim.x) and this launch's first column
-    int edge_mode;                             // point pass: one block, wave 0 takes the first row, wave 1 the last
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
 };
 
@@ -1198,11 +1195,10 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // 1 = ONE set and two waves per SIMD (256 registers per wave): a wave's instruction stream is in order, so whenever one
 // of its loads cannot issue (the memory pipeline is backed up -- the steady state of a bandwidth-bound sweep) or an
 // instruction waits for a result, the SIMD idles unless a second wave is there to take the slot.
-// INTERIOR: the launch covers only wave-rows whose 64 vectors all have both neighbours inside the vector (every row but
-// the first and the last): the stencils and the objective terms need no index tests (10 of a stencil's 34 instructions).
-// The host runs the two edge rows in a one-block launch of the index-tested instantiation (p.edge_mode) that writes its
-// partial sums into one more column; two code paths inside ONE kernel made the register allocator spill.
-template <typename T, int K, bool FIRST = false, int SETS = 2, bool INTERIOR = false>
+// The stencils carry no index tests (10 of a stencil's 34 instructions): what rosen_grad_elem decides from the element's
+// index -- only the first and the last element of the vector differ -- is a set of per-element coefficients formed once
+// per wave-row (RosenCoef, dzo_rosen.h), and every row runs the same straight-line code.
+template <typename T, int K, bool FIRST = false, int SETS = 2>
 __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_kernel(FusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
     constexpr int kOwn = kRowOwn, kLead = kRowLead;
@@ -1246,12 +1242,10 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     const T scale = scaled ? (T)p.scale[0] : (T)1;
     const int64_t nvec = p.n / N;
     const int64_t rows = (nvec + kOwn - 1) / kOwn;
-    // rows of this launch: [row_begin, row_end) block-cyclically (all rows when row_end == 0), or, edge_mode, the first
-    // row on wave 0 and the last on wave 1 of its single block; column of this block's partial sums
-    const int64_t row_end = p.edge_mode ? rows : (p.row_end > 0 ? p.row_end : rows);
-    const int64_t stride = p.edge_mode ? rows : (int64_t)gridDim.x * kWaves;
-    const int pstride = p.pstride > 0 ? p.pstride : (int)gridDim.x;
-    const int pcol = p.pcol0 + (int)blockIdx.x;
+    const int64_t row_end = rows;
+    const int64_t stride = (int64_t)gridDim.x * kWaves;     // wave-rows block-cyclically
+    const int pstride = (int)gridDim.x;
+    const int pcol = (int)blockIdx.x;                       // column of this block's partial sums
     // the 5 (K + 1) dot-product partials of a wave-row go through a streaming transposed reduction (TreeSum,
     // dzo_common.h): ~5 VALU instructions per value, and the wave-wide total of value v accumulates in ONE lane
     // (a 9-exchange butterfly + 10 v_readlane + 5 masked adds per pair was half of this kernel's VALU work)
@@ -1335,9 +1329,12 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         char *nrb = rowbase(refill_row);
         constexpr bool kRefill = DZO_PP_REFILL != 0;
         const int64_t v = row * kOwn - kLead + lane;
-        const bool valid = INTERIOR || (v >= 0 && v < nvec);
+        const bool valid = v >= 0 && v < nvec;
         const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
         const int64_t e0 = v * N;
+        RosenCoef<T> rc[N];                                       // rosen_grad_elem's index tests as coefficients, once per row
+#pragma unroll
+        for (int e = 0; e < N; ++e) rc[e] = rosen_coef<T>(e0 + e, p.n);
         if constexpr (kRegrad) {
             // the gradients of this row's K + 1 points, every lane (a halo lane's outer element: see above)
 #pragma unroll
@@ -1348,8 +1345,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
                 for (int e = 0; e < N; ++e) {
                     const T xl = e > 0 ? xv[j][(e + N - 1) % N] : xp;
                     const T xr = e + 1 < N ? xv[j][(e + 1) % N] : xq;
-                    if constexpr (INTERIOR) gv[j][e] = rosen_grad_interior<T>(xl, xv[j][e], xr);
-                    else gv[j][e] = rosen_grad_elem<T>(e0 + e, p.n, xl, xv[j][e], xr);
+                    gv[j][e] = rosen_grad_coef<T>(rc[e], xl, xv[j][e], xr);
                 }
                 __builtin_amdgcn_sched_barrier(0);               // point by point (the temporaries of 21 stencils at once do not fit)
             }
@@ -1394,7 +1390,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
-                if (owner && (INTERIOR || e0 + j + 1 < p.n)) fobj_h += rosen_term<T>(xh[j], xq);
+                if (owner && e0 + j + 1 < p.n) fobj_h += rosen_term<T>(xh[j], xq);
             }
         }
         // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
@@ -1405,11 +1401,10 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         for (int j = 0; j < N; ++j) {
             const T xp = j > 0 ? xn[(j + N - 1) % N] : xprev;
             const T xq = j + 1 < N ? xn[(j + 1) % N] : xnext;
-            if constexpr (INTERIOR) gn[j] = rosen_grad_interior<T>(xp, xn[j], xq);
-            else gn[j] = rosen_grad_elem<T>(e0 + j, p.n, xp, xn[j], xq);
+            gn[j] = rosen_grad_coef<T>(rc[j], xp, xn[j], xq);
             sn[j] = xn[j] - xv[0][j];                               // :145
             yn[j] = gn[j] - gv[0][j];                               // :478-480
-            if (owner && (INTERIOR || e0 + j + 1 < p.n)) fobj += rosen_term<T>(xn[j], xq);
+            if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
         }
         if (!(p.debug_skip & 2)) {
             if constexpr (!FIRST) { if (owner && p.store_d) store16_nt(atw(p.d, boff), q); }
@@ -1483,8 +1478,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     };
     T xA[K + 1][N], gA[K + 1][N];
     T xB[SETS == 2 ? K + 1 : 1][N], gB[SETS == 2 ? K + 1 : 1][N];
-    int64_t row = p.edge_mode ? (wave == 0 ? 0 : (wave == 1 && rows > 1 ? rows - 1 : rows))
-                              : p.row_begin + (int64_t)blockIdx.x * kWaves + wave;
+    int64_t row = (int64_t)blockIdx.x * kWaves + wave;
     auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };   // (past the end: the last row again, unconditionally)
     if constexpr (SETS == 1) {
         issue(in_range(row), xA, gA);
@@ -2625,26 +2619,26 @@ template <typename T> static bool point_one_set(const dzo_lbfgs_s *o) { return o
 
 // the instantiation of the point pass for this optimizer: the smallest K that holds m pairs; one or two register sets
 // (DZO_TUNE_POINT_SETS; see the kernel)
-template <typename T, bool INTERIOR> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(FusedParams<T>) {
+template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(FusedParams<T>) {
     if (point_one_set<T>(o)) {
         if constexpr (sizeof(T) == 8) {
-            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1, INTERIOR>
-                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1, INTERIOR>
-                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1, INTERIOR>
-                   : lbfgs_point_pass_kernel<T, 20, false, 1, INTERIOR>;
+            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
+                   : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1>
+                   : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1>
+                   : lbfgs_point_pass_kernel<T, 20, false, 1>;
         } else {                                             // (fp32, K > 12: the fp64 copies for the dots do not fit 256 registers)
-            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1, INTERIOR> : lbfgs_point_pass_kernel<T, 12, false, 1, INTERIOR>;
+            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1> : lbfgs_point_pass_kernel<T, 12, false, 1>;
         }
     }
-    return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 2, INTERIOR>
-           : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 2, INTERIOR>
-           : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 2, INTERIOR>
-           : lbfgs_point_pass_kernel<T, 20, false, 2, INTERIOR>;
+    return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 2>
+           : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 2>
+           : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 2>
+           : lbfgs_point_pass_kernel<T, 20, false, 2>;
 }
-// first: the first step's kernel; interior: the instantiation without index tests (rows 1 .. rows - 2 only)
-template <typename T> static void (*point_pass_kernel_for(dzo_lbfgs_s *o, bool first, bool interior = false))(FusedParams<T>) {
+// first: the first step's kernel
+template <typename T> static void (*point_pass_kernel_for(dzo_lbfgs_s *o, bool first))(FusedParams<T>) {
     if (first) return lbfgs_point_pass_kernel<T, 8, true>;
-    return interior ? point_pass_kernel_sel<T, true>(o) : point_pass_kernel_sel<T, false>(o);
+    return point_pass_kernel_sel<T>(o);
 }
 
 // step_direction of the last step, on demand: the same pass once more over the view of the ring that step started
@@ -2712,20 +2706,8 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.changed = c.flag();
     fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, k == 0);
-    // rows 1 .. rows - 2 on the instantiation without index tests, the first and the last row in a one-block launch of
-    // the index-tested one, whose partial sums take one more column (DZO_TUNE_POINT_SPLIT=0: one launch for all rows)
-    const bool split = k > 0 && DZO_PP_REGRAD != 0 && rows > 2 && tune("DZO_TUNE_POINT_SPLIT", 1) != 0;
-    void (*kern_in)(FusedParams<T>) = split ? point_pass_kernel_for<T>(o, false, true) : nullptr;
-    int grid = points_grid<T>(o, kern);
-    if (split) {
-        int64_t blocks = (rows - 2 + kWaves - 1) / kWaves;
-        const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern_in);
-        if (blocks > res) blocks = res;
-        if (blocks > (int64_t)o->gram_grid * kWaves - 1) blocks = (int64_t)o->gram_grid * kWaves - 1;
-        if (blocks > kMaxPartialBlocks - 1) blocks = kMaxPartialBlocks - 1;
-        grid = (int)(blocks < 1 ? 1 : blocks);
-    }
-    const int pgrid = split ? grid + 1 : grid;            // columns of per-block partial sums
+    const int grid = points_grid<T>(o, kern);
+    const int pgrid = grid;                               // columns of per-block partial sums
     fp.store_d = o->lazy_d ? 0 : 1;
     {
         // tile-major ring: plain stores while the two streams fit the 256-MiB Infinity Cache (695 vs 735 us at
@@ -2743,13 +2725,12 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     if (fp.stage_rows < 1) fp.stage_rows = 1;
     if (fp.stage_rows > stage_max) fp.stage_rows = stage_max;
     size_t stage_bytes = (size_t)kWaves * fp.stage_rows * stage_tiles * kTileBytes;
-    if (o->stage_kern != (const void *)kern || o->stage_bytes != stage_bytes || o->stage_kern2 != (const void *)kern_in) {   // (once per kernel and size)
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess ||
-            (kern_in && hipFuncSetAttribute((const void *)kern_in, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess)) {
+    if (o->stage_kern != (const void *)kern || o->stage_bytes != stage_bytes) {   // (once per kernel and size)
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes) != hipSuccess) {
             (void)hipGetLastError();                      // a device that does not grant it: stay within the default 64 KiB
             o->stage_small = true;
         }
-        o->stage_kern = (const void *)kern; o->stage_bytes = stage_bytes; o->stage_kern2 = (const void *)kern_in;
+        o->stage_kern = (const void *)kern; o->stage_bytes = stage_bytes;
     }
     if (o->stage_small && fp.stage_rows > 14 / stage_tiles) {
         fp.stage_rows = 14 / stage_tiles;
@@ -2766,19 +2747,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         fp.t = (T)t; fp.t_half = (T)round_to_dtype(c.dtype, t * 0.5);
         if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
         c.flag_armed = false;
-        if (split) {
-            FusedParams<T> fi = fp, fe = fp;
-            fi.row_begin = 1; fi.row_end = rows - 1; fi.pstride = pgrid; fi.pcol0 = 0;
-            fe.edge_mode = 1; fe.pstride = pgrid; fe.pcol0 = grid;
-            {
-                DZO_TIMED(attempt == 0 ? "lbfgs_single_pass" : "lbfgs_single_pass_retry", s);
-                hipLaunchKernelGGL(kern_in, dim3(grid), dim3(kBlock), stage_bytes, s, fi);
-            }
-            {
-                DZO_TIMED("lbfgs_single_pass_edges", s);
-                hipLaunchKernelGGL(kern, dim3(1), dim3(kBlock), stage_bytes, s, fe);
-            }
-        } else {
+        {
             DZO_TIMED(attempt == 0 ? "lbfgs_single_pass" : "lbfgs_single_pass_retry", s);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), stage_bytes, s, fp);
         }

@@ -88,10 +88,8 @@ def main():
             if long_name.startswith("lbfgs_single_pass_kernel<double") and "lbfgs_single_pass" not in out:
                 out["lbfgs_single_pass"] = out[long_name]
             if long_name.startswith("lbfgs_point_pass_kernel<double") and not long_name.startswith("lbfgs_point_pass_kernel<double, 8, true"):
-                # the default optimizer's pass = bench.py's profiling label "lbfgs_single_pass": the interior instantiation
-                # (`..., true>`) when the sweep is split, the whole-range one otherwise; `<double, 8, true, ...>` is the first step's
-                if long_name.endswith(", true>") or "lbfgs_single_pass" not in out:
-                    out["lbfgs_single_pass"] = out[long_name]
+                # the default optimizer's pass = bench.py's profiling label "lbfgs_single_pass" (`<double, 8, true, ...>` is the first step's)
+                out["lbfgs_single_pass"] = out[long_name]
         json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
         print(f"wrote profiles/{tag}_pmc.json")
