@@ -420,13 +420,19 @@ def secondary_workload(args):
         opt = dzo.BFGSOptimizer(prob, None, dzo.DeviceArray.from_host(x0), 1.0)
         for _ in range(args.warmup):
             opt.step()
-        dzo.profile_reset(); dzo.profile_enable(True)
+        dzo.synchronize()
         _barrier(world)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             opt.step()
         dzo.synchronize(); _barrier(world)
         el = sharding.max_over_ranks(time.perf_counter() - t0)
+        # kernel-level HIP events: a second, untimed stretch of the same loop (a step is ten launches of 3-30 us: two event
+        # records per launch put ~10 us between every pair of kernels, 250 against 160 us per step in a rocprofv3 trace)
+        dzo.profile_reset(); dzo.profile_enable(True)
+        for _ in range(min(args.steps, 50)):
+            opt.step()
+        dzo.synchronize()
         dzo.profile_enable(False)
         tab = dzo.profile_table()
         # isolated update + next direction (K8 + K9): 3 n^2 T algorithmic bytes
@@ -476,6 +482,9 @@ def secondary_workload(args):
                     "ms_per_step": round(1e3 * el / args.steps, 4), "dtype": "f64",
                     "config": {"workload": f"dense BFGS on convex quadratic 1/2 x'Ax, n={n}, fp64 (BASELINE configs[1])",
                                "objective_evals_per_step": round(opt.objective_evaluations / max(opt.iteration_count, 1), 2),
+                               "line_searches": ("device-driven (one host wait per step)" if os.environ.get("DZO_TUNE_BFGS_DEV_SEARCH", "1") != "0"
+                                                 else "host-driven rounds"),
+                               "kernel_events": "separate untimed stretch of the same loop (the timed region carries no event records)",
                                "device": info["name"]},
                     "update_plus_direction": {"host_wall_us": round(upd * 1e6, 1), "algorithmic_bytes": 3 * n * n * 8,
                                               "algorithmic_GBps": round(3 * n * n * 8 / upd / 1e9, 1)},
@@ -623,7 +632,7 @@ def _two_pass_leg(dzo, n, m, esize, args):
         opt2.step()
     steps2 = max(20, min(args.steps, 50))
     dzo.synchronize()
-    dzo.profile_reset(); dzo.profile_enable(1)
+    dzo.profile_reset(); dzo.profile_enable(2)          # (every kernel: the two-loop's total needs the reduce and finish kernels too)
     t0 = time.perf_counter()
     for _ in range(steps2):
         opt2.step()
@@ -634,8 +643,8 @@ def _two_pass_leg(dzo, n, m, esize, args):
     k = opt2.history_count
     assert opt2.single_pass_steps == 0
     out = {"steps": steps2, "ms_per_step": round(1e3 * el / steps2, 4), "step_calls_per_s": round(steps2 / el, 2),
-           "note": "same workload, optimizer created with DZO_TUNE_SINGLE_PASS=0 in this process; HIP events on the "
-                   "launching stream; algorithmic bytes: gram (2k+1) n T, combine (2k+1) n T, two-loop (4k+2) n T"}
+           "note": "same workload, optimizer created with DZO_TUNE_SINGLE_PASS=0 in this process; HIP events around EVERY kernel on the "
+                   "launching stream (ms_per_step includes ~8 us per bracket); algorithmic bytes: gram (2k+1) n T, combine (2k+1) n T, two-loop (4k+2) n T"}
 
     def leg(name, nbytes):
         if name not in tab or not tab[name][0]:

@@ -582,6 +582,7 @@ __global__ __launch_bounds__(kBlock) void norm2_pair_kernel(int64_t n, const T *
         __threadfence_system();
     }
 }
+struct BfgsSearchDev;
 }  // namespace dzo
 
 struct dzo_bfgs_s {
@@ -622,6 +623,7 @@ struct dzo_bfgs_s {
     double *ws = nullptr;                       // device: partials + scalars + flags
     double *host = nullptr;                     // pinned
     double *host_dev = nullptr;                 // the same buffer as the device sees it
+    dzo::BfgsSearchDev *dsearch = nullptr;      // device: the two line searches' state machines and their posted requests (bfgs_dev_search)
     double ticket = 0;                          // last result published through host[20] (wait_ticket)
     double *partials() const { return ws; }
     double *scalars() const { return ws + dzo::kMaxPartialBlocks + 8; }       // [overlap, delta]
@@ -1072,6 +1074,400 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
     return DZO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same two searches with the state machines ON THE DEVICE.  A host-driven round costs a round trip
+// (kernel -> pinned word -> host decision -> next launch reaches the GPU: 20-25 us against 36 us of
+// kernels per round at config 2), and a step has three of them: norms -> first round -> second round ->
+// accepted step.  Here the norm kernel's last thread begins both searches and posts the first round's
+// requests in device memory (PhiReqDev), every round's finish kernel feeds the six values to the two
+// machines and posts the next round's requests, and the host enqueues norm + rounds back to back and
+// waits ONCE, for the last enqueued round's summary; a round behind two finished searches does nothing.
+// PhiDev is PhiSearch with buffers as indices: a trial point is its request slot (0: scratch, 1, 2: the
+// two speculative buffers), a gradient its grad_pool entry.  Same arithmetic (doubles rounded to the
+// dtype where the host code rounds), same decisions, same evaluation counts: tested bit for bit against
+// the host-driven search.
+// ---------------------------------------------------------------------------------------------
+struct PhiDev {
+    double f0, t0, step, fa, req_t, x1, f1, x2, f2, xb, fb, t_best, f_best;
+    double spec_t[3];
+    int32_t state, increases, want, req_ref;
+    int32_t spec_ref[3], active[3];
+    int32_t step_grad, g1, g2, best_grad;          // grad_pool entries (-1: none)
+    int32_t step_round, r1, r2, best_round;
+    int32_t ref_copy;                              // slot whose trial point is the new reference point (:136 / :155), -1: none
+};
+struct BfgsSearchDev {
+    PhiDev q[2];
+    PhiReqDev req;
+    double norm[2];
+    int64_t evals;
+};
+enum { kPhiFirst = 0, kPhiDoubling, kPhiShrinking, kPhiQuadratic, kPhiDone, kPhiSequential };
+constexpr int kSumBase = 24;                       // summary of the searches in the pinned host doubles, from here
+constexpr int kHostDoubles = 64;
+
+__device__ __forceinline__ double dev_rt(int32_t dt, double v) { return dt == DZO_F32 ? (double)(float)v : v; }   // round_to_dtype
+
+__device__ __forceinline__ void phi_dev_to_quadratic(int32_t dt, PhiDev &q) {                     // phi_search_to_quadratic
+    q.xb = 0; q.fb = q.f0; q.best_grad = -1; q.best_round = 0;
+    if (q.f1 < q.fb) { q.xb = q.x1; q.fb = q.f1; q.best_grad = q.g1; q.best_round = q.r1; }
+    if (q.f2 < q.fb) { q.xb = q.x2; q.fb = q.f2; q.best_grad = q.g2; q.best_round = q.r2; }
+    const double d1 = dev_rt(dt, q.f0 - q.f1), d2 = dev_rt(dt, q.f2 - q.f1);
+    const double sum = dev_rt(dt, d1 + d2);
+    if (d1 >= 0 && d2 >= 0 && sum > 0) {
+        const double num = dev_rt(dt, dev_rt(dt, d1 + d1) + sum);
+        const double ratio = dev_rt(dt, num / dev_rt(dt, sum + sum));
+        q.req_t = dev_rt(dt, ratio * q.x1);
+        q.want = 1; q.req_ref = 0;
+        q.state = kPhiQuadratic;
+    } else {
+        q.t_best = q.xb; q.f_best = q.fb;
+        q.want = 0;
+        q.state = kPhiDone;
+    }
+}
+
+__device__ __forceinline__ void phi_dev_bracket_done(int32_t dt, PhiDev &q, double x1, double f1, double x2, double f2, int g1 = -1, int r1 = 0,
+                                            int g2 = -1, int r2 = 0) {
+    q.x1 = x1; q.f1 = f1; q.x2 = x2; q.f2 = f2; q.g1 = g1; q.r1 = r1; q.g2 = g2; q.r2 = r2;
+    phi_dev_to_quadratic(dt, q);
+}
+
+__device__ __forceinline__ void phi_dev_begin(int32_t dt, PhiDev &q, double f0, double t0) {      // phi_search_begin
+    q.f0 = f0; q.t0 = t0;
+    q.step = q.fa = q.req_t = q.x1 = q.f1 = q.x2 = q.f2 = q.xb = q.fb = q.t_best = q.f_best = 0;
+    q.increases = 0; q.want = 0; q.req_ref = 0;
+    q.step_grad = q.g1 = q.g2 = q.best_grad = -1;
+    q.step_round = q.r1 = q.r2 = q.best_round = 0;
+    q.ref_copy = -1;
+    q.state = kPhiDone;
+    for (int e = 0; e < 3; ++e) { q.spec_t[e] = 0; q.spec_ref[e] = 0; q.active[e] = 0; }
+    if (!isfinite(f0) || !(t0 > 0) || !isfinite(t0)) { phi_dev_bracket_done(dt, q, 0, f0, 0, f0); return; }
+    q.state = kPhiFirst;
+    q.step = t0;
+    q.req_t = t0; q.want = 1; q.req_ref = 0;
+}
+
+// phi_search_feed; slot: where the consumed evaluation's trial point lies, cur_grad / cur_round: its gradient
+__device__ __forceinline__ void phi_dev_feed(int32_t dt, int32_t max_increases, PhiDev &q, double f, bool changed, bool nonzero, bool equal_ref,
+                                    int slot, int cur_grad, int cur_round, int64_t &evals) {
+    q.want = 0;
+    switch (q.state) {
+    case kPhiFirst:
+        if (!nonzero) { phi_dev_bracket_done(dt, q, 0, q.f0, 0, q.f0); return; }
+        if (!changed) { q.state = kPhiSequential; return; }
+        evals += 1;
+        q.fa = f;
+        q.step_grad = cur_grad; q.step_round = cur_round;
+        if (q.fa <= q.f0) {
+            q.increases = 0;
+            q.ref_copy = slot;
+            q.state = kPhiDoubling;
+            q.req_t = dev_rt(dt, q.step + q.step); q.increases += 1;
+            q.want = 1; q.req_ref = 1;
+        } else {
+            q.state = kPhiShrinking;
+            q.req_t = dev_rt(dt, 0.5 * q.step);
+            q.want = 1; q.req_ref = 0;
+        }
+        return;
+    case kPhiDoubling: {
+        evals += 1;
+        const double dbl = q.req_t, fb = f;
+        bool stop = (max_increases > 0 && q.increases >= max_increases) || !isfinite(fb) || fb > q.fa;
+        if (!stop) stop = equal_ref;
+        if (stop) { phi_dev_bracket_done(dt, q, q.step, q.fa, dbl, fb, q.step_grad, q.step_round, cur_grad, cur_round); return; }
+        q.step = dbl; q.fa = fb; q.step_grad = cur_grad; q.step_round = cur_round;
+        q.ref_copy = slot;
+        q.req_t = dev_rt(dt, q.step + q.step); q.increases += 1;
+        q.want = 1; q.req_ref = 1;
+        return;
+    }
+    case kPhiShrinking: {
+        evals += 1;
+        const double hs = q.req_t, fb = f;
+        if (fb <= q.f0) { phi_dev_bracket_done(dt, q, hs, fb, q.step, q.fa, cur_grad, cur_round, q.step_grad, q.step_round); return; }
+        if (hs == 0.0) { phi_dev_bracket_done(dt, q, 0, q.f0, 0, q.f0); return; }
+        q.step = hs; q.fa = fb; q.step_grad = cur_grad; q.step_round = cur_round;
+        q.req_t = dev_rt(dt, 0.5 * q.step);
+        q.want = 1; q.req_ref = 0;
+        return;
+    }
+    case kPhiQuadratic:
+        evals += 1;
+        if (f < q.fb) { q.xb = q.req_t; q.fb = f; q.best_grad = cur_grad; q.best_round = cur_round; }
+        q.t_best = q.xb; q.f_best = q.fb;
+        q.state = kPhiDone;
+        return;
+    default:
+        return;
+    }
+}
+
+// the requests of the next launch (the loop body of bfgs_dual_search that fills req[])
+__device__ __forceinline__ void phi_dev_post(int32_t dt, double sign, PhiDev &q, PhiReqDev &R, int side) {
+    for (int e = 0; e < 3; ++e) {
+        q.spec_t[e] = 0; q.spec_ref[e] = 0; q.active[e] = 0;
+        R.ts[side][e] = 0; R.active[side][e] = 0; R.ref_req[side][e] = -1; R.use_ref[side][e] = 0;
+    }
+    if (!q.want) return;
+    auto post = [&](int slot, double t, int use_ref, int ref_req, int is_ref) {
+        R.ts[side][slot] = dev_rt(dt, sign * t);
+        R.active[side][slot] = 1; R.use_ref[side][slot] = use_ref; R.ref_req[side][slot] = ref_req;
+        q.spec_t[slot] = t; q.spec_ref[slot] = is_ref; q.active[slot] = 1;
+    };
+    post(0, q.req_t, q.req_ref, -1, q.req_ref);
+    if (q.state == kPhiFirst) {
+        post(1, dev_rt(dt, q.req_t + q.req_t), 0, 0, 1);
+        post(2, dev_rt(dt, 0.5 * q.req_t), 0, -1, 0);
+    } else if (q.state == kPhiDoubling) {
+        post(1, dev_rt(dt, q.req_t + q.req_t), 0, 0, 1);
+    } else if (q.state == kPhiShrinking) {
+        post(1, dev_rt(dt, 0.5 * q.req_t), 0, -1, 0);
+    }
+}
+
+// what the host needs after its one wait: 5 doubles per search + the evaluation count
+//   [0] want | state << 8 | (best_grad + 1) << 16 | best_round << 32 (as an integer-valued double: < 2^53)
+//   [1] t_best  [2] f_best  [3] t0  [4] the direction's norm
+constexpr int kSumStride = 5;
+__device__ __forceinline__ void phi_dev_summary(const PhiDev &q, double norm, double *o) {
+    const int64_t packed = (int64_t)q.want | ((int64_t)q.state << 8) | ((int64_t)(q.best_grad + 1) << 16) | ((int64_t)q.best_round << 32);
+    o[0] = (double)packed; o[1] = q.t_best; o[2] = q.f_best; o[3] = q.t0; o[4] = norm;
+}
+
+// BfgsSearchDev lives in device memory between kernels; inside a kernel the whole block moves it to LDS (one memory
+// latency instead of one per field: a single thread walking the structure in device memory took 13-20 us per round)
+// and thread 0 works on register copies.
+constexpr int kSearchWords = (int)(sizeof(BfgsSearchDev) / 4);
+static_assert(sizeof(BfgsSearchDev) % 4 == 0, "word copies");
+__device__ __forceinline__ void search_to_lds(const BfgsSearchDev *S, BfgsSearchDev *L) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(S);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(L);
+    for (int i = threadIdx.x; i < kSearchWords; i += kBlock) dst[i] = src[i];
+}
+__device__ __forceinline__ void search_from_lds(BfgsSearchDev *S, const BfgsSearchDev *L) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(L);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(S);
+    for (int i = threadIdx.x; i < kSearchWords; i += kBlock) dst[i] = src[i];
+}
+
+// :921 and :928 (the two norms) and the begin of both searches
+template <typename T>
+__global__ __launch_bounds__(kBlock) void norm2_pair_begin_kernel(int64_t n, const T *__restrict__ a, const T *__restrict__ b,
+                                                                  BfgsSearchDev *__restrict__ S, double f0, double step_length,
+                                                                  int32_t dt, double sign) {
+    __shared__ double lds[kWaves];
+    __shared__ BfgsSearchDev L;
+    double sa = 0, sb = 0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {          // (norm2_pair_kernel's sums)
+        const double va = (double)a[i], vb = (double)b[i];
+        sa = __builtin_fma(va, va, sa);
+        sb = __builtin_fma(vb, vb, sb);
+    }
+    const double ra = block_sum(sa, lds);
+    const double rb = block_sum(sb, lds);
+    if (threadIdx.x == 0) {
+        const double na = dt == DZO_F32 ? (double)sqrtf((float)ra) : sqrt(ra);
+        const double nb = dt == DZO_F32 ? (double)sqrtf((float)rb) : sqrt(rb);
+        phi_dev_begin(dt, L.q[0], f0, dev_rt(dt, step_length / na));      // (in LDS: private copies of the structures end up in scratch memory)
+        phi_dev_begin(dt, L.q[1], f0, dev_rt(dt, step_length / nb));
+        phi_dev_post(dt, sign, L.q[0], L.req, 0);
+        phi_dev_post(dt, sign, L.q[1], L.req, 1);
+        L.norm[0] = na; L.norm[1] = nb;
+        L.evals = 0;
+    }
+    __syncthreads();
+    search_from_lds(S, &L);
+}
+
+template <typename V> __device__ __forceinline__ V sel3(int i, V a, V b, V c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// finish_phi6_kernel + the host loop body of bfgs_dual_search behind it: the round's six sums, both machines fed --
+// the primary request, then the speculative ones that match what the machine asks for next --, the next round's
+// requests posted, the summary and the ticket published; then the whole block copies the new reference points.
+// pts[r][slot]: the trial-point buffers, refp[r]: the reference points.
+struct PhiBuffers { void *pts[2][3]; void *refp[2]; };
+__global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const double *__restrict__ partials, int64_t count, double scale,
+                                                                     double *__restrict__ out, int32_t *__restrict__ flags, double ticket,
+                                                                     BfgsSearchDev *__restrict__ S, int round, int32_t dt,
+                                                                     int32_t max_increases, double sign, PhiBuffers bufs, int64_t vec16,
+                                                                     int publish) {
+    __shared__ double lds6[6 * kWaves];
+    __shared__ BfgsSearchDev L;
+    __shared__ int32_t hf_s[18];
+    __shared__ int copy_s[2];
+    search_to_lds(S, &L);
+    if (threadIdx.x < 18) { hf_s[threadIdx.x] = flags[threadIdx.x]; flags[threadIdx.x] = 0; }    // (re-armed for the next round)
+    __syncthreads();
+    const bool live = L.q[0].want || L.q[1].want;               // (uniform; nothing was evaluated otherwise)
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if (live) {
+        int64_t i = threadIdx.x;
+        for (; i + 7 * kBlock < count; i += 8 * kBlock) {       // (finish_phi6_kernel's sums, same order)
+            double t[8][6];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) t[u][r] = partials[(int64_t)r * count + i + (int64_t)u * kBlock];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) v[r] += t[u][r];
+        }
+        for (; i < count; i += kBlock) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) v[r] += partials[(int64_t)r * count + i];
+        }
+    }
+    double sres[6];
+    block_sum_multi<6>(v, lds6, sres);
+    if (threadIdx.x == 0) {
+        PhiDev *q = L.q;                                         // (worked on in LDS: private copies end up in scratch memory, 4x slower)
+        PhiReqDev &R = L.req;
+        int64_t evals = L.evals;
+        int copies[2] = {-1, -1};
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                PhiDev &sm = q[r];
+                sm.ref_copy = -1;
+                if (!sm.active[0]) continue;
+                const double f3[3] = {dev_rt(dt, scale * sres[r * 3 + 0]), dev_rt(dt, scale * sres[r * 3 + 1]), dev_rt(dt, scale * sres[r * 3 + 2])};
+                int used = 0, slot = 0;
+                for (int turn = 0; turn < 3; ++turn) {           // (at most the three requests of this direction)
+                    used |= 1 << slot;
+                    const int changed = sel3(slot, hf_s[r * 9 + 0], hf_s[r * 9 + 3], hf_s[r * 9 + 6]);
+                    const int nonzero = sel3(slot, hf_s[r * 9 + 1], hf_s[r * 9 + 4], hf_s[r * 9 + 7]);
+                    const int differs = sel3(slot, hf_s[r * 9 + 2], hf_s[r * 9 + 5], hf_s[r * 9 + 8]);
+                    phi_dev_feed(dt, max_increases, sm, sel3(slot, f3[0], f3[1], f3[2]), changed != 0, nonzero != 0, differs == 0,
+                                 slot, (round % 4) * 6 + r * 3 + slot, round, evals);
+                    if (!sm.want) break;
+                    int next = -1;
+#pragma unroll
+                    for (int e = 1; e < 3; ++e)
+                        if (sm.active[e] && !(used & (1 << e)) && sm.spec_t[e] == sm.req_t && sm.spec_ref[e] == sm.req_ref) next = e;
+                    if (next < 0) break;
+                    slot = next;
+                }
+                copies[r] = sm.ref_copy;
+            }
+            phi_dev_post(dt, sign, q[0], R, 0);
+            phi_dev_post(dt, sign, q[1], R, 1);
+            L.evals = evals;
+        }
+        copy_s[0] = copies[0]; copy_s[1] = copies[1];
+        if (publish) {                                           // (the host waits for the last enqueued round only: a system-scope
+            phi_dev_summary(q[0], L.norm[0], out + kSumBase);    // fence pair over PCIe costs more than the rest of this kernel)
+            phi_dev_summary(q[1], L.norm[1], out + kSumBase + kSumStride);
+            out[kSumBase + 2 * kSumStride] = (double)evals;
+            __threadfence_system();
+            out[20] = ticket;
+            __threadfence_system();
+        }
+    }
+    __syncthreads();
+    if (live) search_from_lds(S, &L);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c = copy_s[r];
+        if (c < 0) continue;
+        // (the vectors are allocated in multiples of 64 elements: whole 16-byte words; eight loads in flight per thread)
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(c == 0 ? bufs.pts[r][0] : (c == 1 ? bufs.pts[r][1] : bufs.pts[r][2]));
+        uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(bufs.refp[r]);
+        int64_t i = threadIdx.x;
+        for (; i + 7 * kBlock < vec16; i += 8 * kBlock) {
+            uint4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[i + (int64_t)u * kBlock];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[i + (int64_t)u * kBlock] = t[u];
+        }
+        for (; i < vec16; i += kBlock) dst[i] = src[i];
+    }
+}
+
+static int dev_search_rounds() {
+    const int r = getenv("DZO_TUNE_BFGS_DEV_ROUNDS") ? atoi(getenv("DZO_TUNE_BFGS_DEV_ROUNDS")) : 2;
+    return r < 1 ? 1 : (r > 8 ? 8 : r);
+}
+
+// norms + both searches, one host wait.  *done = false: not applicable (nothing was enqueued).
+static int32_t bfgs_dev_search(dzo_bfgs_s *o, double step_length, double *grad_norm, double *bfgs_norm_v, double *t_a, double *f_a,
+                               double *t_b, double *f_b, bool *done) {
+    const bool enabled = getenv("DZO_TUNE_BFGS_DEV_SEARCH") ? atoi(getenv("DZO_TUNE_BFGS_DEV_SEARCH")) != 0 : true;      // (read per call: tests switch it)
+    const bool dual = getenv("DZO_TUNE_BFGS_DUAL_SEARCH") ? atoi(getenv("DZO_TUNE_BFGS_DUAL_SEARCH")) != 0 : true;
+    *done = false;
+    if (!enabled || !dual || !o->dsearch || o->objective || o->constraint || !o->problem || o->problem->kind != DZO_PROBLEM_QUADRATIC ||
+        o->problem->l2 != 0.0 || o->problem->cons_on || o->n > 65536 || o->problem->scratch_doubles < 6 * o->n)
+        return DZO_OK;
+    const int32_t dt = o->dtype;
+    const size_t es = dtype_size(dt);
+    const size_t vbytes = (size_t)((o->n + 63) / 64 * 64) * es;
+    hipStream_t s = o->stream;
+    const void *dirs[2] = {o->g, o->d};
+    {
+        DZO_TIMED("bfgs_norm_pair", s);
+        DZO_DISPATCH(dt, hipLaunchKernelGGL(norm2_pair_begin_kernel<T>, dim3(1), dim3(kBlock), 0, s, o->n, (const T *)o->g, (const T *)o->d,
+                                            o->dsearch, o->f, step_length, dt, o->sign));
+    }
+    PhiBuffers bufs;
+    bufs.pts[0][0] = o->scratch; bufs.pts[0][1] = o->spec_buf[0]; bufs.pts[0][2] = o->spec_buf[1]; bufs.refp[0] = o->ref_point;
+    bufs.pts[1][0] = o->scratch2; bufs.pts[1][1] = o->spec_buf[2]; bufs.pts[1][2] = o->spec_buf[3]; bufs.refp[1] = o->ref_point2;
+    int round = 0;
+    auto enqueue_round = [&](bool publish) -> int32_t {
+        round += 1;
+        PhiDirHost req[2];
+        for (int r = 0; r < 2; ++r) {
+            req[r].dir = dirs[r];
+            for (int e = 0; e < 3; ++e) {
+                req[r].point_out[e] = bufs.pts[r][e];
+                req[r].grad_out[e] = (char *)o->grad_pool + (size_t)((round % 4) * 6 + r * 3 + e) * vbytes;
+                req[r].active[e] = true;                         // (the kernel takes these three from the device's requests)
+            }
+            req[r].ref[0] = bufs.refp[r];
+        }
+        o->ticket += 1.0;
+        DZO_REQUIRE(problem_phi6_async(o->problem, s, o->x, req, o->phi_flags(), o->host_dev, o->ticket, &o->dsearch->req), DZO_ERR_HIP,
+                    "the two-direction objective kernel refused a launch it had accepted");
+        {
+            DZO_TIMED("bfgs_search_advance", s);
+            hipLaunchKernelGGL(finish_phi6_advance_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)o->problem->scratch, o->n, 0.5,
+                               o->host_dev, o->phi_flags(), o->ticket, o->dsearch, round, dt, o->max_increases, o->sign, bufs,
+                               (int64_t)(vbytes / 16), publish ? 1 : 0);
+        }
+        DZO_HIP(hipGetLastError());
+        return DZO_OK;
+    };
+    const double *sum = o->host + kSumBase;
+    for (int batch = dev_search_rounds();; batch = 1) {
+        for (int i = 0; i < batch; ++i) DZO_TRY(enqueue_round(i + 1 == batch));
+        DZO_TRY(wait_ticket(s, o->host + 20, o->ticket));
+        if ((((int64_t)sum[0]) & 0xFF) == 0 && (((int64_t)sum[kSumStride]) & 0xFF) == 0) break;   // neither search wants another evaluation
+    }
+    *grad_norm = sum[4]; *bfgs_norm_v = sum[kSumStride + 4];
+    o->evals += (int64_t)sum[2 * kSumStride];
+    o->best_grad[0] = o->best_grad[1] = nullptr;
+    double tt[2], ff[2];
+    for (int r = 0; r < 2; ++r) {
+        const double *q = sum + kSumStride * r;
+        const int64_t packed = (int64_t)q[0];
+        const int state = (int)((packed >> 8) & 0xFF);
+        const double t0 = q[3];
+        if (state == kPhiSequential) {                           // the rare tiny-step path (:91-101): the sequential code
+            DZO_TRY(bfgs_quadratic_search(o, dirs[r], o->f, t0, &tt[r], &ff[r]));
+            continue;
+        }
+        tt[r] = q[1]; ff[r] = q[2];
+        const int bg = (int)((packed >> 16) & 0xFFFF) - 1, br = (int)(packed >> 32);
+        if (state == kPhiDone && tt[r] != 0.0 && bg >= 0 && round - br < 4)
+            o->best_grad[r] = (char *)o->grad_pool + (size_t)bg * vbytes;
+    }
+    *t_a = tt[0]; *f_a = ff[0]; *t_b = tt[1]; *f_b = ff[1];
+    *done = true;
+    return DZO_OK;
+}
+
 // make the stored matrix whole again (upper <- lower) before anything reads it as a full matrix
 static int32_t bfgs_mirror(dzo_bfgs_s *o) {
     if (!o->upper_stale) return DZO_OK;
@@ -1135,10 +1531,11 @@ static int32_t bfgs_step(dzo_bfgs_s *o) {
     const size_t bytes = (size_t)o->n * dtype_size(dt);
     const double step_length = o->last_step_length;              // :918
     double grad_norm, bfgs_norm_v;
-    DZO_TRY(bfgs_norm_pair(o, o->g, o->d, &grad_norm, &bfgs_norm_v));   // :921, :928
     double t_g, f_g, t_b, f_b;
     bool dual = false;
-    DZO_TRY(bfgs_dual_search(o, o->g, round_to_dtype(dt, step_length / grad_norm), o->d, round_to_dtype(dt, step_length / bfgs_norm_v),
+    DZO_TRY(bfgs_dev_search(o, step_length, &grad_norm, &bfgs_norm_v, &t_g, &f_g, &t_b, &f_b, &dual));   // :921-932 with one host wait
+    if (!dual) DZO_TRY(bfgs_norm_pair(o, o->g, o->d, &grad_norm, &bfgs_norm_v));   // :921, :928
+    if (!dual) DZO_TRY(bfgs_dual_search(o, o->g, round_to_dtype(dt, step_length / grad_norm), o->d, round_to_dtype(dt, step_length / bfgs_norm_v),
                              &t_g, &f_g, &t_b, &f_b, &dual));    // :922-925 and :929-932 side by side
     if (!dual) {
         o->best_grad[0] = o->best_grad[1] = nullptr;
@@ -1222,9 +1619,11 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
     DZO_HIP(hipMalloc((void **)&o->upd_part, sizeof(double) * (size_t)(2 * ((o->n + kColsPerBlock - 1) / kColsPerBlock) + 8)));   // (>= 2 ceil(n / kTriRI) too)
     DZO_HIP(hipMalloc((void **)&o->ws, sizeof(double) * (kMaxPartialBlocks + 48)));
     DZO_HIP(hipMemset(o->ws, 0, sizeof(double) * (kMaxPartialBlocks + 48)));
-    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * 32, hipHostMallocMapped | hipHostMallocCoherent));
+    DZO_HIP(hipHostMalloc((void **)&o->host, sizeof(double) * kHostDoubles, hipHostMallocMapped | hipHostMallocCoherent));
     DZO_HIP(hipHostGetDevicePointer((void **)&o->host_dev, o->host, 0));
-    for (int i = 0; i < 32; ++i) o->host[i] = 0;
+    for (int i = 0; i < kHostDoubles; ++i) o->host[i] = 0;
+    DZO_HIP(hipMalloc((void **)&o->dsearch, sizeof(BfgsSearchDev)));
+    DZO_HIP(hipMemset(o->dsearch, 0, sizeof(BfgsSearchDev)));
     DZO_HIP(hipDeviceSynchronize());
     return DZO_OK;
 }
@@ -1424,6 +1823,7 @@ int32_t dzo_bfgs_destroy(dzo_bfgs_t o) {
                     o->spec_buf[3], o->grad_pool, o->H, o->ws, o->upd_part, o->tri_rowpart, o->tri_colpart, o->tri_dummy};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->host) (void)hipHostFree(o->host);
+    if (o->dsearch) (void)hipFree(o->dsearch);
     problem_view_destroy(o->problem);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     delete o;

@@ -55,7 +55,17 @@ struct PhiDirHost {
     void *grad_out[3] = {nullptr, nullptr, nullptr};
     bool active[3] = {false, false, false};
 };
-bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev, double ticket);   // result_dev[20] <- ticket, last
+// the requests of one launch as the DEVICE posts them (device-driven line searches of the dense BFGS step): step sizes
+// (signed, already rounded to the dtype), which of the six run, and what each one's :150 test compares with
+struct PhiReqDev {
+    double ts[2][3];
+    int32_t active[2][3];
+    int32_t ref_req[2][3];      // the request of the same direction in this launch to compare with, or -1
+    int32_t use_ref[2][3];      // 0: ignore PhiDirHost::ref of this request
+};
+// dreq: take step sizes / activity / references from there (the pointers still from req) and leave the finish to the caller
+bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev, double ticket,
+                        const PhiReqDev *dreq = nullptr);   // result_dev[20] <- ticket, last
 // Enqueue g = grad f(x) on `s`.
 int32_t problem_grad_async(dzo_problem_s *p, hipStream_t s, void *g, const void *x);
 // Fused accept + gradient + delta_gradient + rho partials (chained Rosenbrock, aligned operands).

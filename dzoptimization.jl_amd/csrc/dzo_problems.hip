@@ -367,9 +367,24 @@ template <typename T> struct PhiDir {
 template <typename T>
 __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
                                                                 PhiDir<T> a, PhiDir<T> b,
-                                                                double *__restrict__ partials, int32_t *__restrict__ flags) {
+                                                                double *__restrict__ partials, int32_t *__restrict__ flags,
+                                                                const PhiReqDev *__restrict__ dreq) {
     constexpr int N = Vec16<T>::N;
     __shared__ double lds6[6 * kWaves];
+    if (dreq) {
+        // device-driven search (dzo_bfgs.hip): which requests run, their step sizes and their :150 references were
+        // posted by the previous round's finish kernel; a round behind a finished search does nothing
+        int any = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            a.ts[r] = (T)dreq->ts[0][r]; a.active[r] = dreq->active[0][r]; a.ref_req[r] = dreq->ref_req[0][r];
+            b.ts[r] = (T)dreq->ts[1][r]; b.active[r] = dreq->active[1][r]; b.ref_req[r] = dreq->ref_req[1][r];
+            if (!dreq->use_ref[0][r]) a.ref[r] = nullptr;
+            if (!dreq->use_ref[1][r]) b.ref[r] = nullptr;
+            any |= a.active[r] | b.active[r];
+        }
+        if (!any) return;
+    }
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
         const T *col = A + j * n;
         double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -780,7 +795,8 @@ bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const voi
 // Up to three step sizes along each of two directions in one pass over A.  req[side] describes the
 // requests (inactive ones are skipped); values and flags land in result_dev (>= 17 doubles, may be
 // pinned host memory): values [0..5], int32 flags from [8].  `flags`: 18 zeroed int32 on the device.
-bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev, double ticket) {
+bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev, double ticket,
+                        const PhiReqDev *dreq) {
     if (!p || p->kind != DZO_PROBLEM_QUADRATIC || p->l2 != 0.0 || p->cons_on) return false;
     const int64_t n = p->n;
     if (p->scratch_doubles < 6 * n) return false;
@@ -801,9 +817,10 @@ bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const Ph
             }
         }
         hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
-                           p->scratch, flags);
+                           p->scratch, flags, dreq);
     };
     if (p->dtype == DZO_F64) launch(double{}); else launch(float{});
+    if (dreq) return true;                                       // (the caller's finish kernel sums, advances the searches and posts the next requests)
     hipLaunchKernelGGL(finish_phi6_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)p->scratch, n, 0.5, result_dev, flags, ticket);
     return true;
 }

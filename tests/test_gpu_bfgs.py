@@ -349,6 +349,37 @@ def test_side_by_side_line_searches_equal_the_sequential_ones(n, monkeypatch):
             assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
 
 
+@pytest.mark.parametrize("n,dtype,step0,max_inc", [(16, np.float64, 1.0, 0), (200, np.float64, 1.0, 0), (513, np.float64, 1.0, 0),
+                                                   (200, np.float32, 1.0, 0), (64, np.float64, 1e4, 0), (64, np.float64, 1e-7, 0),
+                                                   (200, np.float64, 1e-7, 3), (130, np.float32, 50.0, 2), (4096, np.float64, 1.0, 0)])
+def test_device_driven_line_searches_equal_the_host_driven_ones(n, dtype, step0, max_inc, monkeypatch):
+    """bfgs_dev_search: the two searches' state machines run on the device (norm kernel begins them, every round's
+    finish kernel feeds them and posts the next requests), the host waits once per step.  A re-scheduling again:
+    same points, values, step types and lengths, evaluation counts -- whatever number of rounds is enqueued ahead."""
+    A = orc.quadratic_matrix(n).astype(dtype)
+    x0 = (orc.pcg_fill(n, 4) - 0.5).astype(dtype)
+    runs = []
+    for dev, rounds in (("0", "2"), ("1", "2"), ("1", "1"), ("1", "4")):
+        monkeypatch.setenv("DZO_TUNE_BFGS_DEV_SEARCH", dev)
+        monkeypatch.setenv("DZO_TUNE_BFGS_DEV_ROUNDS", rounds)
+        opt = dzo.BFGSOptimizer(dzo.Problem(dzo.QUADRATIC, n, A=A, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
+        if max_inc:
+            opt.set_max_increases(max_inc)
+        rows = []
+        for _ in range(12 if n == 4096 else 40):
+            opt.step()
+            rows.append((opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value, opt.last_step_type,
+                         opt.last_step_length, opt.objective_evaluations, opt.iteration_count))
+            if opt.has_terminated:
+                break
+        runs.append(rows)
+    assert len(runs[0]) >= 3
+    for other in runs[1:]:
+        assert len(other) == len(runs[0])
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n", [8, 124, 126, 248, 4100, 100_000])
 def test_adgd_fused_step_equals_separate_kernels(n, dtype, monkeypatch):
