@@ -902,6 +902,7 @@ template <typename T> struct FusedParams {
     int nt_tiles;                              // point ring: non-temporal stores for the new point's tiles (when they do not fit the Infinity Cache)
     int stage_rows;                            // point ring: rows whose new tiles a wave collects in LDS before it writes them in one burst
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
+    int prio;                                  // point pass: per-phase issue priority (two waves per SIMD)
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
 };
 
@@ -1195,6 +1196,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // 1 = ONE set and two waves per SIMD (256 registers per wave): a wave's instruction stream is in order, so whenever one
 // of its loads cannot issue (the memory pipeline is backed up -- the steady state of a bandwidth-bound sweep) or an
 // instruction waits for a result, the SIMD idles unless a second wave is there to take the slot.
+__device__ unsigned long long g_dev_wave_times[1024 * 4 * 2];        // dev instrumentation (DZO_TUNE_SP_DEBUG & 1024): start / end clock of every wave of the pass
 // The stencils carry no index tests (10 of a stencil's 34 instructions): what rosen_grad_elem decides from the element's
 // index -- only the first and the last element of the vector differ -- is a set of per-element coefficients formed once
 // per wave-row (RosenCoef, dzo_rosen.h), and every row runs the same straight-line code.
@@ -1332,6 +1334,15 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         const bool valid = v >= 0 && v < nvec;
         const bool owner = valid && lane >= kLead && lane < kLead + kOwn;
         const int64_t e0 = v * N;
+        // dev experiment (priority between the two waves of a SIMD; the older wave otherwise always wins the vector issue)
+        // Issue priority between the two waves of a SIMD (SETS == 1).  The SIMD picks by priority, then AGE: left alone, the
+        // wave of the block that arrived first wins every contested slot, runs at twice its partner's pace, and finishes
+        // its rows 100 us early -- per-wave clocks: blocks 0..255 done at 237 us, blocks 256..511 at 335 us, the last
+        // third of the sweep running at one wave per SIMD.  So a wave is low while it forms the direction (it has
+        // nothing in flight then anyway) and high in the dot-product phase, where the next row's tiles are requested
+        // (337 -> 322 us), and the younger half of the grid one level higher still there (-> 316 us, both halves
+        // done within 1 us of each other).  Scheduling only: rows, sums and results are what they were.
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
         RosenCoef<T> rc[N];                                       // rosen_grad_elem's index tests as coefficients, once per row
 #pragma unroll
         for (int e = 0; e < N; ++e) rc[e] = rosen_coef<T>(e0 + e, p.n);
@@ -1424,6 +1435,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         }
         // ---- dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1); value 5 j + c of the row
         const bool want_dots = !(p.debug_skip & 1);
+        if (p.prio) { if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         if (want_dots) {
             double t5[kGramValues] = {0, 0, 0, 0, 0};
 #pragma unroll
@@ -1482,6 +1494,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };   // (past the end: the last row again, unconditionally)
     if constexpr (SETS == 1) {
         issue(in_range(row), xA, gA);
+        if ((p.debug_skip & 1024) && blockIdx.x < 1024) { if (lane == 0) g_dev_wave_times[(blockIdx.x * kWaves + wave) * 2] = wall_clock64(); }
         while (row < row_end) {
             compute(row, byte_offset(row), xA, gA, in_range(row + stride));
             if (staged >= stage_rows) flush_stage();
@@ -1541,6 +1554,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     const double fo = block_sum(fobj, lds);
     const double fh = block_sum(fobj_h, lds);
     if (threadIdx.x == 0) { p.obj_partials[pcol] = fo; p.obj_partials[pstride + pcol] = fh; }
+    if ((p.debug_skip & 1024) && blockIdx.x < 1024) { if (lane == 0) g_dev_wave_times[(blockIdx.x * kWaves + wave) * 2 + 1] = wall_clock64(); }
 }
 
 // ring streams elementwise, tile positions included (the halo copies transform like their originals):
@@ -2719,6 +2733,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     // of a CU is this one block's)
     // (two blocks per CU with one register set per wave: half the LDS each)
     const bool one_set = point_one_set<T>(o) && k > 0;
+    fp.prio = one_set ? (tune("DZO_TUNE_POINT_PRIO", 1) != 0 ? 1 : 0) : 0;   // (two waves per SIMD only; see the kernel)
     const int stage_tiles = (k == 0 || DZO_PP_REGRAD == 0) ? 2 : 1;      // tiles staged per row: the point, and its gradient where the kernel writes it
     const int stage_max = (one_set ? 72 : 144) / (4 * stage_tiles);        // KiB of LDS per block / (waves x KiB per staged row)
     fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", 16);
@@ -3447,3 +3462,12 @@ int32_t dzo_lbfgs_stream(dzo_lbfgs_t o, void **hip_stream) {
 }
 
 }  // extern "C"
+
+// dev instrumentation (tools/wave_times.py; not part of include/dzo.h): the clocks the point pass left behind when run with
+// DZO_TUNE_SP_DEBUG=1024 -- 100-MHz ticks, [2 w] = start and [2 w + 1] = end of wave w = 4 block + wave-in-block
+extern "C" int32_t dzo_debug_wave_times(unsigned long long *out_host, int32_t count) {
+    DZO_HIP(hipDeviceSynchronize());
+    DZO_REQUIRE(out_host && count > 0 && count <= 1024 * 4 * 2, DZO_ERR_INVALID, "count out of range");
+    DZO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(dzo::g_dev_wave_times), sizeof(unsigned long long) * (size_t)count));
+    return DZO_OK;
+}
