@@ -1,7 +1,7 @@
 """Dev tool (GPU box): start / end clock of every wave of the last point pass (DZO_TUNE_SP_DEBUG=1024 build hook)."""
 import ctypes, os, sys
 import numpy as np
-os.environ["DZO_TUNE_SP_DEBUG"] = str(1024 + 2048 * int(os.environ.get("PRIO_MASK", "0")))
+os.environ["DZO_TUNE_SP_DEBUG"] = "1024"        # (DZO_TUNE_POINT_PRIO=0 in the environment: the pass without its issue priorities)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dzo_loader import dzo
 from bench import rosenbrock_chain_x0
