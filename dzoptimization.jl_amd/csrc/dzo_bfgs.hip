@@ -1094,7 +1094,7 @@ struct PhiDev {
     int32_t spec_ref[3], active[3];
     int32_t step_grad, g1, g2, best_grad;          // grad_pool entries (-1: none)
     int32_t step_round, r1, r2, best_round;
-    int32_t ref_copy;                              // slot whose trial point is the new reference point (:136 / :155), -1: none
+    int32_t ref_buf;                               // the trial-point buffer (= request slot) that holds the reference point (:136 / :155)
 };
 struct BfgsSearchDev {
     PhiDev q[2];
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void phi_dev_begin(int32_t dt, PhiDev &q, double f0, 
     q.increases = 0; q.want = 0; q.req_ref = 0;
     q.step_grad = q.g1 = q.g2 = q.best_grad = -1;
     q.step_round = q.r1 = q.r2 = q.best_round = 0;
-    q.ref_copy = -1;
+    q.ref_buf = 0;
     q.state = kPhiDone;
     for (int e = 0; e < 3; ++e) { q.spec_t[e] = 0; q.spec_ref[e] = 0; q.active[e] = 0; }
     if (!isfinite(f0) || !(t0 > 0) || !isfinite(t0)) { phi_dev_bracket_done(dt, q, 0, f0, 0, f0); return; }
@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void phi_dev_feed(int32_t dt, int32_t max_increases, 
         q.step_grad = cur_grad; q.step_round = cur_round;
         if (q.fa <= q.f0) {
             q.increases = 0;
-            q.ref_copy = slot;
+            q.ref_buf = slot;
             q.state = kPhiDoubling;
             q.req_t = dev_rt(dt, q.step + q.step); q.increases += 1;
             q.want = 1; q.req_ref = 1;
@@ -1178,7 +1178,7 @@ __device__ __forceinline__ void phi_dev_feed(int32_t dt, int32_t max_increases, 
         if (!stop) stop = equal_ref;
         if (stop) { phi_dev_bracket_done(dt, q, q.step, q.fa, dbl, fb, q.step_grad, q.step_round, cur_grad, cur_round); return; }
         q.step = dbl; q.fa = fb; q.step_grad = cur_grad; q.step_round = cur_round;
-        q.ref_copy = slot;
+        q.ref_buf = slot;
         q.req_t = dev_rt(dt, q.step + q.step); q.increases += 1;
         q.want = 1; q.req_ref = 1;
         return;
@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void phi_dev_post(int32_t dt, double sign, PhiDev &q,
         R.active[side][slot] = 1; R.use_ref[side][slot] = use_ref; R.ref_req[side][slot] = ref_req;
         q.spec_t[slot] = t; q.spec_ref[slot] = is_ref; q.active[slot] = 1;
     };
-    post(0, q.req_t, q.req_ref, -1, q.req_ref);
+    post(0, q.req_t, q.req_ref ? 1 + q.ref_buf : 0, -1, q.req_ref);
     if (q.state == kPhiFirst) {
         post(1, dev_rt(dt, q.req_t + q.req_t), 0, 0, 1);
         post(2, dev_rt(dt, 0.5 * q.req_t), 0, -1, 0);
@@ -1285,22 +1285,19 @@ template <typename V> __device__ __forceinline__ V sel3(int i, V a, V b, V c) { 
 
 // finish_phi6_kernel + the host loop body of bfgs_dual_search behind it: the round's six sums, both machines fed --
 // the primary request, then the speculative ones that match what the machine asks for next --, the next round's
-// requests posted, the summary and the ticket published; then the whole block copies the new reference points.
-// pts[r][slot]: the trial-point buffers, refp[r]: the reference points.
-struct PhiBuffers { void *pts[2][3]; void *refp[2]; };
+// requests posted, the summary and the ticket published.  The reference point of :136 / :155 is not copied anywhere:
+// it is the trial point the machine consumed last, which stays in its request's buffer until the next launch -- and
+// that launch reads a reference element before it writes any trial-point element of the same index (PhiDev::ref_buf).
 __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const double *__restrict__ partials, int64_t count, double scale,
                                                                      double *__restrict__ out, int32_t *__restrict__ flags, double ticket,
                                                                      BfgsSearchDev *__restrict__ S, int round, int32_t dt,
-                                                                     int32_t max_increases, double sign, PhiBuffers bufs, int64_t vec16,
-                                                                     int publish) {
+                                                                     int32_t max_increases, double sign, int publish) {
     __shared__ double lds6[6 * kWaves];
     __shared__ BfgsSearchDev L;
     __shared__ int32_t hf_s[18];
-    __shared__ int copy_s[2];
-    search_to_lds(S, &L);
+    const bool live = S->q[0].want || S->q[1].want;             // (uniform; nothing was evaluated otherwise)
+    search_to_lds(S, &L);                                       // (complete at the barriers inside block_sum_multi, like hf_s)
     if (threadIdx.x < 18) { hf_s[threadIdx.x] = flags[threadIdx.x]; flags[threadIdx.x] = 0; }    // (re-armed for the next round)
-    __syncthreads();
-    const bool live = L.q[0].want || L.q[1].want;               // (uniform; nothing was evaluated otherwise)
     double v[6] = {0, 0, 0, 0, 0, 0};
     if (live) {
         int64_t i = threadIdx.x;
@@ -1326,12 +1323,10 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const doubl
         PhiDev *q = L.q;                                         // (worked on in LDS: private copies end up in scratch memory, 4x slower)
         PhiReqDev &R = L.req;
         int64_t evals = L.evals;
-        int copies[2] = {-1, -1};
         if (live) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 PhiDev &sm = q[r];
-                sm.ref_copy = -1;
                 if (!sm.active[0]) continue;
                 const double f3[3] = {dev_rt(dt, scale * sres[r * 3 + 0]), dev_rt(dt, scale * sres[r * 3 + 1]), dev_rt(dt, scale * sres[r * 3 + 2])};
                 int used = 0, slot = 0;
@@ -1350,13 +1345,11 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const doubl
                     if (next < 0) break;
                     slot = next;
                 }
-                copies[r] = sm.ref_copy;
             }
             phi_dev_post(dt, sign, q[0], R, 0);
             phi_dev_post(dt, sign, q[1], R, 1);
             L.evals = evals;
         }
-        copy_s[0] = copies[0]; copy_s[1] = copies[1];
         if (publish) {                                           // (the host waits for the last enqueued round only: a system-scope
             phi_dev_summary(q[0], L.norm[0], out + kSumBase);    // fence pair over PCIe costs more than the rest of this kernel)
             phi_dev_summary(q[1], L.norm[1], out + kSumBase + kSumStride);
@@ -1368,23 +1361,6 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const doubl
     }
     __syncthreads();
     if (live) search_from_lds(S, &L);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int c = copy_s[r];
-        if (c < 0) continue;
-        // (the vectors are allocated in multiples of 64 elements: whole 16-byte words; eight loads in flight per thread)
-        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(c == 0 ? bufs.pts[r][0] : (c == 1 ? bufs.pts[r][1] : bufs.pts[r][2]));
-        uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(bufs.refp[r]);
-        int64_t i = threadIdx.x;
-        for (; i + 7 * kBlock < vec16; i += 8 * kBlock) {
-            uint4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = src[i + (int64_t)u * kBlock];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dst[i + (int64_t)u * kBlock] = t[u];
-        }
-        for (; i < vec16; i += kBlock) dst[i] = src[i];
-    }
 }
 
 static int dev_search_rounds() {
@@ -1411,9 +1387,7 @@ static int32_t bfgs_dev_search(dzo_bfgs_s *o, double step_length, double *grad_n
         DZO_DISPATCH(dt, hipLaunchKernelGGL(norm2_pair_begin_kernel<T>, dim3(1), dim3(kBlock), 0, s, o->n, (const T *)o->g, (const T *)o->d,
                                             o->dsearch, o->f, step_length, dt, o->sign));
     }
-    PhiBuffers bufs;
-    bufs.pts[0][0] = o->scratch; bufs.pts[0][1] = o->spec_buf[0]; bufs.pts[0][2] = o->spec_buf[1]; bufs.refp[0] = o->ref_point;
-    bufs.pts[1][0] = o->scratch2; bufs.pts[1][1] = o->spec_buf[2]; bufs.pts[1][2] = o->spec_buf[3]; bufs.refp[1] = o->ref_point2;
+    void *pts[2][3] = {{o->scratch, o->spec_buf[0], o->spec_buf[1]}, {o->scratch2, o->spec_buf[2], o->spec_buf[3]}};   // trial-point buffer of request slot e
     int round = 0;
     auto enqueue_round = [&](bool publish) -> int32_t {
         round += 1;
@@ -1421,11 +1395,10 @@ static int32_t bfgs_dev_search(dzo_bfgs_s *o, double step_length, double *grad_n
         for (int r = 0; r < 2; ++r) {
             req[r].dir = dirs[r];
             for (int e = 0; e < 3; ++e) {
-                req[r].point_out[e] = bufs.pts[r][e];
+                req[r].point_out[e] = pts[r][e];
                 req[r].grad_out[e] = (char *)o->grad_pool + (size_t)((round % 4) * 6 + r * 3 + e) * vbytes;
                 req[r].active[e] = true;                         // (the kernel takes these three from the device's requests)
             }
-            req[r].ref[0] = bufs.refp[r];
         }
         o->ticket += 1.0;
         DZO_REQUIRE(problem_phi6_async(o->problem, s, o->x, req, o->phi_flags(), o->host_dev, o->ticket, &o->dsearch->req), DZO_ERR_HIP,
@@ -1433,8 +1406,7 @@ static int32_t bfgs_dev_search(dzo_bfgs_s *o, double step_length, double *grad_n
         {
             DZO_TIMED("bfgs_search_advance", s);
             hipLaunchKernelGGL(finish_phi6_advance_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)o->problem->scratch, o->n, 0.5,
-                               o->host_dev, o->phi_flags(), o->ticket, o->dsearch, round, dt, o->max_increases, o->sign, bufs,
-                               (int64_t)(vbytes / 16), publish ? 1 : 0);
+                               o->host_dev, o->phi_flags(), o->ticket, o->dsearch, round, dt, o->max_increases, o->sign, publish ? 1 : 0);
         }
         DZO_HIP(hipGetLastError());
         return DZO_OK;

@@ -61,9 +61,10 @@ struct PhiReqDev {
     double ts[2][3];
     int32_t active[2][3];
     int32_t ref_req[2][3];      // the request of the same direction in this launch to compare with, or -1
-    int32_t use_ref[2][3];      // 0: ignore PhiDirHost::ref of this request
+    int32_t use_ref[2][3];      // [side][0]: 0 = no stored reference point, 1 + b = the direction's trial-point buffer b (point_out[b]) as it stands
 };
-// dreq: take step sizes / activity / references from there (the pointers still from req) and leave the finish to the caller
+// dreq: take step sizes / activity / references from there (the buffers still from req; req's ref pointers are not used) and
+// leave the finish to the caller
 bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const PhiDirHost req[2], int32_t *flags, double *result_dev, double ticket,
                         const PhiReqDev *dreq = nullptr);   // result_dev[20] <- ticket, last
 // Enqueue g = grad f(x) on `s`.

@@ -379,11 +379,16 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
         for (int r = 0; r < 3; ++r) {
             a.ts[r] = (T)dreq->ts[0][r]; a.active[r] = dreq->active[0][r]; a.ref_req[r] = dreq->ref_req[0][r];
             b.ts[r] = (T)dreq->ts[1][r]; b.active[r] = dreq->active[1][r]; b.ref_req[r] = dreq->ref_req[1][r];
-            if (!dreq->use_ref[0][r]) a.ref[r] = nullptr;
-            if (!dreq->use_ref[1][r]) b.ref[r] = nullptr;
             any |= a.active[r] | b.active[r];
         }
         if (!any) return;
+        // the :150 reference of a primary request: none, or one of the direction's own trial-point buffers as the
+        // previous launch left it (no copy of the reference point between the rounds)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { a.ref[r] = nullptr; b.ref[r] = nullptr; }
+        const int ra = dreq->use_ref[0][0], rb = dreq->use_ref[1][0];
+        if (ra) a.ref[0] = ra == 1 ? a.point_out[0] : (ra == 2 ? a.point_out[1] : a.point_out[2]);
+        if (rb) b.ref[0] = rb == 1 ? b.point_out[0] : (rb == 2 ? b.point_out[1] : b.point_out[2]);
     }
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
         const T *col = A + j * n;
@@ -422,9 +427,11 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
             for (int side = 0; side < 2; ++side) {
                 const PhiDir<T> &d = side ? b : a;
                 const T dj = d.dir[j];
-                T xt[3];
+                T xt[3], refv[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) xt[r] = dfma(d.ts[r], dj, xo);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) refv[r] = (d.active[r] && d.ref[r]) ? d.ref[r][j] : (T)0;   // first: a reference may be one of this launch's own output buffers
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     if (!d.active[r]) continue;
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
                     if (d.grad_out[r]) d.grad_out[r][j] = (T)c[slot];      // exactly what quadratic_kernel<WRITE_G> stores
                     if (xo != xt[r]) flags[slot * 3 + 0] = 1;
                     if (dj != (T)0) flags[slot * 3 + 1] = 1;
-                    if (d.ref[r]) { if (!is_equal(xt[r], d.ref[r][j])) flags[slot * 3 + 2] = 1; }
+                    if (d.ref[r]) { if (!is_equal(xt[r], refv[r])) flags[slot * 3 + 2] = 1; }
                     else if (d.ref_req[r] >= 0) { if (!is_equal(xt[r], xt[d.ref_req[r]])) flags[slot * 3 + 2] = 1; }
                 }
             }
