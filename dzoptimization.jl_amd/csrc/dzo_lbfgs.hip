@@ -342,7 +342,15 @@ __global__ __launch_bounds__(kBlock) void chain_head_kernel(int64_t n, const T *
 }
 
 // ============================================================================ GRAM mode
+// dev instrumentation: start / end clock of every wave of the last instrumented kernel (point pass: DZO_TUNE_SP_DEBUG & 1024;
+// Gram pass / combine: DZO_TUNE_TP_DEBUG = 1 / 2), read back by tools/wave_times.py
+__device__ unsigned long long g_dev_wave_times[1024 * 4 * 2];
+__device__ __forceinline__ void dev_stamp(int debug_on, int which) {
+    if (debug_on && blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_dev_wave_times[(blockIdx.x * kWaves + (threadIdx.x >> 6)) * 2 + which] = wall_clock64();
+}
+
 template <typename T> struct GramParams {
+    int debug;
     int64_t n;
     const T *g;
     const T *sp;                // pivot pair (the pair whose Gram row/column is (re)computed)
@@ -612,6 +620,7 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
     double acc[kGramValues];
 #pragma unroll
     for (int c = 0; c < kGramValues; ++c) acc[c] = 0;
+    dev_stamp(p.debug, 0);
     const T *sp = p.sp, *yp = p.yp;
     const int k = p.k;
     const int64_t nvec = p.n / N;
@@ -721,6 +730,10 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
     // the whole launch waited ~50 us for it (the Gram pass measured 579 us in step! against
     // 526 us for the same code without a ragged tile in tools/grambench.hip).
     if (full_tiles * tile_v < nvec && blockIdx.x == gridDim.x - 1) do_tile(full_tiles * tile_v, std::false_type{});
+    // (Per-wave clocks at config 3: the blocks that arrived first on a CU get through their tiles at nearly twice the pace
+    // of the last ones -- a SIMD serves the oldest of its waves first -- and are done at 283 us against 514 us.  A priority
+    // that falls with a block's progress evens that out, 491 ... 528 us, and the kernel takes exactly as long, 550 us: the
+    // pass is bound by the memory system, which does not care whose requests it serves.  Not kept.)
     if (p.peel) { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::true_type{}); }
     else { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::false_type{}); }
     (void)nthreads;
@@ -750,9 +763,11 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
             p.partials[(int64_t)(lane * kGramValues + c) * gridDim.x + blockIdx.x] = r;
         }
     }
+    dev_stamp(p.debug, 1);
 }
 
 template <typename T> struct CombineParams {
+    int debug;
     int64_t n;
     const T *g;
     T *d;
@@ -784,6 +799,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
     const T scale = k > 0 ? (T)p.scale[0] : (T)1;
     const int64_t nvec = p.n / N;
     const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    dev_stamp(p.debug, 0);
     for (int64_t base = (int64_t)blockIdx.x * kBlock * U; base < nvec; base += nthreads * U) {
         T q[U][N];
         bool ok[U];
@@ -848,6 +864,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
             p.d[e] = q;
         }
     }
+    dev_stamp(p.debug, 1);
 }
 
 // ============================================================================ single-pass step
@@ -1196,7 +1213,6 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // 1 = ONE set and two waves per SIMD (256 registers per wave): a wave's instruction stream is in order, so whenever one
 // of its loads cannot issue (the memory pipeline is backed up -- the steady state of a bandwidth-bound sweep) or an
 // instruction waits for a result, the SIMD idles unless a second wave is there to take the slot.
-__device__ unsigned long long g_dev_wave_times[1024 * 4 * 2];        // dev instrumentation (DZO_TUNE_SP_DEBUG & 1024): start / end clock of every wave of the pass
 // The stencils carry no index tests (10 of a stencil's 34 instructions): what rosen_grad_elem decides from the element's
 // index -- only the first and the last element of the vector differ -- is a set of per-element coefficients formed once
 // per wave-row (RosenCoef, dzo_rosen.h), and every row runs the same straight-line code.
@@ -1837,6 +1853,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     for (int i = 0; i < k; ++i) { gp.s[i] = o->s_slot<T>(o->slot_of(i)); gp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     gp.partials = o->gram_partials;
     gp.rowbytes = o->rowbytes;
+    gp.debug = tune("DZO_TUNE_TP_DEBUG", 0) == 1;
     gp.peel = o->gram_peel;
     gp.fresh_plain = o->gram_fresh_plain;
     gp.pivot_first = (o->gram_skip0 && pivot == 0) ? 1 : 0;
@@ -1946,6 +1963,7 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
     for (int i = 0; i < k; ++i) { cp.s[i] = o->s_slot<T>(o->slot_of(i)); cp.y[i] = o->y_slot<T>(o->slot_of(i)); }
     cp.alpha = o->alpha; cp.coef = o->coef; cp.scale = o->scale;
     cp.rowbytes = o->rowbytes;
+    cp.debug = tune("DZO_TUNE_TP_DEBUG", 0) == 2;
     cp.fresh_plain = o->combine_fresh_plain;
     const bool vec = al16(c.g);
     int u = o->combine_u;
