@@ -234,3 +234,39 @@ def test_one_register_set_variant_of_the_point_pass_runs_the_same_trajectory(dty
     tol = 1e-9 if dtype == np.float64 else 1e-3
     assert np.allclose(f1, f2, rtol=tol, atol=0)
     assert rel(x1, x2) <= (1e-7 if dtype == np.float64 else 1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 1_000_000, 20), (np.float64, 400_000, 8), (np.float32, 600_000, 12)])
+def test_issue_priorities_and_wave_clocks_leave_the_results_alone(dtype, n, m, monkeypatch):
+    """DZO_TUNE_POINT_PRIO (s_setprio by phase in the point pass) and bit 1024 of DZO_TUNE_SP_DEBUG (every wave stamps its
+    start and end clock) change WHEN instructions issue, never what they compute: bit-identical trajectories; and the
+    stamps are there to be read (tools/wave_times.py)."""
+    import ctypes
+
+    def run(prio, debug):
+        monkeypatch.setenv("DZO_TUNE_POINT_PRIO", str(prio))
+        monkeypatch.setenv("DZO_TUNE_SP_DEBUG", str(debug))
+        _, opt = _make(n, m, dtype, step0=0.5)
+        fs = []
+        for _ in range(m + 5):
+            opt.step()
+            if opt.is_stuck:
+                break
+            fs.append((opt.current_objective_value, opt.last_trials))
+        x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
+        assert opt.ring_layout == 2 and opt.single_pass_steps >= len(fs) - 1
+        opt.close()
+        return fs, x, g
+    base = run(1, 0)
+    assert len(base[0]) >= 3
+    for prio, debug in ((0, 0), (1, 1024)):
+        other = run(prio, debug)
+        assert other[0] == base[0] and np.array_equal(other[1], base[1]) and np.array_equal(other[2], base[2])
+    lib = dzo.lib()
+    lib.dzo_debug_wave_times.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    buf = (ctypes.c_ulonglong * 64)()
+    assert lib.dzo_debug_wave_times(buf, 64) == 0
+    t = np.array(buf, dtype=np.uint64).reshape(-1, 2)
+    assert (t[:, 1] > t[:, 0]).all()                                   # every wave of the first eight blocks: end after start
+    assert lib.dzo_debug_wave_times(buf, 0) != 0 and lib.dzo_debug_wave_times(buf, 1 << 20) != 0   # count checked
