@@ -146,7 +146,7 @@ _P = C.POINTER
 ABI = {
     "dzo_init": [_i32], "dzo_shutdown": [], "dzo_device_info": [C.c_char_p, _i32, _P(_i32), _P(_i64)],
     "dzo_synchronize": [],
-    "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_profile_count": [_P(_i32)],
+    "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_unsealed_first_reads": [_P(_i64)], "dzo_profile_count": [_P(_i32)],
     "dzo_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_dbl)],
     "dzo_calibrate_read_bandwidth": [_i64, _i32, _P(_dbl)],
     "dzo_malloc": [_P(_vp), _i64], "dzo_free": [_vp], "dzo_memcpy_h2d": [_vp, _vp, _i64],
@@ -389,6 +389,13 @@ def profile_enable(level=2):
 
 def profile_reset():
     _check(lib().dzo_profile_reset())
+
+
+def unsealed_first_reads() -> int:
+    """Diagnostic (include/dzo.h): how often a host wait found a kernel's published result not yet matching its seal."""
+    v = C.c_int64(0)
+    _check(lib().dzo_unsealed_first_reads(C.byref(v)))
+    return int(v.value)
 
 
 def profile_table():

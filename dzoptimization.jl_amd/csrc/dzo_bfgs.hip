@@ -18,7 +18,9 @@
 // onto v_mfma_f64_16x16x4_f64 with K padded 2->4, but at 0.4 flop/byte the kernel is bound by
 // HBM, not by the 2 fma per element; the VALU form below also keeps the reference's rounding
 // order, which the MFMA accumulate order would not.  See DESIGN.md.
+#include <atomic>
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 #include <utility>
 
@@ -577,6 +579,7 @@ __global__ __launch_bounds__(kBlock) void norm2_pair_kernel(int64_t n, const T *
     const double rb = block_sum(sb, lds);
     if (threadIdx.x == 0) {
         out[0] = ra; out[1] = rb;
+        store_seal(out + 2, seal_bits(ra) ^ seal_bits(rb) ^ seal_bits(ticket));     // (wait_sealed)
         __threadfence_system();
         out[20] = ticket;
         __threadfence_system();
@@ -681,6 +684,7 @@ static int32_t bfgs_norm_pair(dzo_bfgs_s *o, const void *a, const void *b, doubl
                                                   o->host_dev, o->ticket));
         DZO_HIP(hipGetLastError());
         DZO_TRY(wait_ticket(o->stream, o->host + 20, o->ticket));
+        DZO_TRY(wait_sealed(o->stream, o->host, 2, o->host + 2, o->ticket));
         const double sa = o->host[0], sb = o->host[1];
         *na = o->dtype == DZO_F32 ? (double)sqrtf((float)sa) : sqrt(sa);
         *nb = o->dtype == DZO_F32 ? (double)sqrtf((float)sb) : sqrt(sb);
@@ -1039,6 +1043,7 @@ static int32_t bfgs_dual_search(dzo_bfgs_s *o, const void *dir_a, double t0_a, c
         if (!problem_phi6_async(o->problem, o->stream, o->x, req, o->phi_flags(), o->host_dev, o->ticket)) return DZO_OK;
         DZO_HIP(hipGetLastError());
         DZO_TRY(wait_ticket(o->stream, o->host + 20, o->ticket));
+        DZO_TRY(wait_sealed(o->stream, o->host, 17, o->host + 17, o->ticket));
         const int32_t *hf = reinterpret_cast<const int32_t *>(o->host + 8);
         for (int r = 0; r < 2; ++r) {
             PhiSearch &sm = q[r];
@@ -1231,9 +1236,13 @@ __device__ __forceinline__ void phi_dev_post(int32_t dt, double sign, PhiDev &q,
 //   [0] want | state << 8 | (best_grad + 1) << 16 | best_round << 32 (as an integer-valued double: < 2^53)
 //   [1] t_best  [2] f_best  [3] t0  [4] the direction's norm
 constexpr int kSumStride = 5;
-__device__ __forceinline__ void phi_dev_summary(const PhiDev &q, double norm, double *o) {
+__device__ __forceinline__ unsigned long long phi_dev_summary(const PhiDev &q, double norm, double *o) {      // returns its share of the seal
     const int64_t packed = (int64_t)q.want | ((int64_t)q.state << 8) | ((int64_t)(q.best_grad + 1) << 16) | ((int64_t)q.best_round << 32);
-    o[0] = (double)packed; o[1] = q.t_best; o[2] = q.f_best; o[3] = q.t0; o[4] = norm;
+    const double v[kSumStride] = {(double)packed, q.t_best, q.f_best, q.t0, norm};
+    unsigned long long seal = 0;
+#pragma unroll
+    for (int i = 0; i < kSumStride; ++i) { o[i] = v[i]; seal ^= seal_bits(v[i]); }
+    return seal;
 }
 
 // BfgsSearchDev lives in device memory between kernels; inside a kernel the whole block moves it to LDS (one memory
@@ -1351,9 +1360,12 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const doubl
             L.evals = evals;
         }
         if (publish) {                                           // (the host waits for the last enqueued round only: a system-scope
-            phi_dev_summary(q[0], L.norm[0], out + kSumBase);    // fence pair over PCIe costs more than the rest of this kernel)
-            phi_dev_summary(q[1], L.norm[1], out + kSumBase + kSumStride);
+            unsigned long long seal = seal_bits(ticket);         // (wait_sealed: the host checks it before it reads the summary)
+            seal ^= phi_dev_summary(q[0], L.norm[0], out + kSumBase);   // fence pair over PCIe costs more than the rest of this kernel)
+            seal ^= phi_dev_summary(q[1], L.norm[1], out + kSumBase + kSumStride);
             out[kSumBase + 2 * kSumStride] = (double)evals;
+            seal ^= seal_bits((double)evals);
+            store_seal(out + kSumBase + 2 * kSumStride + 1, seal);
             __threadfence_system();
             out[20] = ticket;
             __threadfence_system();
@@ -1415,6 +1427,7 @@ static int32_t bfgs_dev_search(dzo_bfgs_s *o, double step_length, double *grad_n
     for (int batch = dev_search_rounds();; batch = 1) {
         for (int i = 0; i < batch; ++i) DZO_TRY(enqueue_round(i + 1 == batch));
         DZO_TRY(wait_ticket(s, o->host + 20, o->ticket));
+        DZO_TRY(wait_sealed(s, o->host + kSumBase, 2 * kSumStride + 1, o->host + kSumBase + 2 * kSumStride + 1, o->ticket));
         if ((((int64_t)sum[0]) & 0xFF) == 0 && (((int64_t)sum[kSumStride]) & 0xFF) == 0) break;   // neither search wants another evaluation
     }
     *grad_norm = sum[4]; *bfgs_norm_v = sum[kSumStride + 4];

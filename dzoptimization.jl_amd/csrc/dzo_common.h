@@ -71,6 +71,14 @@ int32_t require_init();
 // through the runtime's signal wait.  The stream is queried every 64 Ki spins so that a failed launch cannot hang
 // the caller.  DZO_TUNE_POLL=0: hipStreamSynchronize instead.
 int32_t wait_ticket(hipStream_t s, const double *word, double ticket);
+// ... and then until the `count` doubles at `data` carry the publishing kernel's SEAL: the xor of their bit patterns and
+// of the ticket's, which the kernel stores in `*seal` next to them.  Data and ticket travel to host memory as separate
+// writes; a system-scope fence between them orders them on the GPU, and still the host has been seen to read the new
+// ticket next to the previous publish's data when the two lie in different cache lines (1 to 5 times in 10 000 waits,
+// MI355X over PCIe).  The seal does not depend on any ordering.  (Results that share the ticket's 64-byte line --
+// core_wait_decision -- have never been seen torn and are not sealed.)
+int32_t wait_sealed(hipStream_t s, const double *data, int count, const double *seal, double ticket);
+int64_t unsealed_first_reads();                  // how often wait_sealed had to look twice (process-wide, diagnostic)
 constexpr int kMaxDevices = 32;
 
 // Enter `device` for the lifetime of the scope (HIP's current device of this thread and the
@@ -142,6 +150,9 @@ struct ScopedKernelTimer {
 #define DZO_TIMED(name, stream) ::dzo::ScopedKernelTimer timer__(name, stream)
 
 // ------------------------------------------------------------------------------ device side
+__device__ __forceinline__ unsigned long long seal_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ void store_seal(double *slot, unsigned long long seal) { *reinterpret_cast<unsigned long long *>(slot) = seal; }
+
 template <typename T> struct Vec16;   // 16-byte vector of T
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
 template <> struct Vec16<float>  { using type = float4;  static constexpr int N = 4; };

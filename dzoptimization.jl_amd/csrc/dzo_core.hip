@@ -70,6 +70,28 @@ int32_t wait_ticket(hipStream_t s, const double *word, double ticket) {
     return DZO_OK;
 }
 
+static std::atomic<int64_t> g_unsealed_reads{0};
+int64_t unsealed_first_reads() { return g_unsealed_reads.load(); }
+
+int32_t wait_sealed(hipStream_t s, const double *data, int count, const double *seal, double ticket) {
+    volatile const double *d = data;
+    volatile const unsigned long long *sl = reinterpret_cast<volatile const unsigned long long *>(seal);
+    unsigned long long tb;
+    memcpy(&tb, &ticket, sizeof(tb));
+    for (int64_t spins = 0;; ++spins) {
+        unsigned long long x = tb;
+        for (int i = 0; i < count; ++i) { const double v = d[i]; unsigned long long b; memcpy(&b, &v, sizeof(b)); x ^= b; }
+        if (x == *sl) break;
+        if (spins == 0) g_unsealed_reads += 1;
+        if (spins == 1000000) DZO_HIP(hipStreamSynchronize(s));      // (everything the stream wrote is visible after this)
+        if (spins >= 1001000) { set_error("results published to the host never matched their seal"); return DZO_ERR_HIP; }
+        __builtin_ia32_pause();
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return DZO_OK;
+}
+
 int32_t require_init() {
     if (!ctx().ready) {
         set_error("dzo_init() has not been called (or no HIP device is available)");
@@ -320,6 +342,12 @@ int32_t dzo_synchronize(void) {
 
 int32_t dzo_profile_enable(int32_t on) {
     g_profile = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return DZO_OK;
+}
+
+int32_t dzo_unsealed_first_reads(int64_t *count) {
+    DZO_REQUIRE(count, DZO_ERR_INVALID, "null argument");
+    *count = unsealed_first_reads();
     return DZO_OK;
 }
 

@@ -121,10 +121,13 @@ __device__ __forceinline__ void decide_body(const DecideArgs &a, double *lds) {
         *a.status = st;
         *a.changed = 0;                                          // armed for the next trial (saves a memset launch)
         // outcome straight into the pinned host mirror: no D->H blit kernel on the critical path
+        // (whole 64-bit words, and their seal in word 6: core_wait_decision checks it -- dzo_common.h, wait_sealed)
+        const unsigned long long sw = (unsigned long long)(uint32_t)st, cw = (unsigned long long)(uint32_t)ch;
         a.host_out[0] = f_raw;
         a.host_out[1] = f_second;
-        reinterpret_cast<int32_t *>(a.host_out + 3)[0] = st;
-        reinterpret_cast<int32_t *>(a.host_out + 4)[0] = ch;
+        reinterpret_cast<unsigned long long *>(a.host_out)[3] = sw;
+        reinterpret_cast<unsigned long long *>(a.host_out)[4] = cw;
+        store_seal(a.host_out + 6, seal_bits(f_raw) ^ seal_bits(f_second) ^ sw ^ cw ^ seal_bits(a.ticket));
         __threadfence_system();
         a.host_out[7] = a.ticket;                                // the host spins on this word (core_wait_decision)
         __threadfence_system();

@@ -90,7 +90,10 @@ void launch_decide(OptCore &c, const double *partials, int64_t count, double sca
 // and stamps it with a ticket, so the host spins on that word: no event record between the decision and the gated
 // kernels behind it (a barrier packet, ~5 us on the stream) and no wake-up through the runtime's signal wait.
 // Every few thousand spins the stream is queried so that a failed launch cannot hang the caller.
-int32_t core_wait_decision(OptCore &c) { return wait_ticket(c.stream, c.host + 7, c.ticket); }
+int32_t core_wait_decision(OptCore &c) {
+    DZO_TRY(wait_ticket(c.stream, c.host + 7, c.ticket));
+    return wait_sealed(c.stream, c.host, 6, c.host + 6, c.ticket);   // (words 0, 1, 3, 4 carry the outcome; 2 and 5 stay zero)
+}
 
 static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

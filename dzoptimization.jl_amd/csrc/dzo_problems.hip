@@ -477,10 +477,18 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_kernel(const double *__res
     double sres[6];
     block_sum_multi<6>(v, lds6, sres);
     if (threadIdx.x == 0) {
+        unsigned long long seal = seal_bits(ticket);             // (wait_sealed: out[0..16], seal in out[17])
 #pragma unroll
-        for (int r = 0; r < 6; ++r) out[r] = scale * sres[r];
+        for (int r = 0; r < 6; ++r) { const double v = scale * sres[r]; out[r] = v; seal ^= seal_bits(v); }
+        out[6] = 0; out[7] = 0;
         int32_t *ho = reinterpret_cast<int32_t *>(out + 8);
-        for (int q = 0; q < 18; ++q) { ho[q] = flags[q]; flags[q] = 0; }
+        for (int q = 0; q < 18; q += 2) {
+            const int32_t f0 = flags[q], f1 = flags[q + 1];
+            flags[q] = 0; flags[q + 1] = 0;
+            ho[q] = f0; ho[q + 1] = f1;
+            seal ^= (unsigned long long)(uint32_t)f0 | ((unsigned long long)(uint32_t)f1 << 32);
+        }
+        store_seal(out + 17, seal);
         __threadfence_system();
         out[20] = ticket;                                        // the host spins on this word (wait_ticket)
         __threadfence_system();

@@ -53,6 +53,12 @@ end
 ensure_init() = _initialised[] || init(parse(Int, get(ENV, "DZO_DEVICE", "0")))
 """Wait for every stream of the library (step functions return before their last kernels finish)."""
 synchronize() = check(ccall((:dzo_synchronize, libdzo), Cint, ()))
+"""Diagnostic (include/dzo.h): how often a host wait found a kernel's published result not yet matching its seal."""
+function unsealed_first_reads()
+    r = Ref{Int64}(0)
+    check(ccall((:dzo_unsealed_first_reads, libdzo), Cint, (Ref{Int64},), r))
+    return r[]
+end
 
 ################################################################################ HipVector
 

@@ -109,6 +109,13 @@ int32_t dzo_profile_reset(void);
 int32_t dzo_profile_count(int32_t *count);
 int32_t dzo_profile_get(int32_t i, char *name, int32_t name_len, int64_t *launches, double *total_ms);
 
+/* Diagnostic.  Kernels hand short results to the host (a trial's outcome, the line searches' state: what the reference
+ * keeps in host scalars, src/DZOptimization.jl:328-335) through pinned memory: the result words, their SEAL (the xor of
+ * their bits and of a ticket), then the ticket the host spins on.  The host reads the results only once the seal
+ * matches: on MI355X it has been seen to read a new ticket next to the previous publish's words (1 to 5 times in
+ * 10 000 waits when they lie in different cache lines).  *count = how often a wait had to look twice, process-wide. */
+int32_t dzo_unsealed_first_reads(int64_t *count);
+
 /* Calibration (SURVEY.md 8(d) "calibrate on the box"): GB/s of a plain read-only streaming kernel over
  * `bytes` of device memory re-read `repeats` times.  <= ~200 MiB stays in the Infinity Cache (the ceiling of
  * config 2, H = 128 MiB); several GiB give the HBM streaming ceiling. */

@@ -41,7 +41,12 @@ def run(cases=60, seed=2468):
                 ref.install_state(opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value,
                                   S, Y, opt.rho_history[:k], opt.iteration_count)
                 opt.step(); ref.step()
-                assert opt.is_stuck == ref.is_stuck, (ex, it, n, m, step0)
+                if opt.is_stuck != ref.is_stuck:
+                    # only after dozens of halvings, where f_new - f is one unit in the last place and the two summation
+                    # orders may decide differently (seed 12, case 2: the oracle accepts trial 43 with f lower by 5e-14,
+                    # the GPU halves on to x + t d == x)
+                    assert min(opt.last_trials, ref.last_trials) > 30, (ex, it, n, m, step0, opt.last_trials, ref.last_trials)
+                    break
                 if ref.is_stuck:
                     break
                 if ref.last_trials > 30 and opt.last_trials != ref.last_trials:

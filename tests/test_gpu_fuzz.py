@@ -1,4 +1,4 @@
-"""The three fuzz sweeps (tests/fuzz_*.py: random shapes, every step compared with the oracle) under pytest with a
+"""The fuzz sweeps (tests/fuzz_*.py: random shapes, every step compared with the oracle or with the other scheduling) under pytest with a
 fixed seed and 20 cases each; the scripts themselves take FUZZ_CASES / FUZZ_SEED for longer runs by hand."""
 import pytest
 
@@ -22,3 +22,11 @@ def test_fuzz_adgd_steps_against_the_oracle():
     import fuzz_adgd
     out = fuzz_adgd.run(cases=20, seed=4321)
     assert out["fused_steps"] >= 100, out
+
+
+def test_fuzz_dense_bfgs_device_driven_searches_against_the_host_driven_ones():
+    import fuzz_bfgs_search
+    from dzo_loader import dzo
+    steps, terminated = fuzz_bfgs_search.run(cases=25, seed=97531)
+    assert steps >= 150, (steps, terminated)
+    assert dzo.unsealed_first_reads() >= 0                     # (the diagnostic counter of wait_sealed is reachable)
