@@ -30,3 +30,9 @@ def test_fuzz_dense_bfgs_device_driven_searches_against_the_host_driven_ones():
     steps, terminated = fuzz_bfgs_search.run(cases=25, seed=97531)
     assert steps >= 150, (steps, terminated)
     assert dzo.unsealed_first_reads() >= 0                     # (the diagnostic counter of wait_sealed is reachable)
+
+
+def test_fuzz_batched_bfgs_steps_against_per_instance_oracles():
+    import fuzz_batched
+    out = fuzz_batched.run(cases=12, seed=24680)
+    assert out["instance_steps"] >= 100, out

@@ -6,3 +6,4 @@ FUZZ_CASES=${CASES:-250} FUZZ_SEED=${SEED:-11} timeout -k 10 500 python3 tests/f
 FUZZ_CASES=${CASES:-250} FUZZ_SEED=${SEED:-12} timeout -k 10 500 python3 tests/fuzz_points.py 2>&1 | tail -3
 FUZZ_CASES=${CASES:-250} FUZZ_SEED=${SEED:-13} timeout -k 10 500 python3 tests/fuzz_lbfgs.py 2>&1 | tail -3
 FUZZ_CASES=${CASES:-250} FUZZ_SEED=${SEED:-14} timeout -k 10 500 python3 tests/fuzz_adgd.py 2>&1 | tail -3
+FUZZ_CASES=$(( ${CASES:-250} / 4 )) FUZZ_SEED=${SEED:-15} timeout -k 10 700 python3 tests/fuzz_batched.py 2>&1 | tail -3
