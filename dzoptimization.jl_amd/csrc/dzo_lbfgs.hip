@@ -920,6 +920,7 @@ template <typename T> struct FusedParams {
     int stage_rows;                            // point ring: rows whose new tiles a wave collects in LDS before it writes them in one burst
     int store_d;                               // point ring: write step_direction (it is formed on demand otherwise, see lbfgs_materialize_d)
     int prio;                                  // point pass: per-phase issue priority (two waves per SIMD)
+    int leftover_even;                         // point pass: the last, partial round of rows goes to the even XCDs' blocks first
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
 };
 
@@ -1224,6 +1225,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     __shared__ double wacc[kWaves][kFusedMaxK + 1][kGramValues];
     __shared__ double lds[kWaves];
     __shared__ int lds_flag;
+    __shared__ int64_t stage_row_s[kWaves][40];                 // the rows of the batch being collected (at most 36)
     // The new point's tiles are not written row by row: a wave collects them in its own slice of LDS and writes
     // stage_rows rows in one burst.  HBM pays for every switch between reading and writing: with this pass's
     // memory shape alone (tools/pointbench.hip: 42 tile reads per row, no arithmetic) the sweep takes 495 us
@@ -1238,7 +1240,6 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     constexpr int kStageTiles = kWriteG ? 2 : 1;
     char *stage = stage_lds + (size_t)wave * stage_rows * (kStageTiles * kTileBytes);
     int staged = 0;
-    int64_t stage_row0 = 0;                    // the row in slot 0 of the batch being collected
     const int k = p.k, kn = p.k_next;          // k <= K
     // pairs i >= k get a zero coefficient, and the host points the table entries of the points beyond k at point
     // k, so that those pairs are X_k - X_k = 0: every load below is unconditional straight-line code
@@ -1286,7 +1287,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         asm volatile("" : "+s"(uoff));                           // (see lbfgs_single_pass_kernel)
         return reinterpret_cast<const T *>(rb + (uint32_t)(uoff + toff));
     };
-    // the staged rows (stage_row0, stage_row0 + stride, ...) to the spare slot's tiles: the owned vectors, and the
+    // the staged rows (stage_row_s) to the spare slot's tiles: the owned vectors, and the
     // first / last owned vector of a row also as the right / left halo copy of the neighbouring row's tile.
     // PLAIN stores while the two streams fit the Infinity Cache (the next pass reads these tiles first: measured
     // inside step! at n = 1e7, k = 20, 695 us against 735 us with non-temporal stores -- the opposite of the pair
@@ -1294,7 +1295,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     // (n = 3e7, 480 MB per pass: plain stores lose 8 %)
     auto flush_stage = [&]() {
         for (int b = 0; b < staged; ++b) {
-            const int64_t r = stage_row0 + (int64_t)b * stride;
+            const int64_t r = stage_row_s[wave][b];
             const int64_t v = r * kOwn - kLead + lane;
             const bool own = v >= 0 && v < nvec && lane >= kLead && lane < kLead + kOwn;
             T xs[N], gs[N];
@@ -1438,7 +1439,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             if (!(p.debug_skip & 64)) {
                 // the trial point and its gradient into this wave's LDS slice (every lane: the slice is private to
                 // the wave, no barrier); they reach the spare slot's tiles in flush_stage()
-                if (staged == 0) stage_row0 = row;
+                if (lane == 0) stage_row_s[wave][staged] = row;
                 char *sl = stage + (size_t)staged * (kStageTiles * kTileBytes) + toff;
                 store16(reinterpret_cast<T *>(sl), xn);
                 if constexpr (kWriteG) store16(reinterpret_cast<T *>(sl + kTileBytes), gn);
@@ -1509,12 +1510,31 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     int64_t row = (int64_t)blockIdx.x * kWaves + wave;
     auto in_range = [&](int64_t r) { return r < rows ? r : rows - 1; };   // (past the end: the last row again, unconditionally)
     if constexpr (SETS == 1) {
+        // The rows that do not fill a last round of all waves go to the blocks of the EVEN XCDs first (block b runs on XCD
+        // b mod 8): per-wave clocks show the odd XCDs 3 % behind the even ones on every MI355X seen, and a 40th row on
+        // one of their waves is what the kernel ends on.  (A guess about the machine that costs nothing when it is wrong:
+        // somebody has to take those rows.)
+        const int64_t full = rows / stride, rem = rows - full * stride;
+        const int xcd = (int)(blockIdx.x & 7), per = (int)(blockIdx.x >> 3);
+        const int64_t even_blocks = (int64_t)gridDim.x / 2;
+        // (a bijection of the blocks only when the grid is a multiple of 8: otherwise the plain order)
+        const int64_t rank = (p.leftover_even && gridDim.x % 8 == 0)
+                                 ? ((xcd & 1) ? even_blocks + (xcd >> 1) + 4 * (int64_t)per : (xcd >> 1) + 4 * (int64_t)per)
+                                 : (int64_t)blockIdx.x;
+        auto row_at = [&](int64_t i) -> int64_t {
+            if (i < full) return i * stride + (int64_t)blockIdx.x * kWaves + wave;
+            const int64_t r = rank * kWaves + wave;
+            return (i == full && r < rem) ? full * stride + r : rows;
+        };
+        int64_t it = 0;
+        row = row_at(0);
         issue(in_range(row), xA, gA);
         if ((p.debug_skip & 1024) && blockIdx.x < 1024) { if (lane == 0) g_dev_wave_times[(blockIdx.x * kWaves + wave) * 2] = wall_clock64(); }
         while (row < row_end) {
-            compute(row, byte_offset(row), xA, gA, in_range(row + stride));
+            const int64_t next = row_at(it + 1);
+            compute(row, byte_offset(row), xA, gA, in_range(next));
             if (staged >= stage_rows) flush_stage();
-            row += stride;
+            ++it; row = next;
         }
     } else if constexpr (DZO_PP_REFILL != 0) {
         // (Where the refill requests end up is the compiler's business: with the exit between the two halves it sinks
@@ -2752,6 +2772,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     // (two blocks per CU with one register set per wave: half the LDS each)
     const bool one_set = point_one_set<T>(o) && k > 0;
     fp.prio = one_set ? (tune("DZO_TUNE_POINT_PRIO", 1) != 0 ? 1 : 0) : 0;   // (two waves per SIMD only; see the kernel)
+    fp.leftover_even = tune("DZO_TUNE_POINT_LEFTOVER_EVEN", 1) != 0 ? 1 : 0;
     const int stage_tiles = (k == 0 || DZO_PP_REGRAD == 0) ? 2 : 1;      // tiles staged per row: the point, and its gradient where the kernel writes it
     const int stage_max = (one_set ? 72 : 144) / (4 * stage_tiles);        // KiB of LDS per block / (waves x KiB per staged row)
     fp.stage_rows = tune("DZO_TUNE_POINT_STAGE_ROWS", 16);
