@@ -39,24 +39,34 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 
 
 
 # ------------------------------------------------------------------------------ inputs
-def pcg32_uniform(n, seed):
-    """Vectorised PCG32 XSH-RR stream with the reference's seeding (legacy/PCG.jl:7-22):
-    u_i = 2^-32 * extract(state_i), state_0 = advance(inc + seed)."""
-    mult = np.uint64(0x5851F42D4C957F2D)
-    inc = np.uint64(0x14057B7EF767814F)
-    block = 1 << 16
-    with np.errstate(over="ignore"):
-        # A_i, C_i with state_i = A_i * state_0 + C_i  (mod 2^64), i < block
+_PCG_TABLE = {}
+
+
+def _pcg_table(block):
+    """A_i, C_i with state_i = A_i * state_0 + C_i (mod 2^64), i <= block; built once per process."""
+    if block not in _PCG_TABLE:
         A = np.empty(block + 1, np.uint64)
         Cc = np.empty(block + 1, np.uint64)
-        A[0], Cc[0] = np.uint64(1), np.uint64(0)
         a, c = 1, 0
         M = (1 << 64) - 1
-        mi, ii = int(mult), int(inc)
+        mi, ii = 0x5851F42D4C957F2D, 0x14057B7EF767814F
+        A[0], Cc[0] = np.uint64(1), np.uint64(0)
         for i in range(1, block + 1):
             a = (a * mi) & M
             c = (c * mi + ii) & M
             A[i], Cc[i] = a, c
+        _PCG_TABLE[block] = (A, Cc)
+    return _PCG_TABLE[block]
+
+
+def pcg32_uniform(n, seed):
+    """Vectorised PCG32 XSH-RR stream with the reference's seeding (legacy/PCG.jl:7-22):
+    u_i = 2^-32 * extract(state_i), state_0 = advance(inc + seed)."""
+    block = 1 << 16 if n > 4096 else 1 << 12
+    A, Cc = _pcg_table(block)
+    M = (1 << 64) - 1
+    mi, ii = 0x5851F42D4C957F2D, 0x14057B7EF767814F
+    with np.errstate(over="ignore"):
         state0 = np.uint64(((ii + seed) * mi + ii) & M)
         out = np.empty(n, np.float64)
         pos = 0
@@ -395,21 +405,27 @@ def launch_check(args):
     return 0
 
 
-def secondary_workload(args):
-    """Configs 2, 4, 5 of BASELINE.json: same JSON shape, their own metric strings."""
+def secondary_workload(args, inproc=None):
+    """Configs 2, 4, 5 of BASELINE.json: same JSON shape, their own metric strings.  `inproc` = (dzo, sharding, info):
+    called from the default line at N = 1 on the already initialised library (no CPU baseline, the dict is returned
+    instead of printed)."""
     import importlib
     cpu_line = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
-        # first of all: the CPU baseline (worker processes for the batched one), while no GPU context exists yet
-        cn = {"bfgs_dense": 4096, "bfgs_batched": 256, "lbfgs_lse_f32": 1_000_000}.get(args.workload, args.n) if args.n == 10_000_000 else args.n
-        cpu_line = cpu_baseline_secondary(args.workload, cn, m=(10 if args.m == 20 else args.m),
-                                          A=quadratic_matrix(cn) if args.workload == "bfgs_dense" else None)
-    import torch
-    world, rank, local = _dist_setup(args.gpus)
-    from dzo_loader import dzo
-    dzo.init(local)
-    sharding = importlib.import_module("dzoptimization_jl_amd.sharding")
-    info = dzo.device_info()
+    if inproc is not None:
+        dzo, sharding, info = inproc
+        world, rank = 1, 0
+    else:
+        if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+            # first of all: the CPU baseline (worker processes for the batched one), while no GPU context exists yet
+            cn = {"bfgs_dense": 4096, "bfgs_batched": 256, "lbfgs_lse_f32": 1_000_000}.get(args.workload, args.n) if args.n == 10_000_000 else args.n
+            cpu_line = cpu_baseline_secondary(args.workload, cn, m=(10 if args.m == 20 else args.m),
+                                              A=quadratic_matrix(cn) if args.workload == "bfgs_dense" else None)
+        import torch
+        world, rank, local = _dist_setup(args.gpus)
+        from dzo_loader import dzo
+        dzo.init(local)
+        sharding = importlib.import_module("dzoptimization_jl_amd.sharding")
+        info = dzo.device_info()
     out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     if args.workload == "bfgs_dense":
@@ -612,6 +628,8 @@ def secondary_workload(args):
                                  "kernel_events": "separate untimed stretch of the same loop",
                                  "note": "launch-latency-bound at this size: the launches of one direction move 168 MB"},
                     "kernels": kern})
+    if inproc is not None:
+        return out
     if rank == 0:
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
@@ -619,6 +637,38 @@ def secondary_workload(args):
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+# the other BASELINE configs inside the default line (N = 1): (workload, timed steps, warm-up) -- the settings of the
+# tracked profiles/rNN_bench_<workload>.json lines, so that the driver's own run carries them too
+SECONDARY_IN_DEFAULT_LINE = (("bfgs_dense", 50, 5), ("lbfgs_lse_f32", 50, 5), ("adgd", 200, 10), ("bfgs_batched", 50, 5))
+
+
+def secondary_in_line(args, dzo, sharding, info):
+    """The default N = 1 line's `secondary` object: configs 2, 4, 5 and AdGD measured in this process AFTER the headline's
+    timed region, two-pass leg and CPU baseline (nothing of it is part of `value`).  Each entry is the workload's own
+    line (python3 bench.py --workload W) without its CPU baseline; a failure is reported, never fatal to the line."""
+    import copy
+    res = {}
+    for w, steps, warm in SECONDARY_IN_DEFAULT_LINE:
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.gpus = w, steps, warm, 1
+        t0 = time.perf_counter()
+        try:
+            o = secondary_workload(a, inproc=(dzo, sharding, info))
+            keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "kernels") if k in o}
+            for k in ("update_plus_direction",):
+                if k in o:
+                    keep[k] = o[k]
+            keep["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+            res[w] = keep
+        except Exception as e:                                  # noqa: BLE001 -- reported in the line
+            res[w] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                dzo.synchronize()
+            except Exception:                                   # noqa: BLE001
+                pass
+    return res
 
 
 def _two_pass_leg(dzo, n, m, esize, args):
@@ -686,6 +736,8 @@ def main():
     ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32", "adgd", "launch_check"],
                     help="lbfgs = BASELINE configs[2] (the headline; default). The others are the remaining "
                          "BASELINE configs, reported as secondary lines.")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default line at N = 1: skip the `secondary` object (configs 2, 4, 5 and AdGD measured after the headline)")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
     ap.add_argument("--batched-steps", type=int, default=0,
                     help="N > 1: timed synchronous steps of the config-5 `batched` object (default: max(--steps, 100))")
@@ -841,6 +893,11 @@ def main():
                                          f"steps to fill the history, then {args.cpu_steps} timed step!() calls with OpenMP x{threads} "
                                          f"(= the host cores this job may use) and {args.cpu_steps_single} more on one core"
                                          + ("" if cn == n else f"; rates scaled by {cn}/{n}")}
+    if world == 1 and not args.no_cpu_baseline and not args.no_secondary and n == 10_000_000 and m == 20:
+        # the remaining BASELINE configs, measured by whoever runs the default line (the full default line only: the
+        # profiling / A-B commands all pass --no-cpu-baseline and stay as they were)
+        opt.close()
+        out["secondary"] = secondary_in_line(args, dzo, sharding, info)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -204,7 +204,8 @@ ABI = {
     "dzo_bfgs_batch_step": [_vp, _i32, _P(_i32)], "dzo_bfgs_batch_get_ptr": [_vp, _i32, _P(_vp)],
     "dzo_bfgs_batch_count_active": [_vp, _P(_i64)],
     "dzo_bfgs_batch_create_on": [_i32, _i32, _i64, _i64, _i32, _vp, _dbl, _P(_vp)], "dzo_bfgs_batch_device": [_vp, _P(_i32)],
-    "dzo_bfgs_batch_create_problem": [_vp, _i64, _vp, _dbl, _i32, _P(_vp)], "dzo_bfgs_batch_set_max_increases": [_vp, _i32],
+    "dzo_bfgs_batch_create_problem": [_vp, _i64, _vp, _dbl, _i32, _P(_vp)],
+    "dzo_bfgs_batch_create_problem_matrices": [_vp, _i64, _vp, _i64, _vp, _dbl, _i32, _P(_vp)], "dzo_bfgs_batch_set_max_increases": [_vp, _i32],
     "dzo_comm_unique_id": [_vp], "dzo_comm_init_rank": [_vp, _i32, _i32, _P(_vp)],
     "dzo_comm_init_all": [_P(_i32), _i32, _P(_vp)], "dzo_comm_destroy": [_vp],
     "dzo_comm_info": [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i64)],
@@ -902,10 +903,11 @@ def symv_(out, H, v):
 class BatchedBFGS:
     """B independent ``BFGSOptimizer`` instances on one device (config 5)."""
 
-    def __init__(self, problem_kind, x0, initial_step_length, device=None):
+    def __init__(self, problem_kind, x0, initial_step_length, device=None, matrices=None):
         """``device``: the GPU this shard lives on (default: the device selected with ``init``); a host that
         drives several shards from one process passes each shard's device and a :class:`Comm` built with
-        ``Comm.init_all``."""
+        ``Comm.init_all``.  ``matrices`` (B x n x n, each symmetric; with a QUADRATIC ``Problem``): instance b
+        minimises 1/2 x'A_b x instead of sharing the problem's A (dzo_bfgs_batch_create_problem_matrices)."""
         _need_init()
         if device is not None:
             init(int(device))                           # x0 is uploaded to that device
@@ -914,7 +916,17 @@ class BatchedBFGS:
         self.dtype = x0.dtype
         self._x0 = x0
         h = C.c_void_p()
-        if isinstance(problem_kind, Problem):
+        if matrices is not None:
+            assert isinstance(problem_kind, Problem), "per-instance matrices need a QUADRATIC Problem (n, dtype, decorators)"
+            self.problem = problem_kind
+            assert self.problem.n == self.n and self.problem.dtype == self.dtype
+            if not isinstance(matrices, DeviceArray):   # symmetric, so the row-major host layout IS column-major
+                matrices = DeviceArray.from_host(np.ascontiguousarray(matrices, dtype=self.dtype))
+            assert tuple(matrices.shape) == (self.batch, self.n, self.n), matrices.shape
+            self._matrices = matrices                   # the caller's array must outlive the batch
+            _check(lib().dzo_bfgs_batch_create_problem_matrices(self.problem.h, self.batch, matrices.ptr, self.n * self.n, x0.ptr,
+                                                                initial_step_length, -1 if device is None else int(device), C.byref(h)))
+        elif isinstance(problem_kind, Problem):
             # objective, shared matrix and decorators from a problem handle (dzo_bfgs_batch_create_problem)
             self.problem = problem_kind
             assert self.problem.n == self.n and self.problem.dtype == self.dtype

@@ -32,11 +32,13 @@ namespace dzo {
 constexpr int kHalf = kBlock / 2;
 
 // the objective of every instance: chained Rosenbrock (n = 2: the README's 2-D Rosenbrock) or the dense
-// quadratic 1/2 x'Ax with ONE symmetric A shared by all instances, plus the decorators of
+// quadratic 1/2 x'Ax with one symmetric A shared by all instances (A_stride = 0) or one A per instance
+// (A_stride = elements between consecutive instances' matrices), plus the decorators of
 // legacy/DZOptimization.jl:219-296 and QuadraticLineSearch.max_increases (:181-188)
 struct BatchObjective {
     int kind = DZO_PROBLEM_ROSENBROCK_CHAIN;
     const void *A = nullptr;            // QUADRATIC: n x n column-major, device
+    int64_t A_stride = 0;               // 0: shared by all instances; else instance b's matrix starts at A + b * A_stride
     double l2 = 0;                      // L2RegularizationWrapper / L2GradientWrapper lambda (:225-249); 0 = off
     int bg_on = 0; double bg_lo = 0, bg_hi = 0;       // UniformBoxGradientWrapper (:275-296)
     int cons_on = 0; double cons_lo = 0, cons_hi = 0; // UniformBoxConstraint (:258-272) as constraint_function!
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch
     const int np = (n + 1) & ~1;
     Inst<T> in;
     in.ob = st.ob;
+    if (in.ob.A) in.ob.A = (const T *)in.ob.A + b * in.ob.A_stride;     // this instance's matrix
     in.n = n; in.lane = threadIdx.x & 63;
     in.x = lds; in.g = lds + np; in.d = lds + 2 * np; in.dg = lds + 3 * np; in.dx = lds + 4 * np;
     in.y = lds + 5 * np; in.yref = lds + 6 * np; in.tv = lds + 7 * np;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += kBlock) { in.x[i] = in.y[i]; gold[i] = in.g[i]; }
         __syncthreads();
-        block_gradient<T>(st.ob, n, in.g, in.x);
+        block_gradient<T>(in.ob, n, in.g, in.x);
         for (int i = threadIdx.x; i < n; i += kBlock) in.dg[i] = in.g[i] - gold[i];
         __syncthreads();
 
@@ -540,9 +543,10 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void batch_init_kernel(BatchState st, double initial_step_length) {
     extern __shared__ __attribute__((aligned(16))) char init_smem[];
     __shared__ double red[4];
-    const BatchObjective ob = st.ob;
+    BatchObjective ob = st.ob;
     const int n = (int)st.n;
     const int64_t b = blockIdx.x;
+    if (ob.A) ob.A = (const T *)ob.A + b * ob.A_stride;                 // this instance's matrix
     T *x = (T *)st.x + b * n;
     T *xs = reinterpret_cast<T *>(init_smem);                  // the (projected) starting point, shared
     T *g = (T *)st.g + b * n, *d = (T *)st.d + b * n, *dx = (T *)st.dx + b * n, *dg = (T *)st.dg + b * n;
@@ -660,7 +664,7 @@ static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_
     const int32_t problem_kind = ob.kind;
     DZO_REQUIRE(problem_kind == DZO_PROBLEM_ROSENBROCK_CHAIN || (problem_kind == DZO_PROBLEM_ROSENBROCK2D && n == 2) ||
                     (problem_kind == DZO_PROBLEM_QUADRATIC && ob.A),
-                DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective and the dense quadratic with a shared A");
+                DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective and the dense quadratic (one shared A or one A per instance)");
     DZO_REQUIRE(batch >= 1, DZO_ERR_INVALID, "batch must be >= 1");
     DZO_TRY(require_same_backend("batched BFGSOptimizer", "src/DZOptimization.jl:363-364", x0_dev, "initial_points", nullptr, ""));
     DZO_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024, DZO_ERR_UNSUPPORTED,
@@ -720,6 +724,24 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
     return batch_create_impl(ob, batch, n, dtype, x0_dev, initial_step_length, out);
 }
 
+// device < 0: the device the calling thread selected; otherwise the shard is created on that device
+static int32_t batch_create_on_device(const BatchObjective &ob, int64_t batch, int64_t n, int32_t dtype, const void *x0_dev,
+                                           double initial_step_length, int32_t device, dzo_bfgs_batch_t *out) {
+    if (device < 0) return batch_create_impl(ob, batch, n, dtype, x0_dev, initial_step_length, out);
+    int count = 0;
+    DZO_HIP(hipGetDeviceCount(&count));
+    DZO_REQUIRE(device < count && device < kMaxDevices, DZO_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+    const int prev = ctx().ready ? ctx().device : -1;
+    DZO_TRY(dzo_init(device));
+    int32_t rc;
+    {
+        DeviceScope scope(device);
+        rc = batch_create_impl(ob, batch, n, dtype, x0_dev, initial_step_length, out);
+    }
+    if (prev >= 0 && prev != device) (void)dzo_init(prev);
+    return rc;
+}
+
 // The batched constructor from a problem handle: kind, n, dtype, the shared matrix A of the quadratic and
 // the decorators (dzo_problem_set_l2 / set_box_gradient / set_box_constraint) are taken from it at
 // creation time.  device < 0: the device the calling thread selected.
@@ -732,19 +754,27 @@ int32_t dzo_bfgs_batch_create_problem(dzo_problem_t problem, int64_t batch, cons
     ob.l2 = problem->l2;
     ob.bg_on = problem->bg_on ? 1 : 0; ob.bg_lo = problem->bg_lo; ob.bg_hi = problem->bg_hi;
     ob.cons_on = problem->cons_on ? 1 : 0; ob.cons_lo = problem->cons_lo; ob.cons_hi = problem->cons_hi;
-    if (device < 0) return batch_create_impl(ob, batch, problem->n, problem->dtype, x0_dev, initial_step_length, out);
-    int count = 0;
-    DZO_HIP(hipGetDeviceCount(&count));
-    DZO_REQUIRE(device < count && device < kMaxDevices, DZO_ERR_INVALID, "device %d out of range [0,%d)", device, count);
-    const int prev = ctx().ready ? ctx().device : -1;
-    DZO_TRY(dzo_init(device));
-    int32_t rc;
-    {
-        DeviceScope scope(device);
-        rc = batch_create_impl(ob, batch, problem->n, problem->dtype, x0_dev, initial_step_length, out);
-    }
-    if (prev >= 0 && prev != device) (void)dzo_init(prev);
-    return rc;
+    return batch_create_on_device(ob, batch, problem->n, problem->dtype, x0_dev, initial_step_length, device, out);
+}
+
+// "Run multiple optimizers in parallel" (README.md:12) with a DIFFERENT quadratic per instance: the problem handle
+// gives kind (QUADRATIC), n, dtype and the decorators; instance b minimises 1/2 x'A_b x with A_b = the n x n
+// column-major symmetric matrix at matrices_dev + b * matrix_stride elements (matrix_stride >= n*n; the caller owns
+// the array and keeps it alive and unchanged while the batch exists).
+int32_t dzo_bfgs_batch_create_problem_matrices(dzo_problem_t problem, int64_t batch, const void *matrices_dev, int64_t matrix_stride,
+                                               const void *x0_dev, double initial_step_length, int32_t device, dzo_bfgs_batch_t *out) {
+    DZO_REQUIRE(problem && out && matrices_dev, DZO_ERR_INVALID, "null argument");
+    DZO_REQUIRE(problem->kind == DZO_PROBLEM_QUADRATIC, DZO_ERR_INVALID, "per-instance matrices belong to the quadratic objective");
+    DZO_REQUIRE(matrix_stride >= problem->n * problem->n, DZO_ERR_INVALID, "matrix_stride %lld < n*n = %lld",
+                (long long)matrix_stride, (long long)(problem->n * problem->n));
+    DZO_TRY(require_init());
+    DZO_TRY(require_same_backend("batched BFGSOptimizer", "src/DZOptimization.jl:363-364", matrices_dev, "matrices", nullptr, ""));
+    BatchObjective ob;
+    ob.kind = problem->kind; ob.A = matrices_dev; ob.A_stride = matrix_stride;
+    ob.l2 = problem->l2;
+    ob.bg_on = problem->bg_on ? 1 : 0; ob.bg_lo = problem->bg_lo; ob.bg_hi = problem->bg_hi;
+    ob.cons_on = problem->cons_on ? 1 : 0; ob.cons_lo = problem->cons_lo; ob.cons_hi = problem->cons_hi;
+    return batch_create_on_device(ob, batch, problem->n, problem->dtype, x0_dev, initial_step_length, device, out);
 }
 
 // QuadraticLineSearch.max_increases (legacy :181-188, :138-151) of every instance; 0 = no cap

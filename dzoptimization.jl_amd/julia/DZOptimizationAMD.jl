@@ -575,11 +575,15 @@ mutable struct BatchedBFGSOptimizer{T}
     handle::Ptr{Cvoid}
     batch::Int
     n::Int
-    function BatchedBFGSOptimizer(kind::Union{Integer,BuiltinProblem}, x0::HipVector{T}, n::Integer, step::Real; device::Union{Nothing,Integer}=nothing) where {T}
+    function BatchedBFGSOptimizer(kind::Union{Integer,BuiltinProblem}, x0::HipVector{T}, n::Integer, step::Real; device::Union{Nothing,Integer}=nothing,
+                                  matrices::Union{Nothing,HipVector{T}}=nothing) where {T}
         ensure_init()
         h = Ref{Ptr{Cvoid}}(C_NULL)
         batch = div(length(x0), n)
-        if kind isa BuiltinProblem      # objective, shared A of the quadratic and the decorators from the problem handle
+        if matrices !== nothing         # one symmetric n x n matrix per instance (instance-major); the caller keeps `matrices` alive
+            check(ccall((:dzo_bfgs_batch_create_problem_matrices, libdzo), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cdouble, Cint, Ref{Ptr{Cvoid}}),
+                        kind.handle, batch, matrices.ptr, n * n, x0.ptr, step, device === nothing ? -1 : device, h))
+        elseif kind isa BuiltinProblem      # objective, shared A of the quadratic and the decorators from the problem handle
             check(ccall((:dzo_bfgs_batch_create_problem, libdzo), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cdouble, Cint, Ref{Ptr{Cvoid}}),
                         kind.handle, batch, x0.ptr, step, device === nothing ? -1 : device, h))
         elseif device === nothing

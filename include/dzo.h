@@ -431,6 +431,13 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
  * the device the calling thread selected (dzo_init). */
 int32_t dzo_bfgs_batch_create_problem(dzo_problem_t problem, int64_t batch, const void *x0_dev,
                                       double initial_step_length, int32_t device, dzo_bfgs_batch_t *out);
+/* The same with a DIFFERENT quadratic per instance ("run multiple optimizers in parallel", README.md:12, each with its own
+ * objective): the handle gives kind (DZO_PROBLEM_QUADRATIC), n, dtype and the decorators; instance b minimises
+ * 1/2 x'A_b x with A_b the symmetric n x n column-major matrix at matrices_dev + b * matrix_stride ELEMENTS
+ * (matrix_stride >= n*n).  The caller owns matrices_dev and keeps it alive and unchanged while the batch exists. */
+int32_t dzo_bfgs_batch_create_problem_matrices(dzo_problem_t problem, int64_t batch, const void *matrices_dev,
+                                               int64_t matrix_stride, const void *x0_dev,
+                                               double initial_step_length, int32_t device, dzo_bfgs_batch_t *out);
 /* QuadraticLineSearch.max_increases (legacy/DZOptimization.jl:181-188, :138-151) of every instance; 0 = no cap */
 int32_t dzo_bfgs_batch_set_max_increases(dzo_bfgs_batch_t b, int32_t max_increases);
 int32_t dzo_bfgs_batch_destroy(dzo_bfgs_batch_t b);

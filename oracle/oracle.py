@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdzo_oracle.so")
+_LIB_PATH = os.environ.get("DZO_ORACLE_LIB") or os.path.join(_HERE, "libdzo_oracle.so")   # (DZO_ORACLE_LIB: the sanitizer build)
 
 ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE = 0, 1, 2, 3
 DOT_SEQUENTIAL, DOT_EIGHT_LANE, DOT_WIDE = 0, 1, 2

@@ -220,17 +220,30 @@ def test_each_batched_step_matches_per_instance_oracle_on_identical_state(n, B, 
     assert dzo.STEP_BFGS in types
 
 
-@pytest.mark.parametrize("case", ["quadratic", "rosen_l2", "rosen_box", "rosen_max_increases", "quadratic_all"])
+def _instance_matrix(n, b, r=8):
+    """A_b = D_b + U_b U_b'/r (SPD, symmetric bit for bit), a different one per instance."""
+    dvec = 1.0 + (9.0 + 30.0 * b) * orc.pcg_fill(n, 20 + b)
+    U = (orc.pcg_fill(n * r, 40 + b) - 0.5).reshape(n, r, order="F")
+    A = (U @ U.T) / r
+    A[np.diag_indices(n)] += dvec
+    return np.asfortranarray(0.5 * (A + A.T))
+
+
+@pytest.mark.parametrize("case", ["quadratic", "rosen_l2", "rosen_box", "rosen_max_increases", "quadratic_all",
+                                  "quadratic_per_instance", "quadratic_per_instance_all"])
 def test_batched_objectives_and_decorators_match_per_instance_oracle(case):
-    """Batched breadth: the dense quadratic with a shared A, the L2 / box-gradient / box-constraint
+    """Batched breadth: the dense quadratic with a shared A or with one A per instance ("run multiple optimizers
+    in parallel", README.md:12, each on its own objective), the L2 / box-gradient / box-constraint
     decorators (legacy/DZOptimization.jl:219-296) and QuadraticLineSearch.max_increases (:181-188),
     each step from the oracle's state."""
     n, B, steps = 64, 4, 14
-    kw, max_inc = {}, 0
+    kw, max_inc, mats = {}, 0, None
     if case.startswith("quadratic"):
         A = orc.quadratic_matrix(n)
         kind_o, kind_d, kw = orc.QUADRATIC, dzo.QUADRATIC, dict(A=A)
         X0 = np.stack([orc.pcg_fill(n, 4 + b) - 0.5 for b in range(B)])
+        if "per_instance" in case:
+            mats = [_instance_matrix(n, b) for b in range(B)]
     else:
         kind_o, kind_d = orc.ROSENBROCK_CHAIN, dzo.ROSENBROCK_CHAIN
         X0 = np.stack([orc.pcg_fill(n, 1000 + b) for b in range(B)])
@@ -238,13 +251,19 @@ def test_batched_objectives_and_decorators_match_per_instance_oracle(case):
         kw.update(l2=0.05)
     if case == "rosen_box":
         kw.update(box_constraint=(0.05, 0.9), box_gradient=(0.05, 0.9))
-    if case == "quadratic_all":
+    if case in ("quadratic_all", "quadratic_per_instance_all"):
         kw.update(l2=0.01, box_constraint=(-0.4, 0.3), box_gradient=(-0.4, 0.3))
     if case == "rosen_max_increases":
         max_inc = 1
     prob_d = dzo.Problem(kind_d, n, **kw)
-    batch = dzo.BatchedBFGS(prob_d, X0, 1.0)
-    refs = [orc.BFGS(orc.Problem(kind_o, n, **kw), X0[b].copy(), 1.0) for b in range(B)]
+    if mats is None:
+        batch = dzo.BatchedBFGS(prob_d, X0, 1.0)
+        refs = [orc.BFGS(orc.Problem(kind_o, n, **kw), X0[b].copy(), 1.0) for b in range(B)]
+    else:                                                     # the handle's own A is NOT what the instances minimise
+        batch = dzo.BatchedBFGS(prob_d, X0, 1.0, matrices=np.stack(mats))
+        refs = [orc.BFGS(orc.Problem(kind_o, n, **dict(kw, A=mats[b])), X0[b].copy(), 1.0) for b in range(B)]
+        f0 = batch.current_objective_value.to_host()
+        assert len(set(np.round(f0 / np.abs(f0).max(), 6))) == B      # really B different objectives
     if max_inc:
         batch.set_max_increases(max_inc)
         for r in refs:
@@ -276,7 +295,39 @@ def test_batched_objectives_and_decorators_match_per_instance_oracle(case):
             _check_step(one, refs[b], f_before[b], (case, it, b))
             moved += int(not refs[b].has_terminated)
     assert moved >= steps                                     # the comparison really covered moving instances
-    if "box" in case or case == "quadratic_all":
+    if "box" in case or case.endswith("_all"):
         lo, hi = kw["box_constraint"]
         X = batch.current_point.to_host()
         assert X.min() >= lo and X.max() <= hi
+
+
+def test_per_instance_matrices_constructor_rejects_what_it_cannot_run():
+    """dzo_bfgs_batch_create_problem_matrices: quadratic handles only, a stride that holds a matrix, device memory
+    (the backend assert of src/DZOptimization.jl:363-364 applies to the matrices as to every other array)."""
+    import ctypes as C
+    n, B = 8, 3
+    X0 = dzo.DeviceArray.from_host(np.stack([orc.pcg_fill(n, b) for b in range(B)]))
+    mats = np.stack([_instance_matrix(n, b) for b in range(B)])
+    mats_dev = dzo.DeviceArray.from_host(mats)
+    quad = dzo.Problem(dzo.QUADRATIC, n, A=orc.quadratic_matrix(n))
+    h = C.c_void_p()
+    with pytest.raises(dzo.DzoError):                                       # not a quadratic
+        dzo._check(dzo.lib().dzo_bfgs_batch_create_problem_matrices(dzo.Problem(dzo.ROSENBROCK_CHAIN, n).h, B, mats_dev.ptr, n * n,
+                                                                    X0.ptr, 1.0, -1, C.byref(h)))
+    with pytest.raises(dzo.DzoError):                                       # stride shorter than a matrix
+        dzo._check(dzo.lib().dzo_bfgs_batch_create_problem_matrices(quad.h, B, mats_dev.ptr, n * n - 1, X0.ptr, 1.0, -1, C.byref(h)))
+    with pytest.raises(AssertionError):                                     # host memory
+        dzo._check(dzo.lib().dzo_bfgs_batch_create_problem_matrices(quad.h, B, mats.ctypes.data, n * n, X0.ptr, 1.0, -1, C.byref(h)))
+    # a padded stride: the same run as the dense array
+    pad = np.zeros((B, n * n + 5))
+    pad[:, :n * n] = mats.reshape(B, -1)
+    pad_dev = dzo.DeviceArray.from_host(pad)
+    dzo._check(dzo.lib().dzo_bfgs_batch_create_problem_matrices(quad.h, B, pad_dev.ptr, n * n + 5, X0.ptr, 1.0, -1, C.byref(h)))
+    a = dzo.BatchedBFGS(quad, X0.to_host(), 1.0, matrices=mats)
+    a.step(5, poll=False)
+    dzo._check(dzo.lib().dzo_bfgs_batch_step(h, 5, None))
+    p = C.c_void_p()
+    dzo._check(dzo.lib().dzo_bfgs_batch_get_ptr(h, 0, C.byref(p)))
+    xb = dzo.DeviceArray((B, n), np.float64, ptr=p.value, owner=False).to_host()
+    assert np.array_equal(xb, a.current_point.to_host())
+    dzo._check(dzo.lib().dzo_bfgs_batch_destroy(h))
