@@ -426,7 +426,7 @@ int32_t dzo_bfgs_batch_create(int32_t problem_kind, int64_t batch, int64_t n, in
                               const void *x0_dev /* batch x n row-major */,
                               double initial_step_length, dzo_bfgs_batch_t *out);
 /* From a problem handle: chained Rosenbrock, or the dense quadratic 1/2 x'Ax with ONE matrix A shared by
- * every instance; the decorators set on the handle (dzo_problem_set_l2 / set_box_gradient /
+ * every instance (one matrix per instance: dzo_bfgs_batch_create_problem_matrices below); the decorators set on the handle (dzo_problem_set_l2 / set_box_gradient /
  * set_box_constraint, legacy/DZOptimization.jl:219-296) are applied inside the step kernel.  device < 0:
  * the device the calling thread selected (dzo_init). */
 int32_t dzo_bfgs_batch_create_problem(dzo_problem_t problem, int64_t batch, const void *x0_dev,
