@@ -123,6 +123,13 @@ def device_info():
     return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
 
 
+def device_count() -> int:
+    """HIP devices visible to the process (no ``init`` needed, no context created)."""
+    v = C.c_int32()
+    _check(lib().dzo_device_count(C.byref(v)))
+    return v.value
+
+
 def synchronize():
     _check(lib().dzo_synchronize())
 
@@ -145,6 +152,7 @@ _P = C.POINTER
 # name -> argtypes; every function returns int32 except dzo_last_error / dzo_version
 ABI = {
     "dzo_init": [_i32], "dzo_shutdown": [], "dzo_device_info": [C.c_char_p, _i32, _P(_i32), _P(_i64)],
+    "dzo_device_count": [_P(_i32)],
     "dzo_synchronize": [],
     "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_unsealed_first_reads": [_P(_i64)], "dzo_profile_count": [_P(_i32)],
     "dzo_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_dbl)],
@@ -1152,6 +1160,6 @@ __all__ = [
     "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "Comm", "batches_all_done", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
     "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
     "norm2", "inv_norm", "negate_", "scale_",
-    "update_inverse_hessian_", "update_inverse_hessian_mfma_", "symv_", "init", "build", "lib", "device_info", "synchronize",
+    "update_inverse_hessian_", "update_inverse_hessian_mfma_", "symv_", "init", "build", "lib", "device_info", "device_count", "synchronize",
     "profile_enable", "profile_reset", "profile_table", "DzoError", "AssertionFailed",
 ]

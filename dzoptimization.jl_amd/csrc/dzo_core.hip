@@ -333,6 +333,16 @@ int32_t dzo_device_info(char *name, int32_t name_len, int32_t *compute_units, in
     return DZO_OK;
 }
 
+// the number of HIP devices this process sees (needs no dzo_init and creates no context: a host that drives one shard
+// per GPU sizes its loop with it)
+int32_t dzo_device_count(int32_t *count) {
+    DZO_REQUIRE(count, DZO_ERR_INVALID, "null argument");
+    int c = 0;
+    DZO_HIP(hipGetDeviceCount(&c));
+    *count = c;
+    return DZO_OK;
+}
+
 int32_t dzo_synchronize(void) {
     DZO_TRY(require_init());
     DZO_TRY(settle_all_optimizers());

@@ -100,6 +100,8 @@ int32_t dzo_shutdown(void);
 int32_t dzo_version(void);
 const char *dzo_last_error(void);
 int32_t dzo_device_info(char *name, int32_t name_len, int32_t *compute_units, int64_t *hbm_bytes);
+/* the number of HIP devices the process sees; needs no dzo_init (one shard per GPU from one process: dzo_comm_init_all) */
+int32_t dzo_device_count(int32_t *count);
 int32_t dzo_synchronize(void);
 
 /* Per-kernel HIP-event timing on the launching stream (bench.py's roofline leg).

@@ -1,5 +1,6 @@
-"""The plain-C consumer of include/dzo.h (examples/readme_rosenbrock.c = the reference's README
-example, README.md:25-41): it must compile and link against libdzo_hip.so with gcc alone
+"""The plain-C consumers of include/dzo.h (examples/readme_rosenbrock.c = the reference's README
+example, README.md:25-41; examples/batched_shards.c = one process driving a shard of independent optimizers on
+every visible GPU): they must compile and link against libdzo_hip.so with gcc alone
 (CPU test), and converge to (1, ..., 1) on a device (GPU test).  No Python, no PyTorch in
 that process: the C ABI is the product, the ctypes mirror only a second binding."""
 import os
@@ -11,19 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "dzoptimization.jl_amd")
 
 
-def _build(tmp_path):
+def _build(tmp_path, name="readme_rosenbrock"):
     import __graft_entry__ as entry
     entry.build()
-    exe = str(tmp_path / "readme_rosenbrock")
+    exe = str(tmp_path / name)
     cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "readme_rosenbrock.c"), "-L" + PKG, "-ldzo_hip",
-           "-Wl,-rpath," + PKG, "-o", exe]
+           os.path.join(ROOT, "examples", name + ".c"), "-L" + PKG, "-ldzo_hip",
+           "-Wl,-rpath," + PKG, "-lm", "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     return exe
 
 
-def test_c_example_compiles_and_links(tmp_path):
-    exe = _build(tmp_path)
+@pytest.mark.parametrize("name", ["readme_rosenbrock", "batched_shards"])
+def test_c_example_compiles_and_links(tmp_path, name):
+    exe = _build(tmp_path, name)
     assert os.path.exists(exe)
     # every dzo_* symbol the example needs is resolved by libdzo_hip.so
     out = subprocess.run(["nm", "-u", exe], check=True, capture_output=True, text=True).stdout
@@ -40,3 +42,14 @@ def test_c_example_runs_and_converges(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_batched_shards_example_runs_on_every_visible_gpu(tmp_path):
+    """examples/batched_shards.c: one host process, one shard of independent BFGS instances per visible GPU
+    (dzo_bfgs_batch_create_on), the convergence flag through dzo_comm_init_all + dzo_bfgs_batch_all_done
+    (SURVEY 8(b)/(e)'s single-process form).  On the 1-GPU box: one shard, a one-rank communicator."""
+    exe = _build(tmp_path, "batched_shards")
+    r = subprocess.run([exe, "48", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout and "all_done = 1" in r.stdout, r.stdout
