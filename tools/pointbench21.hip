@@ -16,7 +16,7 @@
 typedef double v2 __attribute__((ext_vector_type(2)));
 constexpr int R = 21;
 
-template <int SETS, int W, bool NTS, int SPIN, int BATCH>
+template <int SETS, int W, bool NTS, int SPIN, int BATCH, int CH = 1, bool BSYNC = false>
 __global__ __launch_bounds__(256, SETS == 1 ? 2 : 1) void sweep21(char *ring, long rows, long stream_bytes, double *sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long stride = (long)gridDim.x * 4;
@@ -30,11 +30,14 @@ __global__ __launch_bounds__(256, SETS == 1 ? 2 : 1) void sweep21(char *ring, lo
         for (int t = 0; t < R; ++t) r[t] = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(rb + (unsigned long)t * stream_bytes));
     };
     const long first = (long)blockIdx.x * 4 + wave;
-    auto finish_row = [&](long row, v2 s) {
-        const long it = (row - first) / stride;
+    // CH > 1: a wave takes CH CONSECUTIVE rows at a time (rows (c * waves + first) * CH + j), so that a burst of BATCH = CH
+    // rows is one contiguous piece of the written stream (4 CH KiB per block)
+    auto row_of = [&](long it) { return CH == 1 ? first + it * stride : ((it / CH) * stride + first) * CH + it % CH; };
+    auto finish_row = [&](long it, v2 s) {
         if (W && it % BATCH == BATCH - 1) {
+            if (BSYNC) __syncthreads();
             for (int b = 0; b < BATCH; ++b) {
-                const long r2 = row - (long)b * stride;
+                const long r2 = clampr(row_of(it - b));
                 char *wb = ring + (unsigned long)R * stream_bytes + (unsigned long)__builtin_amdgcn_readfirstlane((int)r2) * 1024 + lane * 16;
                 if (lane >= 1 && lane < 63) { if (NTS) __builtin_nontemporal_store(s, reinterpret_cast<v2 *>(wb)); else *reinterpret_cast<v2 *>(wb) = s; }
             }
@@ -46,35 +49,36 @@ __global__ __launch_bounds__(256, SETS == 1 ? 2 : 1) void sweep21(char *ring, lo
         for (int k = 0; k < SPIN; ++k) { s.x = __builtin_fma(v.x, 1.0000001, s.x); s.y = __builtin_fma(v.y, 0.9999999, s.y); }
         if (SPIN == 0) { s.x += v.x; s.y += v.y; }
     };
-    long row = first;
-    issue(clampr(row), A);
+    const long its = CH == 1 ? (rows - first + stride - 1) / stride : ((rows + CH - 1) / CH - first + stride - 1) / stride * CH;   // (CH > 1: whole chunks, clamped rows)
+    long it = 0;
+    issue(clampr(row_of(0)), A);
     if (SETS == 2) {
-        auto compute = [&](long rw, v2 *r) {
+        auto compute = [&](long i, v2 *r) {
             v2 s = {0, 0};
 #pragma unroll
             for (int t = 0; t < R; ++t) eat(r[t], s);
-            finish_row(rw, s);
+            finish_row(i, s);
         };
-        while (row < rows) {
-            issue(clampr(row + stride), B);
-            compute(row, A);
-            row += stride;
-            if (row >= rows) break;
-            issue(clampr(row + stride), A);
-            compute(row, B);
-            row += stride;
+        while (it < its) {
+            issue(clampr(row_of(it + 1)), B);
+            compute(it, A);
+            ++it;
+            if (it >= its) break;
+            issue(clampr(row_of(it + 1)), A);
+            compute(it, B);
+            ++it;
         }
     } else {
-        while (row < rows) {
-            const char *nb = base(clampr(row + stride));
+        while (it < its) {
+            const char *nb = base(clampr(row_of(it + 1)));
             v2 s = {0, 0};
 #pragma unroll
             for (int t = 0; t < R; ++t) {
                 eat(A[t], s);
                 A[t] = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(nb + (unsigned long)t * stream_bytes));   // refill behind its last reader
             }
-            finish_row(row, s);
-            row += stride;
+            finish_row(it, s);
+            ++it;
         }
     }
     if (acc == 1.2345e300) sink[0] = acc;
@@ -100,7 +104,13 @@ int main() {
 #define RUN(SETS, W, NTS, SPIN, BATCH) { double us = time_us([&] { hipLaunchKernelGGL((sweep21<SETS, W, NTS, SPIN, BATCH>), dim3(cus * (SETS == 1 ? 2 : 1)), dim3(256), 0, 0, ring, rows, stream_bytes, sink); }); \
         printf("%d set(s), %d wave(s)/SIMD: 21 tile reads + %d tile write (%s, bursts of %2d rows), %3d fma per vector: %7.1f us  %6.0f GB/s moved, %6.0f GB/s by (k+2) n T\n", \
                SETS, SETS == 1 ? 2 : 1, W, NTS ? "nt   " : "plain", BATCH, 2 * SPIN, us, (rd + W * wr1) / us / 1e3, 22.0 * n * 8 / us / 1e3); }
+#define RUNX(SETS, W, NTS, SPIN, BATCH, CH, BSYNC) { double us = time_us([&] { hipLaunchKernelGGL((sweep21<SETS, W, NTS, SPIN, BATCH, CH, BSYNC>), dim3(cus * (SETS == 1 ? 2 : 1)), dim3(256), 0, 0, ring, rows, stream_bytes, sink); }); \
+        printf("%d set(s): 21 reads + %d write (%s), bursts of %2d rows, %2d CONSECUTIVE rows per wave%s, %3d fma per vector: %7.1f us\n", \
+               SETS, W, NTS ? "nt   " : "plain", BATCH, CH, BSYNC ? ", block-synchronised bursts" : "", 2 * SPIN, us); }
     for (int rep = 0; rep < 2; ++rep) {
+        RUNX(1, 1, true, 0, 16, 16, false) RUNX(1, 1, true, 0, 16, 16, true) RUNX(1, 1, true, 0, 8, 8, false) RUNX(1, 1, true, 0, 4, 4, false)
+        RUNX(1, 0, true, 0, 16, 16, false) RUNX(1, 1, true, 48, 16, 16, false) RUNX(1, 1, false, 0, 16, 16, false)
+        // (bursts longer than the ~39 rows a wave has at n = 1e7 would simply never be written: BATCH <= 16 only)
         RUN(1, 0, true, 0, 16) RUN(1, 1, true, 0, 16) RUN(1, 1, false, 0, 16) RUN(1, 1, true, 0, 1)
         RUN(1, 1, true, 8, 16) RUN(1, 1, true, 24, 16) RUN(1, 1, true, 48, 16) RUN(1, 1, true, 96, 16)
         RUN(2, 0, true, 0, 16) RUN(2, 1, true, 0, 16) RUN(2, 1, true, 24, 16) RUN(2, 1, true, 48, 16) RUN(2, 1, true, 96, 16)
