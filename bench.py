@@ -788,11 +788,19 @@ def main():
         trials += opt.last_trials
         flag.update(opt.is_stuck)                       # global "everyone converged" flag
     dzo.synchronize()
+    el_local = time.perf_counter() - t0                 # this rank's own time, before it waits for the others
     _barrier(world)
     elapsed = time.perf_counter() - t0
     dzo.profile_enable(False)
 
     elapsed = sharding.max_over_ranks(elapsed)
+    # N > 1: every rank's own rate and trial count (the replicas start from different points, so their numbers of
+    # rejected first trials -- a second pass each -- differ: a slower rank shows here, with its reason)
+    per_rank = None
+    if world > 1:
+        per_rank = [{"rank": r,
+                     "step_calls_per_s": round(sharding.sum_over_ranks(args.steps / el_local if r == rank else 0.0), 2),
+                     "objective_evals": int(sharding.sum_over_ranks(float(trials) if r == rank else 0.0))} for r in range(world)]
     any_stuck = sharding.max_over_ranks(1.0 if opt.is_stuck else 0.0) > 0
 
     table = dzo.profile_table()
@@ -876,6 +884,7 @@ def main():
                                    f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",
                    "rccl_world_size": comm.nranks if comm is not None else None,
+                   "per_rank": per_rank,
                    "objective_evals_per_step": round(trials / args.steps, 3), "any_stuck": any_stuck,
                    "f_start": f_start, "f_end": opt.current_objective_value, "device": info["name"]},
         "roofline": roofline, "kernels": kernels,
