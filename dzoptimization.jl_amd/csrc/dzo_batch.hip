@@ -666,7 +666,8 @@ static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_
                     (problem_kind == DZO_PROBLEM_QUADRATIC && ob.A),
                 DZO_ERR_UNSUPPORTED, "batched mode implements the (chained) Rosenbrock objective and the dense quadratic (one shared A or one A per instance)");
     DZO_REQUIRE(batch >= 1, DZO_ERR_INVALID, "batch must be >= 1");
-    DZO_TRY(require_same_backend("batched BFGSOptimizer", "src/DZOptimization.jl:363-364", x0_dev, "initial_points", nullptr, ""));
+    DZO_TRY(require_same_backend("batched BFGSOptimizer", "src/DZOptimization.jl:363-364", x0_dev, "initial_points",
+                                 ob.A_stride ? ob.A : nullptr, "matrices"));     // (the caller's per-instance matrices; a shared A is the problem handle's own copy)
     DZO_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024, DZO_ERR_UNSUPPORTED,
                 "batched mode needs an even n in 2..1024 (got %lld)", (long long)n);
     dzo_bfgs_batch_s *b = new dzo_bfgs_batch_s();
@@ -767,10 +768,8 @@ int32_t dzo_bfgs_batch_create_problem_matrices(dzo_problem_t problem, int64_t ba
     DZO_REQUIRE(problem->kind == DZO_PROBLEM_QUADRATIC, DZO_ERR_INVALID, "per-instance matrices belong to the quadratic objective");
     DZO_REQUIRE(matrix_stride >= problem->n * problem->n, DZO_ERR_INVALID, "matrix_stride %lld < n*n = %lld",
                 (long long)matrix_stride, (long long)(problem->n * problem->n));
-    DZO_TRY(require_init());
-    DZO_TRY(require_same_backend("batched BFGSOptimizer", "src/DZOptimization.jl:363-364", matrices_dev, "matrices", nullptr, ""));
     BatchObjective ob;
-    ob.kind = problem->kind; ob.A = matrices_dev; ob.A_stride = matrix_stride;
+    ob.kind = problem->kind; ob.A = matrices_dev; ob.A_stride = matrix_stride;   // (backend assert: batch_create_impl, on the shard's device)
     ob.l2 = problem->l2;
     ob.bg_on = problem->bg_on ? 1 : 0; ob.bg_lo = problem->bg_lo; ob.bg_hi = problem->bg_hi;
     ob.cons_on = problem->cons_on ? 1 : 0; ob.cons_lo = problem->cons_lo; ob.cons_hi = problem->cons_hi;
