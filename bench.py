@@ -728,8 +728,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the two-pass (Gram + combine) roofline leg at N = 1")
     ap.add_argument("--cpu-dim", dest="cpu_n", type=int, default=None, help="n of the CPU sample (default: same n)")
-    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU steps on all cores")
-    ap.add_argument("--cpu-steps-single", type=int, default=5, help="timed CPU steps on one core")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU steps on all cores")
+    ap.add_argument("--cpu-steps-single", type=int, default=8, help="timed CPU steps on one core (the whole CPU leg: about 10 s)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--kernel-events", type=int, default=1, choices=[1, 2],
                     help="HIP events in the timed region: 1 = the two-loop (roofline) kernels only, 2 = every kernel")
