@@ -23,7 +23,7 @@ def _build(tmp_path, name="readme_rosenbrock"):
     return exe
 
 
-@pytest.mark.parametrize("name", ["readme_rosenbrock", "batched_shards"])
+@pytest.mark.parametrize("name", ["readme_rosenbrock", "batched_shards", "bench_lbfgs"])
 def test_c_example_compiles_and_links(tmp_path, name):
     exe = _build(tmp_path, name)
     assert os.path.exists(exe)
@@ -53,3 +53,28 @@ def test_c_batched_shards_example_runs_on_every_visible_gpu(tmp_path):
     r = subprocess.run([exe, "48", "16"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout and "all_done = 1" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_c_bench_driver_runs_the_same_trajectory_as_the_python_binding(tmp_path):
+    """examples/bench_lbfgs.c: the headline workload through the C ABI alone (own PCG32, own host loop).  Same inputs, same
+    library -> after the same number of steps the objective value is bit for bit what the ctypes binding gets."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from dzo_loader import dzo
+    n, m, steps, warm = 200_000, 20, 30, 5
+    exe = _build(tmp_path, "bench_lbfgs")
+    r = subprocess.run([exe, str(n), str(m), str(steps), str(warm)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    line = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("{")))
+    assert line["iteration_count"] == m + warm + steps and line["value"] > 0
+    dzo.init(0)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(bench.rosenbrock_chain_x0(n, seed=5)), 1.0, m)
+    for _ in range(m + warm):
+        opt.step()
+    assert float("%.10e" % opt.current_objective_value) == line["f_start"]
+    for _ in range(steps):
+        opt.step()
+    assert float("%.10e" % opt.current_objective_value) == line["f_end"]
