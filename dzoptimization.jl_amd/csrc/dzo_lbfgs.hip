@@ -1217,6 +1217,10 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // The stencils carry no index tests (10 of a stencil's 34 instructions): what rosen_grad_elem decides from the element's
 // index -- only the first and the last element of the vector differ -- is a set of per-element coefficients formed once
 // per wave-row (RosenCoef, dzo_rosen.h), and every row runs the same straight-line code.
+// (Measured and not kept, round 3: the small instantiations built for THREE blocks per CU -- K = 8 fits 149 registers, K = 12
+// needs 56 bytes of scratch at 168 -- with 11 instead of 16 staged rows each: n = 1e7, m = 5: 141 against 144 us per pass,
+// m = 8: 161 against 160, m = 10 / 12 (K = 12): 222 / 235 against 203 / 214; n = 1e6 slower throughout.  What did help the
+// small instantiations is asking the occupancy query with the dynamic LDS the launch really uses, see points_grid.)
 template <typename T, int K, bool FIRST = false, int SETS = 2>
 __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_kernel(FusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
@@ -1820,15 +1824,16 @@ template <typename T> static int32_t direction_chain(dzo_lbfgs_s *o) {
 
 // ---------------------------------------------------------------------------- GRAM driver
 // blocks of `kernel` (kBlock threads, static LDS only) that fit on one CU at once; cached
-static int resident_blocks(const void *kernel) {
-    static std::map<const void *, int> cache;
+static int resident_blocks(const void *kernel, size_t dyn_lds = 0) {
+    static std::map<std::pair<const void *, size_t>, int> cache;
     static std::mutex mu;                      // handles may be driven from different host threads
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(kernel);
+    const auto key = std::make_pair(kernel, dyn_lds);
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
-    cache[kernel] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, dyn_lds) != hipSuccess || nb < 1) nb = dyn_lds ? 1 : 4;
+    cache[key] = nb;
     return nb;
 }
 
@@ -2655,11 +2660,11 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
 // of :152 -- skipping a t/2 whose objective, carried by the previous pass, is already known to be no decrease),
 // x and g (= point 0) untouched until a trial is accepted, which makes the spare slot point 0.
 // grid of a point pass: the resident blocks, bounded by the partial-sum buffers
-template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedParams<T>)) {
+template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedParams<T>), size_t dyn_lds = 0) {
     const int64_t nvec = o->core.n / Vec16<T>::N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     int64_t blocks = (rows + kWaves - 1) / kWaves;
-    const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern);
+    const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern, dyn_lds);
     if (blocks > res) blocks = res;
     if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
     if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;             // two objective partials per block in the problem scratch
@@ -2758,8 +2763,6 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.changed = c.flag();
     fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, k == 0);
-    const int grid = points_grid<T>(o, kern);
-    const int pgrid = grid;                               // columns of per-block partial sums
     fp.store_d = o->lazy_d ? 0 : 1;
     {
         // tile-major ring: plain stores while the two streams fit the 256-MiB Infinity Cache (695 vs 735 us at
@@ -2790,6 +2793,11 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
         fp.stage_rows = 14 / stage_tiles;
         stage_bytes = (size_t)kWaves * fp.stage_rows * stage_tiles * kTileBytes;
     }
+    // the blocks resident at once WITH the dynamic LDS of this launch: asked without it, the query answers 3 per CU for the
+    // K = 8 instantiation (149 registers) while 64 KiB of staging let two in, and the third block of every CU ran as a
+    // second round behind the others (n = 1e7, m = 5: 172 -> 144 us per pass, 4400 -> 5500 step!()/s)
+    const int grid = points_grid<T>(o, kern, stage_bytes);
+    const int pgrid = grid;                               // columns of per-block partial sums
     o->d_stale = false;                                   // (whatever was pending belonged to the previous step)
     const int view_k = k, view_newest = o->newest;
     auto direction_pending = [&]() { if (k > 0 && o->lazy_d) { o->d_stale = true; o->dview_k = view_k; o->dview_newest = view_newest; } };
