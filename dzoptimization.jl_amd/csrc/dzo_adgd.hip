@@ -57,6 +57,8 @@ struct dzo_adgd_s {
     bool pipeline = true;            // DZO_TUNE_ADGD_PIPELINE=0: one host round trip per pass
     bool nt_stores = true;           // DZO_TUNE_ADGD_NT_STORES=0: plain stores of the trial point / gradient (measured: no difference)
     dzo::AdgdDev *dev = nullptr;
+    double *pass_partials = nullptr; // [3][grid] partial sums of the fused pass (its own buffer: the grid may exceed what the core's workspace holds)
+    int pass_bpc = 4;                // DZO_TUNE_ADGD_BPC: blocks of the fused pass per CU (measured: 4 / 6 / 8 -> 22.0 / 21.4 / 20.4 k step!()/s at n = 1e7)
     double *slots = nullptr, *slots_dev = nullptr;   // pinned: 2 x 8 doubles, outcome of the last two decisions
     hipEvent_t decided[2] = {nullptr, nullptr};
     bool spec_pending = false;       // a pass + decision is enqueued whose outcome the host has not consumed
@@ -331,6 +333,7 @@ static bool adgd_fused_ok(dzo_adgd_s *o) {
     }
     if (!o->dev) {
         bool ok = hipMalloc((void **)&o->dev, sizeof(AdgdDev)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&o->pass_partials, sizeof(double) * 3 * kMaxPartialBlocks) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&o->slots, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         ok = ok && hipHostGetDevicePointer((void **)&o->slots_dev, o->slots, 0) == hipSuccess;
         for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&o->decided[i], hipEventDisableTiming) == hipSuccess;
@@ -354,11 +357,16 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     fp.st = o->dev;
     fp.x0 = (T *)o->xbuf[0]; fp.g0 = (T *)o->gbuf[0]; fp.x1 = (T *)o->xbuf[1]; fp.g1 = (T *)o->gbuf[1];
     fp.x2 = (T *)o->xbuf[2]; fp.g2 = (T *)o->gbuf[2];
-    fp.partials = c.partials();
+    fp.partials = o->pass_partials;
     fp.changed = c.flag();
     fp.nt_stores = o->nt_stores ? 1 : 0;
+    // grid: four blocks per CU.  (The pass holds 46 registers, so eight would be resident, and a wave has only one row in
+    // flight at a time -- but more blocks do not make the pass faster, 33.2-33.7 us by HIP events at 4 / 6 / 8 per CU, and
+    // the decision kernel behind it sums three partials per block: 22.0 / 21.4 / 20.4 k step!()/s at n = 1e7, round 3.)
     int64_t blocks = (rows + kWaves - 1) / kWaves;
-    if (blocks > 1024) blocks = 1024;                                        // 3 x 1024 partials fit the workspace
+    const int64_t cap = (int64_t)ctx().cus * (o->pass_bpc < 1 ? 1 : (o->pass_bpc > 8 ? 8 : o->pass_bpc));
+    if (blocks > cap) blocks = cap;
+    if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;
     const int grid = (int)(blocks < 1 ? 1 : blocks);
     const double inv_sqrt_two = c.dtype == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);
     auto roles = [&]() { return o->cur; };                                   // the pair a pass from the CURRENT state reads
@@ -368,7 +376,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
             DZO_TIMED(retry ? "adgd_fused_retry" : "adgd_fused_step", s);
             hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
         }
-        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)c.partials(), grid, c.flag(), o->dev,
+        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)o->pass_partials, grid, c.flag(), o->dev,
                            c.dtype == DZO_F32 ? 1 : 0, inv_sqrt_two, (int64_t)c.max_halvings, o->slots_dev + 8 * slot);
         DZO_HIP(hipGetLastError());
         DZO_HIP(hipEventRecord(o->decided[slot], s));
@@ -569,6 +577,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     o->fused = getenv("DZO_TUNE_ADGD_FUSED") ? atoi(getenv("DZO_TUNE_ADGD_FUSED")) != 0 : true;
     o->pipeline = getenv("DZO_TUNE_ADGD_PIPELINE") ? atoi(getenv("DZO_TUNE_ADGD_PIPELINE")) != 0 : true;
     o->nt_stores = getenv("DZO_TUNE_ADGD_NT_STORES") ? atoi(getenv("DZO_TUNE_ADGD_NT_STORES")) != 0 : true;
+    o->pass_bpc = getenv("DZO_TUNE_ADGD_BPC") ? atoi(getenv("DZO_TUNE_ADGD_BPC")) : 4;
     *out = o;
     return DZO_OK;
 }
@@ -603,6 +612,7 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (o->dg_buf) (void)hipFree(o->dg_buf);
     if (o->twin) (void)hipFree(o->twin);
     if (o->dev) (void)hipFree(o->dev);
+    if (o->pass_partials) (void)hipFree(o->pass_partials);
     if (o->slots) (void)hipHostFree(o->slots);
     for (int i = 0; i < 2; ++i) if (o->decided[i]) (void)hipEventDestroy(o->decided[i]);
     core_free(o->core);
