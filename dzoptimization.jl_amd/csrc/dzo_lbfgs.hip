@@ -463,6 +463,10 @@ __global__ __launch_bounds__(kBlock) void gram_reduce_decide_kernel(const double
 __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, double *vals, double *yy, double *sy) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = p.k, ld = k + 1;
+    // (requested first, used last: rho of lane i's pair, for the recurrence below -- the pivot's own entry may be
+    // rewritten further down by this very launch, and the lane that owns it then takes the new value from there)
+    const bool on = wave == 0 && lane < k;
+    double rho_i = on ? p.rho[p.map.slot[lane]] : 1.0;
     // logical k x k views of the caches (entries of non-pivot pairs were computed by the
     // passes in which THEY were the pivot)
     for (int e = threadIdx.x; e < k * k; e += (int)blockDim.x) {
@@ -472,9 +476,11 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     }
     __syncthreads();
     const int pv = p.pivot, ps = p.map.slot[pv];
-    if (p.rho_from_vals && threadIdx.x == 0) {                     // :505 for the pair pushed by the single pass
+    if (p.rho_from_vals) {                                         // :505 for the pair pushed by the single pass
         const double r = vals[pv * kGramValues + 4];
-        p.rho[ps] = p.rho_to_f32 ? (double)(float)r : r;
+        const double rr = p.rho_to_f32 ? (double)(float)r : r;
+        if (threadIdx.x == 0) p.rho[ps] = rr;
+        if (on && lane == pv) rho_i = rr;                          // (the value the early load could not see yet)
     }
     if (threadIdx.x < k) {
         const int i = threadIdx.x, si = p.map.slot[i];
@@ -491,32 +497,44 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     __syncthreads();
     if (!p.do_recurrence || wave != 0) return;
 
-    const bool on = lane < k;
-    const double rho_i = on ? p.rho[p.map.slot[lane]] : 1.0;
+    // The three loops are chains of dependent steps (a division, a v_readlane, an fma per pair), and this kernel sits
+    // between two passes of every step: each loop fetches the Gram entry of its NEXT iteration before it works on the
+    // current one, so the LDS round trip runs under the division instead of in front of it.  Same operations on the same
+    // operands in the same order -- the scalars are bit for bit what the plain loops gave.
+    const int row = on ? lane : 0;                                 // (lanes beyond k read row 0 and use nothing)
     double acc = on ? vals[lane * kGramValues + 0] : 0.0;          // s_i.g
     double alpha_i = 0;
+    double nxt = sy[row * ld + 0];
     for (int j = 0; j < k; ++j) {                                  // :439 newest -> oldest
+        const double syj = nxt;
+        if (j + 1 < k) nxt = sy[row * ld + j + 1];
         const double cand = acc / rho_i;                           // :440 (lane j's value counts)
         const double aj = readlane_f64(cand, j);                    // (uniform j: v_readlane, no LDS round trip)
         if (lane == j) alpha_i = cand;
-        if (on && lane > j) acc = __builtin_fma(-aj, sy[lane * ld + j], acc);
+        if (on && lane > j) acc = __builtin_fma(-aj, syj, acc);
     }
     if (on) p.alpha[lane] = alpha_i;
-    const double scale = -p.rho[p.map.slot[0]] / yy[0];            // :444
+    const double scale = -readlane_f64(rho_i, 0) / yy[0];          // :444 (rho of the newest pair = lane 0's)
     if (lane == 0) p.scale[0] = scale;
     // y_i.q_k with q_k = g - sum_j alpha_j y_j
     double base = on ? vals[lane * kGramValues + 1] : 0.0;         // y_i.g
+    nxt = yy[row * ld + 0];
     for (int j = 0; j < k; ++j) {
+        const double yyj = nxt;
+        if (j + 1 < k) nxt = yy[row * ld + j + 1];
         const double aj = readlane_f64(alpha_i, j);
-        if (on) base = __builtin_fma(-aj, yy[lane * ld + j], base);
+        if (on) base = __builtin_fma(-aj, yyj, base);
     }
     acc = scale * base;
     double c_i = 0;
+    nxt = sy[(k - 1) * ld + row];
     for (int l = k - 1; l >= 0; --l) {                             // :446 oldest -> newest
+        const double syl = nxt;
+        if (l > 0) nxt = sy[(l - 1) * ld + row];
         const double cand = alpha_i + acc / rho_i;                 // :447-448
         const double cl = readlane_f64(cand, l);
         if (lane == l) c_i = cand;
-        if (on && lane < l) acc = __builtin_fma(-cl, sy[l * ld + lane], acc);
+        if (on && lane < l) acc = __builtin_fma(-cl, syl, acc);
     }
     if (on) p.coef[lane] = c_i;
 }
@@ -535,8 +553,7 @@ __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p)
     const int k = p.k;
     double *vals = fin_lds, *yy = vals + kGramValues * k, *sy = yy + k * (k + 1);
     for (int v = threadIdx.x; v < kGramValues * k; v += kBlock) vals[v] = p.partials[v];
-    __syncthreads();
-    gram_finish_body(p, vals, yy, sy);
+    gram_finish_body(p, vals, yy, sy);                             // (its first barrier stands behind these stores too)
 }
 
 // Reduce + finish in ONE launch of one 1024-thread block, for the sizes where the scalar stage's two launches cost
