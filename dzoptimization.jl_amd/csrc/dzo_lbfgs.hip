@@ -460,7 +460,9 @@ __global__ __launch_bounds__(kBlock) void gram_reduce_decide_kernel(const double
 //     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
 //     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
 // One block.  vals: kGramValues*k reduced values already in LDS; yy / sy: k x (k+1) LDS scratch.
-__device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, double *vals, double *yy, double *sy) {
+// gate_ok: the speculative launch's gate as the caller read it (the read is requested first and looked at only here,
+// behind the other requests: whatever was fetched before that is dropped, nothing has been stored outside LDS)
+__device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, double *vals, double *yy, double *sy, int gate_ok = 1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = p.k, ld = k + 1;
     // (requested first, used last: rho of lane i's pair, for the recurrence below -- the pivot's own entry may be
@@ -474,6 +476,7 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
         yy[i * ld + j] = p.Gyy[p.map.slot[i] * p.m1 + p.map.slot[j]];
         sy[i * ld + j] = p.Gsy[p.map.slot[i] * p.m1 + p.map.slot[j]];
     }
+    if (!gate_ok) return;                                          // (uniform: every thread read the same word)
     __syncthreads();
     const int pv = p.pivot, ps = p.map.slot[pv];
     if (p.rho_from_vals) {                                         // :505 for the pair pushed by the single pass
@@ -548,12 +551,12 @@ static inline size_t gram_finish_lds_bytes(int k) { return sizeof(double) * ((si
 // Gram pass, which needs either cache-wide fences, 195 us per pass, or write-through stores and the same
 // single-block sum, 87 us.  The three-launch form stays.)
 __global__ __launch_bounds__(kBlock) void gram_finish_kernel(GramFinishParams p) {
-    if (p.gate && *p.gate != 1) return;
+    const int gate_ok = p.gate ? (*p.gate == 1) : 1;               // (looked at in gram_finish_body, behind the other loads)
     extern __shared__ __attribute__((aligned(16))) double fin_lds[];
     const int k = p.k;
     double *vals = fin_lds, *yy = vals + kGramValues * k, *sy = yy + k * (k + 1);
     for (int v = threadIdx.x; v < kGramValues * k; v += kBlock) vals[v] = p.partials[v];
-    gram_finish_body(p, vals, yy, sy);                             // (its first barrier stands behind these stores too)
+    gram_finish_body(p, vals, yy, sy, gate_ok);                    // (its first barrier stands behind these stores too)
 }
 
 // Reduce + finish in ONE launch of one 1024-thread block, for the sizes where the scalar stage's two launches cost
