@@ -179,17 +179,23 @@ __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__res
                                                              int32_t *__restrict__ changed, AdgdDev *__restrict__ st, int to_f32,
                                                              double inv_sqrt_two, int64_t max_halvings,
                                                              double *__restrict__ slot) {
-    __shared__ double lds[kWaves];
-    if (st->stuck) {                                                         // (uniform)
+    __shared__ double lds[3 * kWaves];
+    // This kernel stands between two passes of every step: the three sets of partials are requested together, behind the
+    // request for the state word, and summed behind ONE pair of barriers (block_sum_multi: every sum bit for bit what
+    // block_sum gives) -- it used to be three rounds of load, barrier, barrier after a first round trip for `stuck`.
+    const int stuck = st->stuck;
+    double a[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < grid; i += kBlock) {
+        a[0] += partials[i];
+        a[1] += partials[(int64_t)grid + i];
+        a[2] += partials[2 * (int64_t)grid + i];
+    }
+    if (stuck) {                                                             // (uniform)
         if (threadIdx.x == 0) { reinterpret_cast<int32_t *>(slot + 3)[0] = 3; slot[7] = (double)st->seq; st->seq += 1; __threadfence_system(); }
         return;
     }
     double v[3];
-    for (int c = 0; c < 3; ++c) {
-        double a = 0;
-        for (int i = threadIdx.x; i < grid; i += kBlock) a += partials[(int64_t)c * grid + i];
-        v[c] = block_sum(a, lds);
-    }
+    block_sum_multi<3>(a, lds, v);
     if (threadIdx.x == 0) {
         auto rnd = [&](double x) { return to_f32 ? (double)(float)x : x; };
         auto root = [&](double x) { return to_f32 ? (double)sqrtf((float)x) : sqrt(x); };

@@ -97,24 +97,37 @@ DecideArgs decide_args(OptCore &c, const double *partials, int64_t count, double
 
 __device__ __forceinline__ void decide_body(const DecideArgs &a, double *lds) {
     double f_new;
-    if (a.partials) {
-        double v = 0;
-        for (int64_t i = threadIdx.x; i < a.count; i += kBlock) v += a.partials[i];
-        f_new = a.scale * block_sum(v, lds);
+    double f_second = 0;
+    // (the host spins on what this block publishes: the change flag and both sets of partials are requested together and
+    // the two sums share one pair of barriers -- block_sum_multi, bit for bit block_sum's values)
+    const int32_t ch_early = threadIdx.x == 0 ? *a.changed : 0;
+    if (a.partials && a.partials2) {
+        __shared__ double lds2[2 * kWaves];
+        double v[2] = {0, 0}, out[2];
+        for (int64_t i = threadIdx.x; i < a.count; i += kBlock) { v[0] += a.partials[i]; v[1] += a.partials2[i]; }
+        block_sum_multi<2>(v, lds2, out);
+        f_new = a.scale * out[0];
+        f_second = a.scale * out[1];
         if (threadIdx.x == 0) a.result[0] = f_new;
     } else {
-        f_new = a.result[0];
-    }
-    double f_second = 0;
-    if (a.partials2) {
-        double v = 0;
-        for (int64_t i = threadIdx.x; i < a.count; i += kBlock) v += a.partials2[i];
-        f_second = a.scale * block_sum(v, lds);
+        if (a.partials) {
+            double v = 0;
+            for (int64_t i = threadIdx.x; i < a.count; i += kBlock) v += a.partials[i];
+            f_new = a.scale * block_sum(v, lds);
+            if (threadIdx.x == 0) a.result[0] = f_new;
+        } else {
+            f_new = a.result[0];
+        }
+        if (a.partials2) {
+            double v = 0;
+            for (int64_t i = threadIdx.x; i < a.count; i += kBlock) v += a.partials2[i];
+            f_second = a.scale * block_sum(v, lds);
+        }
     }
     if (threadIdx.x == 0) {
         const double f_raw = f_new;
         if (a.to_f32) f_new = (double)(float)f_new;
-        const int32_t ch = *a.changed;
+        const int32_t ch = ch_early;
         int32_t st = 0;
         if (ch == 0) st = 2;                                     // :128 isequal -> stuck
         else if (f_new < a.f_cur) st = 1;                        // :139 strict decrease

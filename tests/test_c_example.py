@@ -64,7 +64,7 @@ def test_c_bench_driver_runs_the_same_trajectory_as_the_python_binding(tmp_path)
     sys.path.insert(0, ROOT)
     import bench
     from dzo_loader import dzo
-    n, m, steps, warm = 200_000, 20, 30, 5
+    n, m, steps, warm = 400_000, 20, 30, 5          # (a size whose run does not end stuck within these steps)
     exe = _build(tmp_path, "bench_lbfgs")
     r = subprocess.run([exe, str(n), str(m), str(steps), str(warm)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
