@@ -2701,13 +2701,15 @@ template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(Fused
         if constexpr (sizeof(T) == 8) {
             // (K = 10: m = 10 is the history length most L-BFGS users ask for; on the K = 12 instantiation it paid for two
             // masked pairs -- 211 us per pass at n = 1e7 where m = 12 takes 218)
-            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
+            return o->m <= 6 ? lbfgs_point_pass_kernel<T, 6, false, 1>
+                   : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
                    : o->m <= 10 ? lbfgs_point_pass_kernel<T, 10, false, 1>
                    : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1>
                    : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1>
                    : lbfgs_point_pass_kernel<T, 20, false, 1>;
         } else {                                             // (fp32, K > 12: the fp64 copies for the dots do not fit 256 registers)
-            return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
+            return o->m <= 6 ? lbfgs_point_pass_kernel<T, 6, false, 1>
+                   : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
                    : o->m <= 10 ? lbfgs_point_pass_kernel<T, 10, false, 1> : lbfgs_point_pass_kernel<T, 12, false, 1>;
         }
     }
