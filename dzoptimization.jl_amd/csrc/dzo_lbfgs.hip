@@ -912,7 +912,12 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineParams<T> p) {
 // each side.  62 uses the whole wave.  (56 owned vectors = seven whole 128-B lines per stream, so
 // that rows start on line boundaries, measured slower: 770 vs 757 us -- 11 % more rows and
 // redundant halo loads cost more than the partial first / last line of every row.)
-constexpr int kFusedMaxK = 20;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
+constexpr int kPairMaxK = 20;                  // pairs the single-pass step over a PAIR ring holds (its largest instantiation)
+// points the point pass holds: K = 20 is what fits two waves per SIMD (247 of 256 registers); fp64 has one more
+// instantiation, K = 24 on two register sets and one wave per SIMD (508 of 512), so that m = 21 .. 24 do not fall
+// back to the two-pass kernels (n = 1e7, m = 24: 683 step!()/s there)
+static inline int point_max_k(int32_t dtype) { return dtype == DZO_F64 ? 24 : 20; }
+constexpr int kFusedMaxK = 24;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
 
 template <typename T> struct FusedParams {
     int64_t n;
@@ -2486,7 +2491,7 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (!o->single_pass || !o->blocked || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
     if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post) return false;
-    if (c.iteration_count == 0 || o->k < 1 || o->k > kFusedMaxK) return false;
+    if (c.iteration_count == 0 || o->k < 1 || o->k > kPairMaxK || o->m > kPairMaxK) return false;   // (m: the pass also forms the dots of pair k + 1)
     const int vecn = 16 / (int)dtype_size(c.dtype);
     if (c.n % vecn != 0 || c.n < 4 * vecn || (uint64_t)c.n * dtype_size(c.dtype) >= (1ull << 32)) return false;   // 32-bit byte offsets
     o->refresh_delta_ptrs();
@@ -2512,7 +2517,7 @@ static bool points_ok(dzo_lbfgs_s *o) {
     if (!o->points || !o->single_pass || !o->blocked || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
     if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post || !c.problem) return false;
     if (c.problem->kind != DZO_PROBLEM_ROSENBROCK_CHAIN || c.problem->l2 != 0.0 || c.problem->bg_on || c.problem->cons_on) return false;
-    if (o->k > kFusedMaxK || !al16v(o->d)) return false;
+    if (o->k > point_max_k(c.dtype) || o->m > point_max_k(c.dtype) || !al16v(o->d)) return false;
     if (o->k > 0 && !o->spec_scalars) return false;       // (the scalars come from the previous pass; anything else goes through Gram passes)
     return true;
 }
@@ -2692,7 +2697,7 @@ template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedP
 }
 
 // one register set per wave (two waves per SIMD)?  DZO_TUNE_POINT_SETS=1 (the default), where the instantiation fits 256 registers
-template <typename T> static bool point_one_set(const dzo_lbfgs_s *o) { return o->point_sets == 1 && (sizeof(T) == 8 || o->m <= 12); }
+template <typename T> static bool point_one_set(const dzo_lbfgs_s *o) { return o->point_sets == 1 && o->m <= 20 && (sizeof(T) == 8 || o->m <= 12); }
 
 // the instantiation of the point pass for this optimizer: the smallest K that holds m pairs; one or two register sets
 // (DZO_TUNE_POINT_SETS; see the kernel)
@@ -2713,6 +2718,7 @@ template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(Fused
                    : o->m <= 10 ? lbfgs_point_pass_kernel<T, 10, false, 1> : lbfgs_point_pass_kernel<T, 12, false, 1>;
         }
     }
+    if constexpr (sizeof(T) == 8) { if (o->m > 20) return lbfgs_point_pass_kernel<T, 24, false, 2>; }   // (m <= 24: point_max_k)
     return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 2>
            : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 2>
            : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 2>
@@ -3034,7 +3040,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         // blocked (tile-major) ring: when the constructor knows that the single-pass step applies
         const int vecn = 16 / (int)es;
         o->blocked = tl_want_blocked && tune("DZO_TUNE_BLOCKED", 1) != 0 && tune("DZO_TUNE_SINGLE_PASS", 1) != 0 &&
-                     history_length <= kFusedMaxK && n % vecn == 0 && n >= 4 * vecn && (uint64_t)n * es < (1ull << 32);
+                     history_length <= point_max_k(dtype) && n % vecn == 0 && n >= 4 * vecn && (uint64_t)n * es < (1ull << 32);
     }
     o->nslots = o->m + (o->blocked ? 2 : 1);
     const int m1 = o->nslots;

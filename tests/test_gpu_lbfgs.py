@@ -824,9 +824,10 @@ def test_single_pass_rejected_first_trials_follow_the_reference_loop():
 
 
 def test_history_longer_than_the_single_pass_limit_switches_paths_cleanly():
-    """m = 24 > 20: the tile-major ring and the single-pass step are chosen at construction and only
-    for m <= 20, so this optimizer runs the two-pass kernels throughout -- same steps as the oracle."""
-    n, m = 1000, 24
+    """m = 26 > 24: the tile ring and the single-pass step are chosen at construction and only for m <= 24 (fp64; the point
+    pass has a K = 24 instantiation on two register sets) / m <= 20 (fp32), so this optimizer runs the two-pass kernels
+    throughout -- same steps as the oracle."""
+    n, m = 1000, 26
     opt, ref, _ = _gpu_and_oracle(n, m)
     for it in range(40):
         opt.step(); ref.step()
@@ -940,8 +941,14 @@ def test_blocked_ring_hands_out_the_pairs_as_plain_vectors(n, m, dtype):
     assert opt2.iteration_count == steps + 1 or opt2.is_stuck
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("n,m,step0", [(16, 3, 1.0), (2 * 62 * 3 + 12, 5, 1.0), (4100, 20, 1.0), (100_004, 7, 1.0), (4100, 6, 300.0)])
+# (m = 23: the K = 24 instantiation on two register sets, fp64 only -- fp32 keeps points up to m = 20)
+_POINT_RING_CASES = [(n, m, s0, dt) for dt in (np.float64, np.float32)
+                     for n, m, s0 in [(16, 3, 1.0), (2 * 62 * 3 + 12, 5, 1.0), (4100, 20, 1.0), (100_004, 7, 1.0), (4100, 6, 300.0), (4100, 23, 1.0)]
+                     if not (dt == np.float32 and m > 20)]
+
+
+@pytest.mark.parametrize("n,m,step0,dtype", _POINT_RING_CASES,
+                         ids=[f"{np.dtype(dt).name}-n{n}-m{m}-{s0}" for n, m, s0, dt in _POINT_RING_CASES])
 def test_point_ring_steps_match_the_oracle_from_the_same_state(n, m, step0, dtype):
     """The default optimizer on the built-in chained Rosenbrock keeps the last k + 1 POINTS and GRADIENTS tile-major
     (ring_layout == 2) and forms the pairs in registers; every trial of a step, the first step included, is one pass.

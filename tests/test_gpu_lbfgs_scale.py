@@ -4,7 +4,7 @@ lbfgs_point_pass_kernel launches at most CUs x 4 wave-rows of 62 16-byte vectors
 beyond n ~ 1.3e5 (fp64), fills its 16-row LDS staging burst beyond n ~ 2e6, and swaps its two register sets every
 row.  The parity tests of tests/test_gpu_lbfgs.py stop at n = 100 004, i.e. before any of that; these cases compare
 the point path with the oracle (src/DZOptimization.jl:430-451 two-loop, :454-509 step!, :107-154 backtracking) at
-n = 2.5e5 ... 1.2e7, for every instantiation K in {6, 8, 10, 12, 16, 20} x {fp32, fp64}, both arrangements of the tiles
+n = 2.5e5 ... 1.2e7, for every instantiation K in {6, 8, 10, 12, 16, 20, 24} x {fp32, fp64}, both arrangements of the tiles
 (tile-major, stream-major) and above the 32-bit-offset switch (n = 1.2e7, m = 20: tile-major fallback).
 
 How: installing pairs would turn the point ring into a pair ring, so the GPU optimizer runs FREE and the oracle is
@@ -87,6 +87,8 @@ CASES = [
     (np.float64, 2_500_000, 20, None),         # K = 20, 20 rows per wave: full staging bursts
     (np.float64, 2_500_000, 20, 0),
     (np.float64, 10_000_000, 20, None),        # config 3 itself
+    (np.float64, 400_000, 24, None),           # K = 24: two register sets, one wave per SIMD (m = 21 .. 24, fp64 only)
+    (np.float64, 2_500_000, 22, 0),            # K = 24, tile-major forced, 20 rows per wave
     (np.float32, 500_000, 6, None),            # fp32, K = 6
     (np.float32, 500_000, 7, None),            # fp32, K = 8, tile-major
     (np.float32, 500_000, 10, None),           # fp32, K = 10
