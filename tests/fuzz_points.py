@@ -40,12 +40,21 @@ def run(cases=60, seed=2468):
                 Y = np.stack([h.to_host() for h in opt.delta_gradient_history]) if k else np.zeros((0, n), dtype)
                 ref.install_state(opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value,
                                   S, Y, opt.rho_history[:k], opt.iteration_count)
+                f_before = opt.current_objective_value
                 opt.step(); ref.step()
                 if opt.is_stuck != ref.is_stuck:
                     # only after dozens of halvings, where f_new - f is one unit in the last place and the two summation
                     # orders may decide differently (seed 12, case 2: the oracle accepts trial 43 with f lower by 5e-14,
                     # the GPU halves on to x + t d == x)
-                    assert min(opt.last_trials, ref.last_trials) > 30, (ex, it, n, m, step0, opt.last_trials, ref.last_trials)
+                    # ... or at the minimiser itself: f has fallen by 20 orders of magnitude, every trial's f_new - f is rounding
+                    # noise whatever the step (seed 406, case 72: n = 8, 47 steps in)
+                    # ... or at a minimiser itself (the global one, or the local one of the chained function at f = 3.98...): the
+                    # side that still found a decrease found one at rounding level, whatever the step (seed 406, case 72: n = 8,
+                    # 47 steps in, f = 3.9858877695994894: the oracle accepts trial 14, the GPU halves on until x + t d == x)
+                    moved = ref if opt.is_stuck else opt
+                    decrease = f_before - moved.current_objective_value
+                    assert decrease <= 1e-13 * abs(f_before) or min(opt.last_trials, ref.last_trials) > 30, (
+                        ex, it, n, m, step0, opt.last_trials, ref.last_trials, f_before, decrease, opt.is_stuck, ref.is_stuck)
                     break
                 if ref.is_stuck:
                     break
