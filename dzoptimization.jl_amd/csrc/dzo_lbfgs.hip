@@ -2710,7 +2710,9 @@ template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(Fused
                    : o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1>
                    : o->m <= 10 ? lbfgs_point_pass_kernel<T, 10, false, 1>
                    : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1>
+                   : o->m <= 14 ? lbfgs_point_pass_kernel<T, 14, false, 1>
                    : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1>
+                   : o->m <= 18 ? lbfgs_point_pass_kernel<T, 18, false, 1>
                    : lbfgs_point_pass_kernel<T, 20, false, 1>;
         } else {                                             // (fp32, K > 12: the fp64 copies for the dots do not fit 256 registers)
             return o->m <= 6 ? lbfgs_point_pass_kernel<T, 6, false, 1>

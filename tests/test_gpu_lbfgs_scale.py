@@ -4,7 +4,7 @@ lbfgs_point_pass_kernel launches at most CUs x 4 wave-rows of 62 16-byte vectors
 beyond n ~ 1.3e5 (fp64), fills its 16-row LDS staging burst beyond n ~ 2e6, and swaps its two register sets every
 row.  The parity tests of tests/test_gpu_lbfgs.py stop at n = 100 004, i.e. before any of that; these cases compare
 the point path with the oracle (src/DZOptimization.jl:430-451 two-loop, :454-509 step!, :107-154 backtracking) at
-n = 2.5e5 ... 1.2e7, for every instantiation K in {6, 8, 10, 12, 16, 20, 24} x {fp32, fp64}, both arrangements of the tiles
+n = 2.5e5 ... 1.2e7, for every instantiation K in {6, 8, 10, 12, 14, 16, 18, 20, 24} x {fp32, fp64}, both arrangements of the tiles
 (tile-major, stream-major) and above the 32-bit-offset switch (n = 1.2e7, m = 20: tile-major fallback).
 
 How: installing pairs would turn the point ring into a pair ring, so the GPU optimizer runs FREE and the oracle is
@@ -82,7 +82,9 @@ CASES = [
     (np.float64, 400_000, 9, 0),               # K = 10, tile-major forced
     (np.float64, 400_000, 12, None),           # K = 12, stream-major
     (np.float64, 400_000, 12, 0),              # K = 12, tile-major forced
+    (np.float64, 400_000, 14, None),           # K = 14 (m = 13, 14)
     (np.float64, 400_000, 16, None),           # K = 16
+    (np.float64, 400_000, 17, None),           # K = 18 (m = 17, 18)
     (np.float64, 400_000, 16, 0),
     (np.float64, 2_500_000, 20, None),         # K = 20, 20 rows per wave: full staging bursts
     (np.float64, 2_500_000, 20, 0),
