@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     __syncthreads();
     const bool scaled = k > 0;
     const T scale = scaled ? (T)p.scale[0] : (T)1;
-    const int64_t nvec = p.n / N;
+    const int64_t nvec = (p.n + N - 1) / N;               // (a ragged n: the last vector is padded with phantom elements, see load_vec_tail)
     const int64_t rows = (nvec + kOwn - 1) / kOwn;
     const int64_t row_end = rows;
     const int64_t stride = (int64_t)gridDim.x * kWaves;     // wave-rows block-cyclically
@@ -1622,6 +1622,24 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     if ((p.debug_skip & 1024) && blockIdx.x < 1024) { if (lane == 0) g_dev_wave_times[(blockIdx.x * kWaves + wave) * 2 + 1] = wall_clock64(); }
 }
 
+// Ragged n on the tile ring: a vector length that is not a multiple of the 16-byte vector gets a last vector padded with
+// PHANTOM elements.  They are +0 in every point of the ring and stay +0: their stencil coefficients are all zero
+// (rosen_coef), so their gradient is +0, their direction +-0 and their trial point fma(t, +-0, +0) = +0; they add exact
+// zeros to every sum and never differ from the old point.  The contiguous arrays of the caller have n elements and no
+// padding: whoever moves a vector between them and the ring touches the last vector element by element.
+template <typename T> __device__ __forceinline__ void load_vec_tail(const T *lin, int64_t v, int64_t n, T (&t)[Vec16<T>::N]) {
+    constexpr int N = Vec16<T>::N;
+    if (v * N + N <= n) { load16(lin + v * N, t); return; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = v * N + j < n ? lin[v * N + j] : (T)0;
+}
+template <typename T> __device__ __forceinline__ void store_vec_tail(T *lin, int64_t v, int64_t n, const T (&t)[Vec16<T>::N]) {
+    constexpr int N = Vec16<T>::N;
+    if (v * N + N <= n) { store16(lin + v * N, t); return; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) if (v * N + j < n) lin[v * N + j] = t[j];
+}
+
 // ring streams elementwise, tile positions included (the halo copies transform like their originals):
 // a <- a - b (point ring -> pair ring, in place)
 template <typename T>
@@ -1656,15 +1674,15 @@ __global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t 
         const T xl = v > 0 ? hist_ptr<true>(xs, v - 1, rowbytes)[N - 1] : (T)0;
         const T xr = v + 1 < nvec ? hist_ptr<true>(xs, v + 1, rowbytes)[0] : (T)0;
 #pragma unroll
-        for (int e = 0; e < N; ++e)
-            g[e] = rosen_grad_elem<T>(v * N + e, n, e > 0 ? x[(e + N - 1) % N] : xl, x[e], e + 1 < N ? x[(e + 1) % N] : xr);
+        for (int e = 0; e < N; ++e)             // (an element past n -- the padding of a ragged last vector -- has gradient +0)
+            g[e] = v * N + e < n ? rosen_grad_elem<T>(v * N + e, n, e > 0 ? x[(e + N - 1) % N] : xl, x[e], e + 1 < N ? x[(e + 1) % N] : xr) : (T)0;
         store16(reinterpret_cast<T *>(reinterpret_cast<char *>(gs) + row * rowbytes + pos * 16), g);
     }
 }
 
 // contiguous vector <- stream a - stream b (delta_point / a pair of the point ring as a plain vector)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void ring_gather_diff_kernel(int64_t nvec, const T *__restrict__ a, const T *__restrict__ b,
+__global__ __launch_bounds__(kBlock) void ring_gather_diff_kernel(int64_t n, int64_t nvec, const T *__restrict__ a, const T *__restrict__ b,
                                                                   T *__restrict__ lin, int64_t rowbytes) {
     constexpr int N = Vec16<T>::N;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBlock) {
@@ -1675,7 +1693,7 @@ __global__ __launch_bounds__(kBlock) void ring_gather_diff_kernel(int64_t nvec, 
         load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(b) + row * rowbytes + pos * 16), vb);
 #pragma unroll
         for (int j = 0; j < N; ++j) va[j] = va[j] - vb[j];
-        store16(lin + v * N, va);
+        store_vec_tail(lin, v, n, va);
     }
 }
 
@@ -1683,7 +1701,7 @@ __global__ __launch_bounds__(kBlock) void ring_gather_diff_kernel(int64_t nvec, 
 // One stream of the ring (all its tiles) from / to a contiguous vector of nvec 16-B vectors.  Thread = one
 // tile position; the halo positions 0 and 63 take the neighbouring rows' edge vectors.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void ring_scatter_kernel(int64_t nvec, const T *__restrict__ lin, T *__restrict__ stream, int64_t rowbytes) {
+__global__ __launch_bounds__(kBlock) void ring_scatter_kernel(int64_t n, int64_t nvec, const T *__restrict__ lin, T *__restrict__ stream, int64_t rowbytes) {
     constexpr int N = Vec16<T>::N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
@@ -1692,25 +1710,25 @@ __global__ __launch_bounds__(kBlock) void ring_scatter_kernel(int64_t nvec, cons
         const int64_t v = row * kRowOwn - kRowLead + pos;
         if (v < 0 || v >= nvec) continue;
         T t[N];
-        load16(lin + v * N, t);
+        load_vec_tail(lin, v, n, t);
         store16(reinterpret_cast<T *>(reinterpret_cast<char *>(stream) + row * rowbytes + pos * 16), t);
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void ring_gather_kernel(int64_t nvec, const T *__restrict__ stream, T *__restrict__ lin, int64_t rowbytes) {
+__global__ __launch_bounds__(kBlock) void ring_gather_kernel(int64_t n, int64_t nvec, const T *__restrict__ stream, T *__restrict__ lin, int64_t rowbytes) {
     constexpr int N = Vec16<T>::N;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBlock) {
         T t[N];
         load16(hist_ptr<true>(stream, v, rowbytes), t);
-        store16(lin + v * N, t);
+        store_vec_tail(lin, v, n, t);
     }
 }
 
 // does the contiguous vector still equal the stream it was gathered from?  (bitwise, NaN == NaN; one plain store
 // per block that saw a difference)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void ring_compare_kernel(int64_t nvec, const T *__restrict__ stream, const T *__restrict__ lin, int64_t rowbytes,
+__global__ __launch_bounds__(kBlock) void ring_compare_kernel(int64_t n, int64_t nvec, const T *__restrict__ stream, const T *__restrict__ lin, int64_t rowbytes,
                                                               int32_t *__restrict__ differs) {
     constexpr int N = Vec16<T>::N;
     __shared__ int lds_flag;
@@ -1718,7 +1736,7 @@ __global__ __launch_bounds__(kBlock) void ring_compare_kernel(int64_t nvec, cons
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kBlock) {
         T a[N], b[N];
         load16(hist_ptr<true>(stream, v, rowbytes), a);
-        load16(lin + v * N, b);
+        load_vec_tail(lin, v, n, b);                      // (the padding of a ragged last vector is +0 on both sides)
 #pragma unroll
         for (int j = 0; j < N; ++j) diff |= !is_equal(a[j], b[j]);
     }
@@ -2126,26 +2144,28 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
 }
 
 // ---------------------------------------------------------------------------- blocked ring, host side
+// vectors of 16 bytes a ring stream holds: the last one is padded with phantom elements when n is ragged (see load_vec_tail)
+template <typename T> static inline int64_t ring_nvec(const dzo_lbfgs_s *o) { return (o->core.n + Vec16<T>::N - 1) / Vec16<T>::N; }
+static inline bool ring_ragged(const dzo_lbfgs_s *o) { return o->core.n % (16 / (int64_t)dtype_size(o->core.dtype)) != 0; }
 template <typename T> static void ring_scatter(dzo_lbfgs_s *o, const void *lin, void *stream) {
-    const int64_t nvec = o->core.n / Vec16<T>::N;
     const int grid = stream_grid(o->ring_rows * 64, 1);
-    hipLaunchKernelGGL(ring_scatter_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)lin, (T *)stream, o->rowbytes);
+    hipLaunchKernelGGL(ring_scatter_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->core.n, ring_nvec<T>(o), (const T *)lin, (T *)stream, o->rowbytes);
 }
 template <typename T> static void ring_gather(dzo_lbfgs_s *o, const void *stream, void *lin) {
-    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int64_t nvec = ring_nvec<T>(o);
     const int grid = stream_grid(nvec, 1);
-    hipLaunchKernelGGL(ring_gather_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)stream, (T *)lin, o->rowbytes);
+    hipLaunchKernelGGL(ring_gather_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->core.n, nvec, (const T *)stream, (T *)lin, o->rowbytes);
 }
 
 template <typename T> static void ring_gather_diff(dzo_lbfgs_s *o, const void *a, const void *b, void *lin) {
-    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int64_t nvec = ring_nvec<T>(o);
     const int grid = stream_grid(nvec, 1);
-    hipLaunchKernelGGL(ring_gather_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)a, (const T *)b, (T *)lin, o->rowbytes);
+    hipLaunchKernelGGL(ring_gather_diff_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->core.n, nvec, (const T *)a, (const T *)b, (T *)lin, o->rowbytes);
 }
 template <typename T> static void ring_compare(dzo_lbfgs_s *o, const void *stream, const void *lin) {
-    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int64_t nvec = ring_nvec<T>(o);
     const int grid = stream_grid(nvec, 1);
-    hipLaunchKernelGGL(ring_compare_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, nvec, (const T *)stream, (const T *)lin, o->rowbytes, o->xg_differs);
+    hipLaunchKernelGGL(ring_compare_kernel<T>, dim3(grid), dim3(kBlock), 0, o->core.stream, o->core.n, nvec, (const T *)stream, (const T *)lin, o->rowbytes, o->xg_differs);
 }
 template <typename T> static void ring_diff(dzo_lbfgs_s *o, void *a, const void *b) {
     const int grid = stream_grid(o->ring_rows * 64, 1);
@@ -2158,7 +2178,7 @@ static int32_t lbfgs_ensure_g(dzo_lbfgs_s *o, int slot) {
     OptCore &c = o->core;
     DZO_TIMED("lbfgs_ring_regrad", c.stream);
     const int grid = stream_grid(o->ring_rows * 64, 1);
-    DZO_DISPATCH(c.dtype, hipLaunchKernelGGL(ring_regrad_kernel<T>, dim3(grid), dim3(kBlock), 0, c.stream, c.n, c.n / Vec16<T>::N,
+    DZO_DISPATCH(c.dtype, hipLaunchKernelGGL(ring_regrad_kernel<T>, dim3(grid), dim3(kBlock), 0, c.stream, c.n, ring_nvec<T>(o),
                                              (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes));
     DZO_HIP(hipGetLastError());
     o->g_valid |= 1u << slot;
@@ -2201,6 +2221,7 @@ static int32_t lbfgs_refresh_lin(dzo_lbfgs_s *o) {
 
 static void lbfgs_mark_unsettled(dzo_lbfgs_s *o);
 static int32_t lbfgs_materialize_d(dzo_lbfgs_s *o);
+static int32_t lbfgs_unblock(dzo_lbfgs_s *o);
 
 // Point ring -> pair ring, in place: the caller's arrays receive point 0, then slot_of(i) <- point i - point i+1
 // from the newest pair to the oldest (each subtraction reads two slots no earlier one has touched).  The pair
@@ -2227,6 +2248,9 @@ static int32_t lbfgs_leave_points(dzo_lbfgs_s *o) {
     }
     o->points = false;
     lbfgs_mark_unsettled(o);
+    // the pair kernels of the tile ring read whole 16-byte vectors of the caller's contiguous arrays: a ragged n continues
+    // on the slabs (the two-pass kernels with their element tails)
+    if (ring_ragged(o)) return lbfgs_unblock(o);
     return DZO_OK;
 }
 
@@ -2235,6 +2259,7 @@ static int32_t lbfgs_leave_points(dzo_lbfgs_s *o) {
 static int32_t lbfgs_unblock(dzo_lbfgs_s *o) {
     if (!o->blocked) return DZO_OK;
     DZO_TRY(lbfgs_leave_points(o));
+    if (!o->blocked) return DZO_OK;                         // (a ragged point ring: leaving the points already ended here)
     OptCore &c = o->core;
     DZO_TRY(lbfgs_refresh_lin(o));
     const size_t es = dtype_size(c.dtype);
@@ -2493,7 +2518,8 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
     if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post) return false;
     if (c.iteration_count == 0 || o->k < 1 || o->k > kPairMaxK || o->m > kPairMaxK) return false;   // (m: the pass also forms the dots of pair k + 1)
     const int vecn = 16 / (int)dtype_size(c.dtype);
-    if (c.n % vecn != 0 || c.n < 4 * vecn || (uint64_t)c.n * dtype_size(c.dtype) >= (1ull << 32)) return false;   // 32-bit byte offsets
+    // (a ragged n never gets here: its tile ring exists as a POINT ring only -- lbfgs_leave_points hands it to the slabs)
+    if (c.n < 4 * vecn || (uint64_t)c.n * dtype_size(c.dtype) >= (1ull << 32)) return false;   // 32-bit byte offsets
     o->refresh_delta_ptrs();
     if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg) || !al16v(o->d)) return false;
     // the twin buffers of x and g: allocated here, before the step touches anything; a failed allocation
@@ -2686,7 +2712,7 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
 // x and g (= point 0) untouched until a trial is accepted, which makes the spare slot point 0.
 // grid of a point pass: the resident blocks, bounded by the partial-sum buffers
 template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedParams<T>), size_t dyn_lds = 0) {
-    const int64_t nvec = o->core.n / Vec16<T>::N;
+    const int64_t nvec = ring_nvec<T>(o);
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     int64_t blocks = (rows + kWaves - 1) / kWaves;
     const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern, dyn_lds);
@@ -2774,11 +2800,7 @@ static int32_t lbfgs_materialize_d(dzo_lbfgs_s *o) {
 template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     hipStream_t s = c.stream;
-    constexpr int N = Vec16<T>::N;
     const int k = o->k;
-    const int64_t nvec = c.n / N;
-    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
-    (void)rows;
     if (k > 0) {
         DZO_TRY(gram_scalars<T>(o));                      // alpha / coef / scale of THIS step (computed behind the last decision)
         o->scalars_ready = false;
@@ -3042,7 +3064,8 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         // blocked (tile-major) ring: when the constructor knows that the single-pass step applies
         const int vecn = 16 / (int)es;
         o->blocked = tl_want_blocked && tune("DZO_TUNE_BLOCKED", 1) != 0 && tune("DZO_TUNE_SINGLE_PASS", 1) != 0 &&
-                     history_length <= point_max_k(dtype) && n % vecn == 0 && n >= 4 * vecn && (uint64_t)n * es < (1ull << 32);
+                     history_length <= point_max_k(dtype) && n >= 4 * vecn && (uint64_t)n * es < (1ull << 32) &&
+                     (n % vecn == 0 || tune("DZO_TUNE_POINT_RING", 1) != 0);   // (a ragged n: phantom padding, load_vec_tail -- on the POINT ring only)
     }
     o->nslots = o->m + (o->blocked ? 2 : 1);
     const int m1 = o->nslots;
@@ -3053,7 +3076,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     o->interleaved = tune("DZO_TUNE_INTERLEAVE", 1) != 0;
     if (o->blocked) {
-        const int64_t nvec = n / (16 / (int64_t)es);
+        const int64_t nvec = (n + 16 / (int64_t)es - 1) / (16 / (int64_t)es);
         o->ring_rows = (nvec + kRowOwn - 1) / kRowOwn;
         {
             const int64_t stream_bytes = ((o->ring_rows * kTileBytes + 1023) / 1024 | 1) * 1024;   // an odd number of KiB (HBM channel skew)
@@ -3142,6 +3165,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         }
         o->k = 0; o->newest = o->nslots - 1;   // spare() == 0
         o->refresh_delta_ptrs();
+        DZO_HIP(hipMemsetAsync(o->d_alloc, 0, (size_t)o->stride * es + 4096, c.stream));   // (the padding behind element n: +0, the first pass reads whole vectors)
         if (o->blocked && tune("DZO_TUNE_POINT_RING", 1) != 0) {
             // point ring: the start point and its gradient are point 0
             o->points = true;
@@ -3493,6 +3517,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
         DZO_TRY(lbfgs_points_settle(o));
         o->points = false;
         lbfgs_mark_unsettled(o);
+        if (ring_ragged(o)) { o->k = 0; DZO_TRY(lbfgs_unblock(o)); }   // (see lbfgs_leave_points; nothing of the old ring is kept)
     }
     o->rho_pending = false;                              // the whole history (and its rho) is replaced
     o->gram_ready = false; o->scalars_ready = false; o->spec_scalars = false;

@@ -38,7 +38,7 @@ template <typename T> __device__ __forceinline__ T rosen_grad_elem(int64_t i, in
 template <typename T> struct RosenCoef { T c400, c2a, c2b, c200; };
 template <typename T> __device__ __forceinline__ RosenCoef<T> rosen_coef(int64_t i, int64_t n) {
     RosenCoef<T> c;
-    const bool nx = i + 1 < n, pv = i > 0;
+    const bool nx = i + 1 < n, pv = i > 0 && i < n;           // (i >= n: the phantom padding of a ragged last vector -- all zero, gradient +0)
     c.c400 = nx ? (T)-400 : (T)0; c.c2a = nx ? (T)2 : (T)0; c.c2b = nx ? (T)-2 : (T)0; c.c200 = pv ? (T)200 : (T)0;
     return c;
 }

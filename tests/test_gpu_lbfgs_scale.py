@@ -99,6 +99,14 @@ CASES = [
     (np.float32, 1_000_000, 14, None),         # fp32, K = 16, stream-major
     (np.float32, 5_000_000, 20, None),         # fp32, K = 20, 20 rows per wave
     (np.float64, 12_000_000, 20, None),        # ring > 4 GiB: 32-bit stream offsets do not fit -> tile-major fallback
+    # ragged n (not a multiple of the 16-byte vector): the last vector of every ring stream is padded with phantom
+    # elements whose stencil coefficients are zero
+    (np.float64, 400_001, 12, None),
+    (np.float64, 400_001, 7, None),            # tile-major
+    (np.float64, 10_000_001, 20, None),        # config 3 + 1
+    (np.float32, 500_001, 10, None),
+    (np.float32, 500_002, 12, 0),
+    (np.float32, 1_000_003, 16, None),
 ]
 
 
