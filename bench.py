@@ -738,6 +738,8 @@ def main():
                          "BASELINE configs, reported as secondary lines.")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default line at N = 1: skip the `secondary` object (configs 2, 4, 5 and AdGD measured after the headline)")
+    ap.add_argument("--decorators", default="", help="lbfgs (sweep rows only, never the default line): decorators of legacy/DZOptimization.jl:219-296 "
+                                                      "on the objective, e.g. 'l2=0.001,box=-1.15:0.95' (box = gradient mask + projection)")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
     ap.add_argument("--batched-steps", type=int, default=0,
                     help="N > 1: timed synchronous steps of the config-5 `batched` object (default: max(--steps, 100))")
@@ -758,7 +760,17 @@ def main():
 
     n, m, esize = args.n, args.m, 8
     x0 = rosenbrock_chain_x0(n, seed=5 + rank)           # each rank optimises its own instance
-    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+    decor = {}
+    for item in filter(None, args.decorators.split(",")):
+        key, val = item.split("=")
+        if key == "l2":
+            decor["l2"] = float(val)
+        elif key == "box":
+            lo, hi = (float(v) for v in val.split(":"))
+            decor["box_gradient"] = (lo, hi); decor["box_constraint"] = (lo, hi)
+        else:
+            raise SystemExit(f"--decorators: unknown item {item!r}")
+    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, **decor)
     x_dev = dzo.DeviceArray.from_host(x0)
     del x0
     opt = dzo.LBFGSOptimizer(None, prob, None, x_dev, 1.0, m)
@@ -870,7 +882,7 @@ def main():
         "value": round(value, 3), "unit": "step!() calls/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])",
+        "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={n}, fp64 (BASELINE configs[2])" + (f" + decorators {args.decorators}" if decor else ""),
                    "n": n, "m": m, "history_full": k == m,
                    "two_loop": ((("single_pass on the point ring (one sweep over the last k+1 POINTS per trial of a step; their gradients "
                                   "are recomputed in registers from the points, pairs formed in registers)" if opt.pass_recomputes_gradients else

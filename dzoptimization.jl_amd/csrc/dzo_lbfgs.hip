@@ -22,6 +22,7 @@
 //          the algorithmic floor of SURVEY.md 8(d) plus one re-read of g.
 #include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -36,6 +37,15 @@ constexpr int kGramValues = 5;  // per pair: s.g, y.g, y.y_p, y.s_p, s.y_p  (p =
 
 struct SlotMap {
     uint8_t slot[kMaxHistory];
+};
+
+struct RingDecor {
+    double l2 = 0; bool bg_on = false; double bg_lo = 0, bg_hi = 0; bool cons_on = false; double cons_lo = 0, cons_hi = 0;
+    bool any() const { return l2 != 0.0 || bg_on || cons_on; }
+    bool operator==(const RingDecor &o) const {
+        return l2 == o.l2 && bg_on == o.bg_on && cons_on == o.cons_on && (!bg_on || (bg_lo == o.bg_lo && bg_hi == o.bg_hi)) &&
+               (!cons_on || (cons_lo == o.cons_lo && cons_hi == o.cons_hi));
+    }
 };
 
 constexpr int kRowOwn = 62;                     // wave-row geometry of the single-pass kernel (see there)
@@ -143,6 +153,11 @@ struct dzo_lbfgs_s {
     // gradient tiles of a slot are formed on demand (lbfgs_ensure_g) when the host asks for current_gradient /
     // delta_gradient / a Y[i], or the ring is turned into the pair ring.  Bit j: slot j's gradient tiles are valid.
     uint32_t g_valid = 0;
+    // The decorators (legacy :219-296) the points of the ring were stored under: the passes recompute every point's
+    // gradient, so a pair y_i = g_i - g_i+1 is only the reference's stored pair while the decorators are the ones that
+    // were in force when those gradients were first formed.  A change on the user's problem handle (this build lets
+    // them be changed between steps) therefore turns the ring into the pair ring under the OLD set (lbfgs_step).
+    dzo::RingDecor ring_dec;
     // The caller's arrays ARE current_point / current_gradient (:393): what the host writes into them between two
     // steps must be what the next step starts from.  On the point ring they are copies of point 0, so whenever the
     // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
@@ -919,6 +934,28 @@ constexpr int kPairMaxK = 20;                  // pairs the single-pass step ove
 static inline int point_max_k(int32_t dtype) { return dtype == DZO_F64 ? 24 : 20; }
 constexpr int kFusedMaxK = 24;                 // two register sets of 2k history vectors: 2*2*20 x 16 B per lane
 
+// The decorators of legacy/DZOptimization.jl:219-296 as the point pass applies them (DEC instantiations), per element:
+//   L2GradientWrapper (:247)            g += (lambda + lambda) x          after the stencil, for every point of the ring and the trial point
+//   UniformBoxGradientWrapper (:289-294) g = 0 where the box pushes back   after that (the order of problem_grad_async / grad_decorate_kernel)
+//   UniformBoxConstraint (:264-272)      x = clamp(x, lo, hi)             the trial point, AFTER the change test of :128 and before :138
+//   L2RegularizationWrapper (:231-232)   f += lambda norm2(x)             two more partial sums per block (the trial point and the one at t/2)
+// A decorator that is off has neutral bounds (-inf, +inf), so only the L2 gradient term needs its flag.
+template <typename T> struct PointDecor {
+    T two_lambda;                              // :247 lambda + lambda, rounded to T
+    T bg_lo, bg_hi;
+    T cons_lo, cons_hi;
+    int l2_on;
+};
+template <typename T> __device__ __forceinline__ T decor_grad(const PointDecor<T> &d, T g, T x) {
+    const T g2 = dfma(d.two_lambda, x, g);
+    g = d.l2_on ? g2 : g;                                          // (not fma(0, x, g): that turns a gradient of -0 into +0)
+    const bool pushed_back = (x <= d.bg_lo && g >= (T)0) || (x >= d.bg_hi && g <= (T)0);
+    return pushed_back ? (T)0 : g;
+}
+template <typename T> __device__ __forceinline__ T decor_clamp(const PointDecor<T> &d, T v) {
+    return v < d.cons_lo ? d.cons_lo : (v > d.cons_hi ? d.cons_hi : v);    // clamp(x[i], lo, hi) :269, as box_clamp_kernel
+}
+
 template <typename T> struct FusedParams {
     int64_t n;
     int k;                                     // pairs read (history before the push)
@@ -947,6 +984,7 @@ template <typename T> struct FusedParams {
     int prio;                                  // point pass: per-phase issue priority (two waves per SIMD)
     int leftover_even;                         // point pass: the last, partial round of rows goes to the even XCDs' blocks first
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
+    PointDecor<T> dec;                         // point pass, DEC instantiations: the decorators of legacy/DZOptimization.jl:219-296
 };
 
 // PLAIN: ablation build with plain instead of non-temporal history loads (DZO_TUNE_SP_DEBUG bit 256,
@@ -1246,7 +1284,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // needs 56 bytes of scratch at 168 -- with 11 instead of 16 staged rows each: n = 1e7, m = 5: 141 against 144 us per pass,
 // m = 8: 161 against 160, m = 10 / 12 (K = 12): 222 / 235 against 203 / 214; n = 1e6 slower throughout.  What did help the
 // small instantiations is asking the occupancy query with the dynamic LDS the launch really uses, see points_grid.)
-template <typename T, int K, bool FIRST = false, int SETS = 2>
+// DEC: the decorators ride along (PointDecor above); separate instantiations, so that the undecorated pass is untouched.
+template <typename T, int K, bool FIRST = false, int SETS = 2, bool DEC = false>
 __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_kernel(FusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
     constexpr int kOwn = kRowOwn, kLead = kRowLead;
@@ -1300,6 +1339,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     TreeSum<kGramValues * (K + 1)> dots;
     dots.init();
     double fobj = 0, fobj_h = 0;
+    double fsq = 0, fsq_h = 0;                                  // DEC: sum of squares of the trial point / the point at t/2 (:232)
     bool diff = false;
     auto byte_offset = [&](int64_t row) -> uint32_t {           // of the lane's vector in the contiguous d
         const int64_t v = row * kOwn - kLead + lane;
@@ -1403,6 +1443,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
                     const T xl = e > 0 ? xv[j][(e + N - 1) % N] : xp;
                     const T xr = e + 1 < N ? xv[j][(e + 1) % N] : xq;
                     gv[j][e] = rosen_grad_coef<T>(rc[e], xl, xv[j][e], xr);
+                    if constexpr (DEC) gv[j][e] = decor_grad<T>(p.dec, gv[j][e], xv[j][e]);
                 }
                 __builtin_amdgcn_sched_barrier(0);               // point by point (the temporaries of 21 stencils at once do not fit)
             }
@@ -1437,12 +1478,20 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         for (int j = 0; j < N; ++j) {
             xn[j] = dfma(p.t, q[j], xv[0][j]);
             diff |= owner && !is_equal(xn[j], xv[0][j]);
+            // :134-135 the projection into the box, after the change test (the phantom padding of a ragged n stays +0)
+            if constexpr (DEC) { const T cl = decor_clamp<T>(p.dec, xn[j]); xn[j] = e0 + j < p.n ? cl : xn[j]; }
         }
         // ---- the objective at HALF the step rides along (:152's next candidate)
         {
             T xh[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) xh[j] = dfma(p.t_half, q[j], xv[0][j]);
+            for (int j = 0; j < N; ++j) {
+                xh[j] = dfma(p.t_half, q[j], xv[0][j]);
+                if constexpr (DEC) {
+                    const T cl = decor_clamp<T>(p.dec, xh[j]); xh[j] = e0 + j < p.n ? cl : xh[j];
+                    if (owner) fsq_h = __builtin_fma((double)xh[j], (double)xh[j], fsq_h);      // :232 norm2(x), as sumsq_kernel
+                }
+            }
             const T xhnext = lane_next0<T>(xh[0]);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -1459,6 +1508,10 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
             const T xp = j > 0 ? xn[(j + N - 1) % N] : xprev;
             const T xq = j + 1 < N ? xn[(j + 1) % N] : xnext;
             gn[j] = rosen_grad_coef<T>(rc[j], xp, xn[j], xq);
+            if constexpr (DEC) {
+                gn[j] = decor_grad<T>(p.dec, gn[j], xn[j]);
+                if (owner) fsq = __builtin_fma((double)xn[j], (double)xn[j], fsq);
+            }
             sn[j] = xn[j] - xv[0][j];                               // :145
             yn[j] = gn[j] - gv[0][j];                               // :478-480
             if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
@@ -1619,6 +1672,11 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     const double fo = block_sum(fobj, lds);
     const double fh = block_sum(fobj_h, lds);
     if (threadIdx.x == 0) { p.obj_partials[pcol] = fo; p.obj_partials[pstride + pcol] = fh; }
+    if constexpr (DEC) {
+        const double so = block_sum(fsq, lds);
+        const double sh = block_sum(fsq_h, lds);
+        if (threadIdx.x == 0) { p.obj_partials[2 * pstride + pcol] = so; p.obj_partials[3 * pstride + pcol] = sh; }
+    }
     if ((p.debug_skip & 1024) && blockIdx.x < 1024) { if (lane == 0) g_dev_wave_times[(blockIdx.x * kWaves + wave) * 2 + 1] = wall_clock64(); }
 }
 
@@ -1661,7 +1719,8 @@ __global__ __launch_bounds__(kBlock) void ring_diff_kernel(int64_t rows, T *__re
 // the gradient tiles of a point from its point tiles (point ring; the passes do not write them): every tile position,
 // halo copies included, evaluates rosen_grad_elem on its vector -- the bits the pass had in registers
 template <typename T>
-__global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t nvec, const T *__restrict__ xs, T *__restrict__ gs, int64_t rowbytes) {
+__global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t nvec, const T *__restrict__ xs, T *__restrict__ gs, int64_t rowbytes,
+                                                             PointDecor<T> dec, int dec_on) {
     constexpr int N = Vec16<T>::N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
@@ -1676,6 +1735,10 @@ __global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t 
 #pragma unroll
         for (int e = 0; e < N; ++e)             // (an element past n -- the padding of a ragged last vector -- has gradient +0)
             g[e] = v * N + e < n ? rosen_grad_elem<T>(v * N + e, n, e > 0 ? x[(e + N - 1) % N] : xl, x[e], e + 1 < N ? x[(e + 1) % N] : xr) : (T)0;
+        if (dec_on) {                                       // (the decorated gradient, as the DEC pass forms it)
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] = decor_grad<T>(dec, g[e], x[e]);
+        }
         store16(reinterpret_cast<T *>(reinterpret_cast<char *>(gs) + row * rowbytes + pos * 16), g);
     }
 }
@@ -2144,6 +2207,20 @@ static int32_t lbfgs_speculative_tail(void *self, const int32_t *gate) {
 }
 
 // ---------------------------------------------------------------------------- blocked ring, host side
+template <typename T> static inline PointDecor<T> point_decor(const RingDecor &r) {
+    PointDecor<T> d;
+    // :247 lambda + lambda in T (as problem_grad_async)
+    d.two_lambda = sizeof(T) == 4 ? (T)((float)r.l2 + (float)r.l2) : (T)(r.l2 + r.l2);
+    d.l2_on = r.l2 != 0.0 ? 1 : 0;
+    d.bg_lo = r.bg_on ? (T)r.bg_lo : -std::numeric_limits<T>::infinity(); d.bg_hi = r.bg_on ? (T)r.bg_hi : std::numeric_limits<T>::infinity();
+    d.cons_lo = r.cons_on ? (T)r.cons_lo : -std::numeric_limits<T>::infinity(); d.cons_hi = r.cons_on ? (T)r.cons_hi : std::numeric_limits<T>::infinity();
+    return d;
+}
+static inline RingDecor ring_decor_of(const dzo_problem_s *p) {
+    RingDecor r;
+    if (p) { r.l2 = p->l2; r.bg_on = p->bg_on; r.bg_lo = p->bg_lo; r.bg_hi = p->bg_hi; r.cons_on = p->cons_on; r.cons_lo = p->cons_lo; r.cons_hi = p->cons_hi; }
+    return r;
+}
 // vectors of 16 bytes a ring stream holds: the last one is padded with phantom elements when n is ragged (see load_vec_tail)
 template <typename T> static inline int64_t ring_nvec(const dzo_lbfgs_s *o) { return (o->core.n + Vec16<T>::N - 1) / Vec16<T>::N; }
 static inline bool ring_ragged(const dzo_lbfgs_s *o) { return o->core.n % (16 / (int64_t)dtype_size(o->core.dtype)) != 0; }
@@ -2179,7 +2256,7 @@ static int32_t lbfgs_ensure_g(dzo_lbfgs_s *o, int slot) {
     DZO_TIMED("lbfgs_ring_regrad", c.stream);
     const int grid = stream_grid(o->ring_rows * 64, 1);
     DZO_DISPATCH(c.dtype, hipLaunchKernelGGL(ring_regrad_kernel<T>, dim3(grid), dim3(kBlock), 0, c.stream, c.n, ring_nvec<T>(o),
-                                             (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes));
+                                             (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes, point_decor<T>(o->ring_dec), o->ring_dec.any() ? 1 : 0));
     DZO_HIP(hipGetLastError());
     o->g_valid |= 1u << slot;
     return DZO_OK;
@@ -2541,8 +2618,9 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
 static bool points_ok(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
     if (!o->points || !o->single_pass || !o->blocked || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
-    if (c.objective || c.gradient || c.constraint || c.box_on || !o->speculate || !o->fused_post || !c.problem) return false;
-    if (c.problem->kind != DZO_PROBLEM_ROSENBROCK_CHAIN || c.problem->l2 != 0.0 || c.problem->bg_on || c.problem->cons_on) return false;
+    if (c.objective || c.gradient || c.constraint || !o->speculate || !o->fused_post || !c.problem) return false;
+    // (the decorators of legacy :219-296 ride on the pass: its DEC instantiations, under the set the ring was stored with)
+    if (c.problem->kind != DZO_PROBLEM_ROSENBROCK_CHAIN || !(ring_decor_of(c.problem) == o->ring_dec)) return false;
     if (o->k > point_max_k(c.dtype) || o->m > point_max_k(c.dtype) || !al16v(o->d)) return false;
     if (o->k > 0 && !o->spec_scalars) return false;       // (the scalars come from the previous pass; anything else goes through Gram passes)
     return true;
@@ -2718,7 +2796,7 @@ template <typename T> static int points_grid(dzo_lbfgs_s *o, void (*kern)(FusedP
     const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern, dyn_lds);
     if (blocks > res) blocks = res;
     if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
-    if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;             // two objective partials per block in the problem scratch
+    if (blocks > kMaxPartialBlocks / 2) blocks = kMaxPartialBlocks / 2;     // up to four partial sums per block in the problem scratch (2 kMaxPartialBlocks doubles)
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
@@ -2728,6 +2806,23 @@ template <typename T> static bool point_one_set(const dzo_lbfgs_s *o) { return o
 // the instantiation of the point pass for this optimizer: the smallest K that holds m pairs; one or two register sets
 // (DZO_TUNE_POINT_SETS; see the kernel)
 template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(FusedParams<T>) {
+    if (o->ring_dec.any()) {
+        // the decorated pass (DEC): fewer instantiations, the next larger K serves the history lengths in between
+        if (point_one_set<T>(o)) {
+            if constexpr (sizeof(T) == 8) {
+                return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1, true>
+                       : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1, true>
+                       : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1, true>
+                       : lbfgs_point_pass_kernel<T, 20, false, 1, true>;
+            } else {
+                return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1, true> : lbfgs_point_pass_kernel<T, 12, false, 1, true>;
+            }
+        }
+        if constexpr (sizeof(T) == 8) { if (o->m > 20) return lbfgs_point_pass_kernel<T, 24, false, 2, true>; }
+        return o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 2, true>
+               : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 2, true>
+               : lbfgs_point_pass_kernel<T, 20, false, 2, true>;
+    }
     if (point_one_set<T>(o)) {
         if constexpr (sizeof(T) == 8) {
             // (K = 10: m = 10 is the history length most L-BFGS users ask for; on the K = 12 instantiation it paid for two
@@ -2754,7 +2849,7 @@ template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(Fused
 }
 // first: the first step's kernel
 template <typename T> static void (*point_pass_kernel_for(dzo_lbfgs_s *o, bool first))(FusedParams<T>) {
-    if (first) return lbfgs_point_pass_kernel<T, 8, true>;
+    if (first) return o->ring_dec.any() ? lbfgs_point_pass_kernel<T, 8, true, 2, true> : lbfgs_point_pass_kernel<T, 8, true>;
     return point_pass_kernel_sel<T>(o);
 }
 
@@ -2778,6 +2873,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
     fp.debug_skip = 1 | 64;                               // no pair dots, no tile stores (and with them no halo copies)
+    fp.dec = point_decor<T>(o->ring_dec);
     fp.stage_rows = 1;
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, false);
     const int grid = points_grid<T>(o, kern);
@@ -2818,6 +2914,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.obj_partials = c.problem->scratch;
     fp.changed = c.flag();
     fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
+    fp.dec = point_decor<T>(o->ring_dec);
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, k == 0);
     fp.store_d = o->lazy_d ? 0 : 1;
     {
@@ -2880,6 +2977,10 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
                 const int nvals = kGramValues * o->k;
                 DecideArgs da = decide_args(c, fp.obj_partials, pgrid, 1.0);
                 da.partials2 = fp.obj_partials + pgrid;   // f(x + t/2 d)
+                if (o->ring_dec.l2 != 0.0) {              // :232  + lambda * norm2(x), both candidates
+                    da.l2_partials = fp.obj_partials + 2 * pgrid; da.l2_partials2 = fp.obj_partials + 3 * pgrid;
+                    da.l2_lambda = o->ring_dec.l2;
+                }
                 hipLaunchKernelGGL(gram_reduce_decide_kernel, dim3(nvals + 1), dim3(kBlock), 0, s, (const double *)o->gram_partials, pgrid, vals,
                                    nvals, da);
                 c.flag_armed = true;
@@ -3028,6 +3129,7 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
 using namespace dzo;
 
 static thread_local bool tl_want_blocked = false;       // dzo_lbfgs_create_problem -> dzo_lbfgs_create
+static thread_local RingDecor tl_ring_dec;              // ... and the decorators the start point's gradient was formed under
 
 // ============================================================================ C ABI
 extern "C" {
@@ -3047,6 +3149,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     OptCore &c = o->core;
     c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
     o->x_user = x_dev; o->g_user = g_dev; o->device = ctx().device;
+    o->ring_dec = tl_ring_dec;
     c.f = round_to_dtype(dtype, initial_objective_value);
     o->m = history_length;
     const size_t es = dtype_size(dtype);
@@ -3249,10 +3352,11 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
     DZO_HIP(hipMalloc(&g, (size_t)((problem->n + 63) / 64 * 64) * dtype_size(problem->dtype)));
     int32_t rc = dzo_problem_grad(problem, g, x_dev);     // :421
     // the single-pass step will apply (built-in chained Rosenbrock, no decorators): tile-major history ring
-    tl_want_blocked = problem->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && problem->l2 == 0.0 && !problem->bg_on && !problem->cons_on &&
-                      (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
+    tl_want_blocked = problem->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
+    tl_ring_dec = ring_decor_of(problem);
     if (rc == DZO_OK) rc = dzo_lbfgs_create(problem->n, history_length, problem->dtype, x_dev, g, f0, initial_step_length, out);
     tl_want_blocked = false;
+    tl_ring_dec = RingDecor();
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
     rc = problem_view_create(problem, &(*out)->core.problem);    // private partial-sum workspace per optimizer

@@ -92,6 +92,11 @@ struct DecideArgs {
     int32_t *status;
     double *host_out;          // pinned host mirror: [0] f_new, [3] status, [4] changed, [7] ticket
     double ticket;
+    // L2RegularizationWrapper (legacy/DZOptimization.jl:231-232) riding on the decorated point pass: per-block partials of
+    // norm2 of the trial point (and of the point at half the step); f_new = f + lambda * norm2(x) in T arithmetic, as
+    // l2_finish_kernel (dzo_problems.hip) forms it.  nullptr = no L2 term.
+    const double *l2_partials = nullptr, *l2_partials2 = nullptr;
+    double l2_lambda = 0;
 };
 DecideArgs decide_args(OptCore &c, const double *partials, int64_t count, double scale);   // (takes the next ticket)
 
@@ -108,6 +113,18 @@ __device__ __forceinline__ void decide_body(const DecideArgs &a, double *lds) {
         block_sum_multi<2>(v, lds2, out);
         f_new = a.scale * out[0];
         f_second = a.scale * out[1];
+        if (a.l2_partials) {                                     // (uniform; only the decorated pass sets it)
+            double w[2] = {0, 0}, ss[2];
+            for (int64_t i = threadIdx.x; i < a.count; i += kBlock) { w[0] += a.l2_partials[i]; w[1] += a.l2_partials2[i]; }
+            block_sum_multi<2>(w, lds2, ss);
+            if (a.to_f32) {
+                f_new = (double)((float)f_new + (float)a.l2_lambda * (float)ss[0]);
+                f_second = (double)((float)f_second + (float)a.l2_lambda * (float)ss[1]);
+            } else {
+                f_new = f_new + a.l2_lambda * ss[0];
+                f_second = f_second + a.l2_lambda * ss[1];
+            }
+        }
         if (threadIdx.x == 0) a.result[0] = f_new;
     } else {
         if (a.partials) {

@@ -30,11 +30,21 @@ def run(cases=60, seed=2468):
         m = int(rng.integers(1, 25 if dtype == np.float64 else 21))     # (fp64: up to the K = 24 instantiation)
         step0 = float(rng.choice([1e-2, 1.0, 1.0, 30.0, 3000.0]))
         x0 = ((orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5) * 2.0).astype(dtype)
+        # a third of the cases with decorators (legacy/DZOptimization.jl:219-296) riding on the pass
+        decor = {}
+        which = int(rng.integers(0, 9))
+        if which in (0, 2):
+            decor["l2"] = float(rng.choice([1e-3, 0.05]))
+        if which in (1, 2):
+            lo, hi = float(rng.choice([-0.8, -0.3])), float(rng.choice([0.5, 0.95]))
+            decor["box_gradient"] = (lo, hi)
+            if rng.integers(0, 4):
+                decor["box_constraint"] = (lo, hi)
         if dtype == np.float32:
             orc.set_dot_mode(orc.DOT_WIDE)
         try:
-            ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), step0, m)
-            opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), step0, m)
+            ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype, **decor), x0.copy(), step0, m)
+            opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype, **decor), None, dzo.DeviceArray.from_host(x0), step0, m)
             assert opt.ring_layout == 2, (n, m)
             for it in range(int(rng.integers(3, 2 * m + 8))):
                 k = opt.history_count
@@ -56,16 +66,16 @@ def run(cases=60, seed=2468):
                     moved = ref if opt.is_stuck else opt
                     decrease = f_before - moved.current_objective_value
                     assert decrease <= 1e-13 * abs(f_before) or min(opt.last_trials, ref.last_trials) > 30, (
-                        ex, it, n, m, step0, opt.last_trials, ref.last_trials, f_before, decrease, opt.is_stuck, ref.is_stuck)
+                        ex, it, n, m, step0, decor, opt.last_trials, ref.last_trials, f_before, decrease, opt.is_stuck, ref.is_stuck)
                     break
                 if ref.is_stuck:
                     break
                 if ref.last_trials > 30 and opt.last_trials != ref.last_trials:
                     break        # dozens of halvings: f_new - f is at rounding level, the two summation orders may decide differently
-                assert opt.last_trials == ref.last_trials, (ex, it, n, m, step0, opt.last_trials, ref.last_trials)
+                assert opt.last_trials == ref.last_trials, (ex, it, n, m, step0, decor, opt.last_trials, ref.last_trials)
                 e = rel(opt.step_direction.to_host(), ref.step_direction)
                 worst[dtype] = max(worst[dtype], e)
-                assert e <= (1e-9 if dtype == np.float64 else 1e-3), (ex, it, n, m, step0, e)
+                assert e <= (1e-9 if dtype == np.float64 else 1e-3), (ex, it, n, m, step0, decor, e)
                 ex_ = rel(opt.current_point.to_host(), ref.current_point)
                 # (x_new = x + t d: the point inherits at most the direction's relative error -- seed 404, case 299, fp32, n = 16:
                 # direction 2.2e-5 off, within its tolerance, and the point 8.9e-6)

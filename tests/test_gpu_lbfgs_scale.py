@@ -33,9 +33,12 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
+DECOR = {}                 # decorators of the problem in the cases that set them (legacy/DZOptimization.jl:219-296)
+
+
 def _make(n, m, dtype, step0=1.0):
     x0 = orc.rosenbrock_chain_x0(n, dtype)
-    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), step0, m)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype, **DECOR), None, dzo.DeviceArray.from_host(x0), step0, m)
     return x0, opt
 
 
@@ -182,6 +185,57 @@ def test_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n, m, arrang
             assert opt.current_objective_value == f_scout
         opt.close(); ref.close()
     finally:
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+        orc.set_threads(1)
+
+
+_DECOR_AT_SCALE = [
+    (np.float64, 400_000, 12, dict(l2=0.01)),
+    (np.float64, 400_001, 8, dict(box_gradient=(-1.1, 0.9), box_constraint=(-1.1, 0.9))),
+    (np.float64, 2_500_000, 20, dict(l2=0.01, box_gradient=(-1.1, 0.9), box_constraint=(-1.1, 0.9))),
+    (np.float64, 10_000_000, 20, dict(l2=0.001, box_gradient=(-1.15, 0.95), box_constraint=(-1.15, 0.95))),
+    (np.float64, 400_000, 22, dict(l2=0.01, box_gradient=(-1.1, 0.9), box_constraint=(-1.1, 0.9))),
+    (np.float32, 500_000, 10, dict(l2=0.01, box_gradient=(-1.1, 0.9), box_constraint=(-1.1, 0.9))),
+    (np.float32, 1_000_002, 16, dict(l2=0.01, box_gradient=(-1.1, 0.9))),
+]
+
+
+@pytest.mark.parametrize("dtype,n,m,decor", _DECOR_AT_SCALE, ids=[f"{np.dtype(d).name}-n{n}-m{m}-{'+'.join(sorted(k))}" for d, n, m, k in _DECOR_AT_SCALE])
+def test_decorated_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n, m, decor, monkeypatch):
+    """The DEC instantiations of the pass (L2 term, box-gradient mask, box projection riding along) at the
+    sizes where a wave takes many rows: same protocol as the undecorated cases -- scout run, then the oracle follows the
+    GPU's state through the first two steps with a full history and the first rejected first trial."""
+    DECOR.clear(); DECOR.update(decor)
+    orc.set_threads(8)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)
+    try:
+        step0, trials, f_scout = _scout(n, m, dtype, None)
+        L = len(trials)
+        assert L >= 9, (L, "run too short to check anything")
+        if L >= m + 3:
+            rejected = next((i for i in range(m + 2, L - 2) if 1 < trials[i] <= 20), None)
+            checked = [m, m + 1] + ([rejected] if rejected is not None else [])
+        else:
+            checked = [L - 6, L - 5, L - 4]
+        x0, opt = _make(n, m, dtype, step0=step0)
+        ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype, **decor)
+        ref = orc.LBFGS(ref_p, x0.copy(), step0, m)
+        it = 0
+        for target in checked:
+            while it < target:
+                opt.step(); it += 1
+                assert opt.last_trials == trials[it - 1], (it, "the trajectory is not reproducible")
+            t = _checked_step(opt, ref, n, dtype, (n, m, "step", target))
+            assert t == trials[target]
+            x = opt.current_point.to_host()
+            assert np.array_equal(opt.current_gradient.to_host(), ref_p.grad(x))      # the decorated gradient, bit-exact
+            if "box_constraint" in decor:
+                assert x.min() >= dtype(decor["box_constraint"][0]) and x.max() <= dtype(decor["box_constraint"][1])
+            it += 1
+        opt.close(); ref.close()
+    finally:
+        DECOR.clear()
         orc.set_dot_mode(orc.DOT_SEQUENTIAL)
         orc.set_threads(1)
 
