@@ -715,6 +715,64 @@ def _two_pass_leg(dzo, n, m, esize, args):
     return out
 
 
+def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
+    """Config 3 as the callers beside the headline see it, measured after the timed region:
+    `callbacks`  the reference's real API -- constraint / objective / gradient supplied as C function pointers
+                 (dzo_problem_*_cb: dzo_problem_eval / dzo_problem_grad behind the callback signature, what the Julia host's
+                 closures do), i.e. the GENERAL two-pass step: Gram pass + reduce + finish + combine, trial, accept, delta kernels;
+    `decorated`  the built-in objective with L2 regularisation + box gradient mask + box projection (legacy :219-296) riding
+                 on the point pass (its DEC instantiation);
+    `ragged`     n + 1 (not a multiple of the 16-byte vector), phantom-padded point ring.
+    Rate from a stretch without any event record; the per-kernel table from a second, untimed stretch."""
+    nn = n + 1 if kind == "ragged" else n
+    decor = dict(l2=1e-3, box_gradient=(-1.15, 0.95), box_constraint=(-1.15, 0.95)) if kind == "decorated" else {}
+    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, nn, **decor)
+    x = dzo.DeviceArray.from_host(rosenbrock_chain_x0(nn, seed=5))
+    if kind == "callbacks":
+        opt = dzo.LBFGSOptimizer(None, prob.native_callbacks(), None, x, 1.0, m)
+    else:
+        opt = dzo.LBFGSOptimizer(None, prob, None, x, 1.0, m)
+    for _ in range(m + args.warmup):
+        opt.step()
+    steps = max(20, min(args.steps, 50))
+    dzo.synchronize()
+    trials = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.step()
+        trials += opt.last_trials
+    dzo.synchronize()
+    el = time.perf_counter() - t0
+    dzo.profile_reset(); dzo.profile_enable(2)
+    for _ in range(10):
+        opt.step()
+    dzo.synchronize()
+    dzo.profile_enable(False)
+    tab = dzo.profile_table()
+    k = opt.history_count
+    kern = {nm: {"launches": c, "avg_us": round(1e3 * ms / c, 2)} for nm, (c, ms) in sorted(tab.items(), key=lambda kv: -kv[1][1]) if c}
+    out = {"metric": "step!() calls/s", "value": round(steps / el, 2), "unit": "step!() calls/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
+           "dtype": "f64", "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={nn}, fp64: {kind}", "n": nn, "m": m,
+                                      "history_layout": {0: "slabs", 1: "tiles of pairs", 2: "tiles of points"}[opt.ring_layout],
+                                      "objective_evals_per_step": round(trials / steps, 3), "any_stuck": bool(opt.is_stuck),
+                                      "decorators": decor or None},
+           "kernels": kern}
+    dom = "lbfgs_single_pass" if "lbfgs_single_pass" in tab else "lbfgs_gram_pass"
+    if dom in kern:
+        us = kern[dom]["avg_us"]
+        nb = _kernel_bytes(dom, nn, k, esize, opt.ring_layout, opt.pass_recomputes_gradients)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(nb / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": nb, "avg_launch_us": us}
+        names = ("lbfgs_gram_pass", "lbfgs_gram_reduce", "lbfgs_gram_finish", "lbfgs_gram_reduce_finish", "lbfgs_combine")
+        if "lbfgs_combine" in tab and "lbfgs_gram_pass" in tab:
+            us2 = sum(1e3 * tab[x][1] for x in names if x in tab) / max(tab["lbfgs_combine"][0], 1)
+            nb2 = (4 * k + 2) * nn * esize
+            out["roofline"]["two_loop"] = {"avg_us": round(us2, 1), "algorithmic_bytes": nb2, "achieved": round(nb2 / (us2 * 1e-6) / 1e9, 1),
+                                           "frac": round(nb2 / (us2 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    opt.close()
+    return out
+
+
 # ------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -740,6 +798,8 @@ def main():
                     help="default line at N = 1: skip the `secondary` object (configs 2, 4, 5 and AdGD measured after the headline)")
     ap.add_argument("--decorators", default="", help="lbfgs (sweep rows only, never the default line): decorators of legacy/DZOptimization.jl:219-296 "
                                                       "on the objective, e.g. 'l2=0.001,box=-1.15:0.95' (box = gradient mask + projection)")
+    ap.add_argument("--variant", default="", choices=["", "callbacks", "decorated", "ragged"],
+                    help="lbfgs: print only the line of one variant leg of the `secondary` object (dev)")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
     ap.add_argument("--batched-steps", type=int, default=0,
                     help="N > 1: timed synchronous steps of the config-5 `batched` object (default: max(--steps, 100))")
@@ -759,6 +819,9 @@ def main():
     info = dzo.device_info()
 
     n, m, esize = args.n, args.m, 8
+    if args.variant:
+        print(json.dumps(_lbfgs_variant_leg(dzo, n, m, esize, args, args.variant)))
+        return
     x0 = rosenbrock_chain_x0(n, seed=5 + rank)           # each rank optimises its own instance
     decor = {}
     for item in filter(None, args.decorators.split(",")):
@@ -938,6 +1001,14 @@ def main():
         # profiling / A-B commands all pass --no-cpu-baseline and stay as they were)
         opt.close()
         out["secondary"] = secondary_in_line(args, dzo, sharding, info)
+        for kind in ("callbacks", "decorated", "ragged"):
+            t_leg = time.perf_counter()
+            try:
+                leg = _lbfgs_variant_leg(dzo, n, m, esize, args, kind)
+                leg["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
+                out["secondary"]["lbfgs_" + kind] = leg
+            except Exception as e:                              # noqa: BLE001 -- reported in the line
+                out["secondary"]["lbfgs_" + kind] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

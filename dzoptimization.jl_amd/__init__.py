@@ -168,6 +168,7 @@ ABI = {
     "dzo_negate": [_i64, _i32, _vp], "dzo_scal_oop": [_i64, _i32, _vp, _dbl, _vp],
     "dzo_problem_create": [_i32, _i64, _i32, _vp, _vp, _dbl, _P(_vp)], "dzo_problem_destroy": [_vp],
     "dzo_problem_eval": [_vp, _vp, _P(_dbl)], "dzo_problem_grad": [_vp, _vp, _vp],
+    "dzo_problem_objective_cb": [_vp, _vp], "dzo_problem_gradient_cb": [_vp, _vp, _vp], "dzo_problem_constraint_cb": [_vp, _vp],
     "dzo_problem_set_l2": [_vp, _dbl], "dzo_problem_set_box_gradient": [_vp, _i32, _dbl, _dbl],
     "dzo_problem_set_box_constraint": [_vp, _i32, _dbl, _dbl], "dzo_box_clamp": [_i64, _i32, _vp, _dbl, _dbl],
     "dzo_lbfgs_create": [_i64, _i32, _i32, _vp, _vp, _dbl, _dbl, _P(_vp)],
@@ -228,6 +229,8 @@ def _declare(L):
         fn = getattr(L, name)           # AttributeError here = symbol missing from the library
         fn.argtypes = args
         fn.restype = C.c_int32
+    L.dzo_problem_objective_cb.restype = C.c_double
+    L.dzo_problem_gradient_cb.restype = None
     L.dzo_last_error.restype = C.c_char_p
     L.dzo_last_error.argtypes = []
     L.dzo_version.restype = C.c_int32
@@ -456,6 +459,14 @@ class Problem:
         _check(lib().dzo_problem_grad(self.h, g.ptr, x.ptr))
         return g
 
+    def native_callbacks(self, with_constraint=False):
+        """This objective in the shape of the reference's three callbacks (src/DZOptimization.jl:323-325): C function
+        pointers exported by the library (``dzo_problem_*_cb``, ctx = the problem handle).  Pass the result as
+        ``objective_function`` of an optimizer (the other two callback arguments are then ignored): it runs its
+        general, callback-driven path with no Python frame in the loop -- what a Julia host's closures over
+        ``dzo_problem_eval`` / ``dzo_problem_grad`` amount to."""
+        return NativeCallbacks(self, with_constraint)
+
     def __del__(self):
         try:
             if self.h and _lib is not None:
@@ -463,6 +474,18 @@ class Problem:
                 self.h = None
         except Exception:
             pass
+
+
+class NativeCallbacks:
+    """See :meth:`Problem.native_callbacks`."""
+
+    def __init__(self, problem, with_constraint=False):
+        self.problem = problem
+        L = lib()
+        self.cf = C.cast(L.dzo_problem_constraint_cb, CONSTRAINT_FN) if with_constraint else C.cast(None, CONSTRAINT_FN)
+        self.of = C.cast(L.dzo_problem_objective_cb, OBJECTIVE_FN)
+        self.gf = C.cast(L.dzo_problem_gradient_cb, GRADIENT_FN)
+        self.ctx = problem.h
 
 
 def _wrap_callbacks(constraint, objective, gradient, n, dtype):
@@ -584,6 +607,11 @@ class LBFGSOptimizer(_OptBase):
             self.problem = objective_function
             _check(lib().dzo_lbfgs_create_problem(self.problem.h, self.history_length, x.ptr,
                                                   initial_step_length, C.byref(h)))
+        elif isinstance(objective_function, NativeCallbacks):
+            nc = objective_function
+            assert g0 is None, "native callbacks: use the short constructor (:400-407)"
+            _check(lib().dzo_lbfgs_create_callbacks(nc.cf, nc.of, nc.gf, nc.ctx, self.n, self.history_length,
+                                                    _dt(self.dtype), x.ptr, initial_step_length, C.byref(h)))
         else:
             if isinstance(objective_function, Problem):
                 p = objective_function
@@ -1157,7 +1185,7 @@ def step_(opt):
 
 
 __all__ = [
-    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "Comm", "batches_all_done", "LineSearchEvaluator", "Problem", "DeviceArray", "step_",
+    "LBFGSOptimizer", "BFGSOptimizer", "AdGDOptimizer", "GradientDescentOptimizer", "BatchedBFGS", "Comm", "batches_all_done", "LineSearchEvaluator", "Problem", "NativeCallbacks", "DeviceArray", "step_",
     "axpy_", "axpby_", "rmul_", "copy_", "fill_", "dot", "norm", "isequal", "trial_point_", "box_clamp_",
     "norm2", "inv_norm", "negate_", "scale_",
     "update_inverse_hessian_", "update_inverse_hessian_mfma_", "symv_", "init", "build", "lib", "device_info", "device_count", "synchronize",

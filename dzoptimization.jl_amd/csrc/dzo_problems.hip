@@ -5,6 +5,8 @@
 // (legacy/ExampleFunctions.jl:10-24, README.md:25-31).  Elementwise expressions are the same
 // explicit-fma expressions as oracle/dzo_oracle_impl.h so values agree bit-for-bit per term;
 // only the (deterministic, two-stage) reduction order differs.
+#include <limits>
+
 #include "dzo_problems.h"
 #include "dzo_rosen.h"
 
@@ -1009,6 +1011,24 @@ int32_t dzo_problem_grad(dzo_problem_t p, void *g_dev, const void *x_dev) {
     DZO_TRY(problem_grad_async(p, ctx().stream, g_dev, x_dev));
     DZO_HIP(hipStreamSynchronize(ctx().stream));
     return DZO_OK;
+}
+
+// the built-in objectives in the shape of the reference's callbacks (src/DZOptimization.jl:323-325); ctx = dzo_problem_t
+double dzo_problem_objective_cb(void *problem, const void *x_dev) {
+    double f = 0;
+    if (dzo_problem_eval(static_cast<dzo_problem_t>(problem), x_dev, &f) != DZO_OK) return std::numeric_limits<double>::infinity();
+    return f;
+}
+void dzo_problem_gradient_cb(void *problem, void *g_dev, const void *x_dev) {
+    dzo_problem_t p = static_cast<dzo_problem_t>(problem);
+    if (dzo_problem_grad(p, g_dev, x_dev) != DZO_OK && p && g_dev)
+        (void)hipMemset(g_dev, 0xff, (size_t)p->n * dtype_size(p->dtype));    // NaN in both element types
+}
+int32_t dzo_problem_constraint_cb(void *problem, void *x_dev) {
+    dzo_problem_t p = static_cast<dzo_problem_t>(problem);
+    if (!p || !x_dev) return 0;
+    if (!p->cons_on) return 1;
+    return dzo_box_clamp(p->n, p->dtype, x_dev, p->cons_lo, p->cons_hi) == DZO_OK ? 1 : 0;
 }
 
 }  // extern "C"

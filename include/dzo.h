@@ -189,6 +189,17 @@ int32_t dzo_problem_set_box_constraint(dzo_problem_t p, int32_t enable, double l
 int32_t dzo_box_clamp(int64_t n, int32_t dtype, void *x_dev, double lower_bound, double upper_bound);
 int32_t dzo_problem_eval(dzo_problem_t p, const void *x_dev, double *f);
 int32_t dzo_problem_grad(dzo_problem_t p, void *g_dev, const void *x_dev);
+/* The built-in objectives in the SHAPE of the reference's three callbacks (src/DZOptimization.jl:323-325,
+ * called at :134-138 and :479): pass these function pointers with ctx = the dzo_problem_t to
+ * dzo_lbfgs_create_callbacks / dzo_adgd_create_callbacks and the optimizer runs its general (callback)
+ * path on a device-side objective -- what a Julia host does when its callbacks are closures over
+ * dzo_problem_eval / dzo_problem_grad, without a host-language frame in the loop.  The constraint
+ * callback projects into the problem's box (legacy/DZOptimization.jl:264-272) when one is set and
+ * reports the point feasible; an error inside a callback is reported as +Inf / a NaN-filled gradient
+ * / infeasible, since the reference's callbacks have no error channel. */
+double dzo_problem_objective_cb(void *problem, const void *x_dev);
+void dzo_problem_gradient_cb(void *problem, void *g_dev, const void *x_dev);
+int32_t dzo_problem_constraint_cb(void *problem, void *x_dev);
 
 /* ---------------------------------------------------------------------------------------
  * LBFGSOptimizer  (src/DZOptimization.jl:321-509)

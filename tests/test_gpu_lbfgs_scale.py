@@ -342,3 +342,48 @@ def test_issue_priorities_and_wave_clocks_leave_the_results_alone(dtype, n, m, m
     t = np.array(buf, dtype=np.uint64).reshape(-1, 2)
     assert (t[:, 1] > t[:, 0]).all()                                   # every wave of the first eight blocks: end after start
     assert lib.dzo_debug_wave_times(buf, 0) != 0 and lib.dzo_debug_wave_times(buf, 1 << 20) != 0   # count checked
+
+
+@pytest.mark.parametrize("n,m,constraint", [(1_000_000, 10, False), (2_500_001, 20, False), (1_000_000, 7, True)],
+                         ids=["n1000000-m10", "n2500001-m20", "n1000000-m7-box"])
+def test_callback_path_at_scale_matches_the_oracle_step_by_step(n, m, constraint):
+    """The reference's real API at scale: objective, gradient (and constraint) handed over as C function
+    pointers -- the library's dzo_problem_*_cb, i.e. dzo_problem_eval / dzo_problem_grad behind the callback signature,
+    what the Julia host's closures do -- so step!() runs its general path: Gram pass + reduce + finish + combine, trial
+    kernel, callbacks (src/DZOptimization.jl:134-138, :479), accept and delta kernels on the slab ring.  Per step from the
+    oracle's installed state: direction <= 1e-10, point, gradient bit-exact, objective value, trial counts."""
+    orc.set_threads(8)
+    try:
+        decor = dict(box_gradient=(-1.1, 0.9), box_constraint=(-1.1, 0.9)) if constraint else {}
+        x0 = orc.rosenbrock_chain_x0(n)
+        prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, **decor)
+        ref_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, **decor)
+        opt = dzo.LBFGSOptimizer(None, prob.native_callbacks(with_constraint=constraint), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        ref = orc.LBFGS(ref_p, x0.copy(), 1.0, m)
+        assert opt.ring_layout == 0                       # callbacks: the slab ring and the two-pass kernels
+        assert np.array_equal(opt.current_point.to_host(), ref.current_point)      # (:412-414 projected start when there is a constraint)
+        for it in range(m + 4):
+            S, Y = ref.history_arrays()
+            opt.current_point.upload(ref.current_point); opt.current_gradient.upload(ref.current_gradient)
+            opt.set_objective_value(ref.current_objective_value)
+            opt.set_history(S, Y, ref.rho_history, iteration_count=ref.iteration_count)
+            del S, Y
+            x_before, g_before = ref.current_point.copy(), ref.current_gradient.copy()
+            opt.step(); ref.step()
+            assert not opt.is_stuck and not ref.is_stuck, it
+            assert opt.last_trials == ref.last_trials and opt.iteration_count == ref.iteration_count, it
+            if it > 0:
+                assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
+            x = opt.current_point.to_host()
+            assert rel(x, ref.current_point) <= 1e-12, it
+            assert np.array_equal(opt.current_gradient.to_host(), ref_p.grad(x)), it
+            # (a sum of n terms in two different orders; with half of the coordinates on the box the terms are large and alike)
+            assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-11)
+            # run_and_test! (legacy/DZOptimization.jl:1035-1046), exact
+            assert np.array_equal(opt.delta_point.to_host(), x - x_before), it
+            assert np.array_equal(opt.delta_gradient.to_host(), opt.current_gradient.to_host() - g_before), it
+        assert opt.single_pass_steps == 0 and opt.ring_layout == 0
+        opt.close(); ref.close()
+    finally:
+        orc.set_threads(1)
+
