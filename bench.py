@@ -161,6 +161,25 @@ def _barrier(world):
     torch.cuda.synchronize()
 
 
+def _pmc_secondary(workload, patterns, launches_each=None):
+    """HBM-side bytes per launch of a secondary workload's kernel(s) from the tracked profiles/pmc_secondary_latest.json
+    (builder-side rocprofv3 --pmc passes of `bench.py --workload ...`, tools/collect_pmc_secondary.sh; NOT measured in
+    this process): (bytes or None, traffic_source or None).  Several patterns: the sum (a two-loop = its kernels)."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_secondary_latest.json")))
+        rows = tab.get(workload, {})
+        total = 0
+        for i, pat in enumerate(patterns):
+            hit = [v for k, v in rows.items() if pat in k]
+            if not hit:
+                return None, None
+            mult = 1 if launches_each is None else launches_each[i]
+            total += mult * (hit[0]["read_bytes_per_launch"] + hit[0]["write_bytes_per_launch"])
+        return total, tab.get("_source") + "; not measured in this process"
+    except Exception:                                           # noqa: BLE001 -- the figure is optional
+        return None, None
+
+
 def _kernel_bytes(name, n, k, esize, layout=1, regrad=False):
     """ALGORITHMIC bytes per launch (DESIGN.md section d)."""
     if name in ("lbfgs_single_pass", "lbfgs_single_pass_retry"):
@@ -383,7 +402,9 @@ def batched_leg(dzo, sharding, args, world, rank, comm, info, steps, warmup):
            "roofline": {"bound": "hbm", "kernel": "batch_step_kernel<double, RP> (HIP-event name bfgs_batch_step)",
                         "achieved": None if ach is None else round(ach, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": None, "note": "rank 0's kernel; 1.5 n^2 T per accepted instance-step (lower triangle of H: read twice, written once); line searches included in the time"},
+                        "traffic": _pmc_secondary("batched", ["batch_step_kernel"])[0] if (B == 1024 and n == 256) else None,
+                        "traffic_source": _pmc_secondary("batched", ["batch_step_kernel"])[1] if (B == 1024 and n == 256) else None,
+                        "note": "rank 0's kernel; traffic = one launch of `poll` synchronous steps of the whole shard; 1.5 n^2 T per accepted instance-step (lower triangle of H: read twice, written once); line searches included in the time"},
            "kernels": kern}
     batch.close()
     return res
@@ -510,7 +531,8 @@ def secondary_workload(args, inproc=None):
                     "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern.get(dom, {}).get("algorithmic_GBps"),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(kern.get(dom, {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4),
-                                 "traffic": None,
+                                 "traffic": _pmc_secondary("dense", ["tri_pass_kernel<double, true>"])[0] if (tri and n == 4096) else None,
+                                 "traffic_source": _pmc_secondary("dense", ["tri_pass_kernel<double, true>"])[1] if (tri and n == 4096) else None,
                                  "measured_read_ceiling_GBps": {"resident_buffer_of_this_size": round(ceil_llc, 1), "hbm_4GiB": round(ceil_hbm, 1)},
                                  "frac_of_measured_resident_ceiling": round(kern.get(dom, {}).get("algorithmic_GBps", 0) / max(ceil_llc, 1e-9), 4),
                                  "update_plus_direction_kernel_us": round(sum(kern[k]["avg_us"] * (2 if k == "bfgs_tri_reduce" else 1)
@@ -522,6 +544,17 @@ def secondary_workload(args, inproc=None):
     elif args.workload == "bfgs_batched":
         comm = _make_comm(dzo, world)                              # RCCL communicator behind the C ABI when N > 1 (hard requirement)
         out.update(batched_leg(dzo, sharding, args, world, rank, comm, info, args.steps, args.warmup))
+        if world == 1 and args.n == 10_000_000 and inproc is None:
+            # (the workload's own line only, not the default line's `secondary` object) the other instantiations of the batched kernel at their top sizes (same shard of 1024 instances): RP = 2
+            # in its two forms (n = 384 narrow, n = 512 wide) -- rows of the same table, never `value`
+            import copy
+            rows = {}
+            for nn in (384, 512):
+                a2 = copy.copy(args); a2.n = nn
+                r2 = batched_leg(dzo, sharding, a2, world, rank, comm, info, max(args.steps // 2, 10), args.warmup)
+                rows[f"n{nn}"] = {"value": r2["value"], "unit": r2["unit"], "ms_per_step": r2["ms_per_step"],
+                                  "roofline_frac": r2["roofline"]["frac"], "kernels": r2["kernels"]}
+            out["other_sizes"] = rows
     elif args.workload == "adgd":
         # AdGDOptimizer (src/DZOptimization.jl:179-312) on the headline objective
         n = args.n
@@ -560,7 +593,9 @@ def secondary_workload(args, inproc=None):
                                "device": info["name"]},
                     "roofline": {"bound": "hbm", "kernel": "adgd_fused_step", "achieved": None if ach is None else round(ach, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                                 "traffic": None, "avg_launch_us": None if us is None else round(us, 2),
+                                 "traffic": _pmc_secondary("adgd", ["adgd_fused_rosen_kernel"])[0] if n == 10_000_000 else None,
+                                 "traffic_source": _pmc_secondary("adgd", ["adgd_fused_rosen_kernel"])[1] if n == 10_000_000 else None,
+                                 "avg_launch_us": None if us is None else round(us, 2),
                                  "note": "2 n T per pass: reads x, writes the trial point into the next of three buffers; g_old is recomputed in registers from x_old (3-point stencil), g_new is not written (gradient arrays, delta_point / delta_gradient are formed on demand; the deltas enter only the two norms)"},
                     "kernels": kern})
     else:  # lbfgs_lse_f32 (config 4)
@@ -622,7 +657,9 @@ def secondary_workload(args, inproc=None):
                     "roofline": {"bound": "hbm", "kernel": "two_loop (gram_pass_lanes_kernel + gram_reduce_finish_kernel + combine_kernel)",
                                  "achieved": round((4 * k + 2) * n * 4 / (tl * 1e-6) / 1e9, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((4 * k + 2) * n * 4 / (tl * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "traffic": None, "kernel_sum_us": round(tl, 2),
+                                 "traffic": _pmc_secondary("lse", ["gram_pass_lanes_kernel", "combine_kernel"])[0] if (n == 1_000_000 and m == 10) else None,
+                                 "traffic_source": _pmc_secondary("lse", ["gram_pass_lanes_kernel", "combine_kernel"])[1] if (n == 1_000_000 and m == 10) else None,
+                                 "kernel_sum_us": round(tl, 2),
                                  "wall_us_per_direction": round(wall_us, 2),
                                  "wall_frac": round((4 * k + 2) * n * 4 / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                  "kernel_events": "separate untimed stretch of the same loop",
@@ -938,6 +975,18 @@ def main():
                                                    "kernels and the next step needs a Gram pass"}
             if two_pass is not None:
                 roofline["two_pass"] = two_pass
+            # what the headline is, in the line
+            if dom == "lbfgs_single_pass":
+                contract = (4 * k + 2) * n * esize
+                us_dom = kernels[dom]["avg_us"]
+                roofline["frac_contract_units"] = round(contract / (us_dom * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                roofline["frac_contract_units_note"] = ("SURVEY 8(d)'s (4k+2) n T per two-loop over this kernel's time: > 1 means the pass moves FEWER bytes than 8(d) "
+                                                        "assumes (it keeps the last k+1 points and recomputes their gradients in registers), it is not bandwidth; "
+                                                        "`frac` is on the kernel's own bytes, and the two-loop streamed as 8(d) describes it is `two_pass`")
+                passes = table["lbfgs_single_pass"][0] + table.get("lbfgs_single_pass_retry", (0, 0))[0]
+                own = roofline["algorithmic_bytes_per_launch"] * passes / args.steps
+                roofline["step_frac"] = round(own / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
+                roofline["step_frac_note"] = "the passes' own bytes per step!() (retries included) over ms_per_step: what of the HBM peak a whole step sustains"
 
     value = world * args.steps / elapsed
     out = {
@@ -955,6 +1004,12 @@ def main():
                                  "a step that needed t <= 1/4)") if "lbfgs_single_pass" in table else args.mode),
                    "history_layout": ({0: "slabs", 1: "tiles of pairs", 2: "tiles of points"}[opt.ring_layout] +
                                       {0: "", 1: ", tile-major", 2: ", stream-major"}[opt.tile_arrangement]),
+                   "fast_path_requires": ("`value` is the point pass: objective = the library's built-in chained Rosenbrock (its gradient is a 3-point "
+                                          "stencil the pass recomputes), with or without the L2 / box decorators (secondary.lbfgs_decorated), any n "
+                                          ">= 8 incl. ragged (secondary.lbfgs_ragged) with n T < 4 GiB, m <= 24 (fp32: 20), backtracking search, no "
+                                          "descent check / fallback, GRAM mode, 16-byte aligned x0.  User CALLBACKS -- the reference's real API -- "
+                                          "any other objective, Wolfe, safeguards or CHAIN mode run the general two-pass step: "
+                                          "secondary.lbfgs_callbacks and roofline.two_pass are that rate"),
                    "parallelism": (f"1 optimizer instance per GPU (replicas), world size {world}; convergence flag: "
                                    f"{flag.transport}, {flag.collectives} collectives in the timed region")
                    if world > 1 else "single GPU",
@@ -966,6 +1021,15 @@ def main():
     }
     if batched is not None:
         out["batched"] = batched
+        # N > 1: `value` above is N config-3 replicas (a single huge-n problem stays on one GPU: "replicas only").  The
+        # quantity north_star SHARDS is config 5 -- lifted next to `value` so that a scaling record built from this
+        # line's top level carries it
+        out["sharded_metric"] = batched.get("metric")
+        out["sharded_value"] = batched.get("value")
+        out["sharded_unit"] = batched.get("unit")
+        out["sharded_per_rank"] = batched.get("per_rank_instance_steps_per_s")
+        out["sharded_instances_total"] = batched.get("config", {}).get("instances_total")
+        out["rccl_world_size"] = batched.get("config", {}).get("rccl_world_size")
     if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N = 1 only
         threads = host_cores()
         cn = args.cpu_n or n

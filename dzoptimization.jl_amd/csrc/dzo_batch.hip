@@ -263,9 +263,16 @@ template <typename T> __device__ __forceinline__ void block_gradient(const Batch
     __syncthreads();
 }
 
-// RP = row pairs per thread: n <= 256*RP, n even
-template <typename T, int RP>
-__global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch_step_kernel(BatchState st, int steps, int debug) {
+// RP = row pairs per thread: n <= 256*RP, n even.
+// RP = 2 (256 < n <= 512) comes in two forms.  Four columns of H in flight at two blocks per CU, as RP = 1 has them, do not fit
+// 256 registers (round 3 shipped that: 48 spilled values, 196 bytes of scratch).  Measured on the 1024-instance shard (round 4,
+// tools/run_batch_rp2_ab.sh, instance-steps/s):            n = 384      n = 512
+//     4 columns, 2 blocks per CU, spilling                  2.89 M       1.57 M
+//     2 columns, 2 blocks per CU (207 registers)            2.82 M       1.58 M      <- WIDE = 0, n <= 448
+//     4 columns, 1 block per CU (308 registers)             2.55 M       1.67 M      <- WIDE = 1, beyond
+// Neither spills; the narrow form wins while two instances' H still share a CU's bandwidth well, the wide one at the top.
+template <typename T, int RP, int WIDE = 0>
+__global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 && WIDE == 0 ? 2 : 1)) void batch_step_kernel(BatchState st, int steps, int debug) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = (int)st.n;
     const int64_t b = blockIdx.x;
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(kBlock, RP == 1 ? 2 : (RP == 2 ? 2 : 1)) void batch
             // the first 16 bytes of H instead (a broadcast) and their values are zeroed -- because a load
             // behind a branch makes the compiler wait for it at the join (vmcnt(0) per load: measured 6.6 us
             // per chunk of eight columns, i.e. eight serial round trips).
-            constexpr int UJ = RP == 1 ? 4 : (RP == 2 ? 4 : 2);
+            constexpr int UJ = RP == 1 ? 4 : (RP == 2 ? (WIDE ? 4 : 2) : 2);
             const int my_cols = (n - half + 1) / 2;                // columns half, half + 2, ... < n
             auto issue = [&](int c0, T (&hv)[UJ][RP][2]) {
 #pragma unroll
@@ -605,6 +612,14 @@ __global__ __launch_bounds__(kBlock) void batch_count_active_kernel(const int32_
 
 }  // namespace dzo
 
+static inline int tune_env(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+typedef void (*batch_kernel_fn)(dzo::BatchState, int, int);
+static batch_kernel_fn batch_kernel_of(int32_t dtype, int rp, int wide) {
+    using namespace dzo;
+    if (dtype == DZO_F64) return rp == 1 ? batch_step_kernel<double, 1> : rp == 2 ? (wide ? batch_step_kernel<double, 2, 1> : batch_step_kernel<double, 2, 0>) : batch_step_kernel<double, 4>;
+    return rp == 1 ? batch_step_kernel<float, 1> : rp == 2 ? (wide ? batch_step_kernel<float, 2, 1> : batch_step_kernel<float, 2, 0>) : batch_step_kernel<float, 4>;
+}
+
 struct dzo_bfgs_batch_s {
     dzo::BatchState st;
     int device = 0;                     // the shard's GPU; every entry point enters it (DeviceScope)
@@ -614,6 +629,7 @@ struct dzo_bfgs_batch_s {
     unsigned long long *count_host = nullptr;
     size_t lds_bytes = 0;
     int rp = 1;
+    int wide = 0;                   // RP = 2 only: the four-column, one-block-per-CU form (see batch_step_kernel)
     bool upper_stale = false;           // steps ran since the upper triangles of H were last mirrored from the lower ones
 };
 
@@ -677,6 +693,7 @@ static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_
     if (b->st.ob.kind == DZO_PROBLEM_ROSENBROCK2D) b->st.ob.kind = DZO_PROBLEM_ROSENBROCK_CHAIN;   // n = 2: the same function
     b->st.batch = batch; b->st.n = n;
     b->rp = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
+    b->wide = (b->rp == 2 && n > tune_env("DZO_TUNE_BATCH_RP2_WIDE_ABOVE", 448)) ? 1 : 0;
     const size_t es = dtype_size(dtype);
     const size_t np = (size_t)((n + 1) & ~(int64_t)1);
     b->lds_bytes = 9 * np * es + (5 * np + 16) * sizeof(double) + 16;
@@ -701,10 +718,7 @@ static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_
     DZO_HIP(hipDeviceSynchronize());   // null-stream memset/D2D copies are asynchronous to the host and to our non-blocking streams
     if (b->lds_bytes > 48 * 1024) {
         // gfx950 has 160 KiB of LDS per CU; dynamic requests above the default need the attribute
-        const void *fn = nullptr;
-        if (dtype == DZO_F64) fn = b->rp == 1 ? (const void *)batch_step_kernel<double, 1> : b->rp == 2 ? (const void *)batch_step_kernel<double, 2> : (const void *)batch_step_kernel<double, 4>;
-        else fn = b->rp == 1 ? (const void *)batch_step_kernel<float, 1> : b->rp == 2 ? (const void *)batch_step_kernel<float, 2> : (const void *)batch_step_kernel<float, 4>;
-        DZO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        DZO_HIP(hipFuncSetAttribute((const void *)batch_kernel_of(dtype, b->rp, b->wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     }
     {
         DZO_TIMED("bfgs_batch_init", b->stream);
@@ -816,10 +830,8 @@ int32_t dzo_bfgs_batch_step(dzo_bfgs_batch_t b, int32_t steps, int32_t *all_done
         b->upper_stale = true;
         DZO_TIMED("bfgs_batch_step", b->stream);
         const dim3 grid((unsigned)b->st.batch), block(kBlock);
-#define L(TT, R) hipLaunchKernelGGL((batch_step_kernel<TT, R>), grid, block, b->lds_bytes, b->stream, b->st, (int)steps, getenv("DZO_TUNE_BATCH_DEBUG") ? atoi(getenv("DZO_TUNE_BATCH_DEBUG")) : 0)
-        if (b->dtype == DZO_F64) { if (b->rp == 1) L(double, 1); else if (b->rp == 2) L(double, 2); else L(double, 4); }
-        else { if (b->rp == 1) L(float, 1); else if (b->rp == 2) L(float, 2); else L(float, 4); }
-#undef L
+        hipLaunchKernelGGL(batch_kernel_of(b->dtype, b->rp, b->wide), grid, block, b->lds_bytes, b->stream, b->st, (int)steps,
+                           getenv("DZO_TUNE_BATCH_DEBUG") ? atoi(getenv("DZO_TUNE_BATCH_DEBUG")) : 0);
     }
     DZO_HIP(hipGetLastError());
     if (all_done) {

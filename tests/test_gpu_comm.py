@@ -49,3 +49,26 @@ def test_bad_arguments_are_errors_not_crashes():
         dzo.Comm.init_all([99])
     with pytest.raises(dzo.DzoError):
         dzo.Comm.init_rank(dzo.Comm.unique_id(), 2, 5)
+
+
+def test_bench_gpus_2_runs_over_rccl_when_two_devices_are_visible():
+    """`python bench.py --gpus 2` on a box with two GPUs: two ranks, the library's own RCCL communicator of size 2, and the
+    sharded quantity (config 5) next to `value` at the top level of the line.  Skipped on the 1-GPU
+    build box -- RCCL refuses two ranks on one device; the 2-rank gloo rehearsal (tests/test_sharding_gloo.py,
+    tests/test_bench_launch.py) is what runs there."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--dim", "1000000"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2
+    assert out["sharded_value"] > 0 and len(out["sharded_per_rank"]) == 2 and out["sharded_instances_total"] == 2048
+    assert out["batched"]["config"]["rccl_world_size"] == 2

@@ -19,7 +19,7 @@ run batched --workload bfgs_batched --steps 40 --warmup 4 --poll 10
 run adgd --workload adgd --steps 60 --warmup 5
 run lse --workload lbfgs_lse_f32 --steps 50 --warmup 5
 python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, os, re, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 out, tag = sys.argv[1], sys.argv[2]
 def short(n): return re.sub(r'\(.*', '', n).replace('void ', '').replace('dzo::', '').strip()
@@ -38,6 +38,7 @@ def durs(d):
     return agg
 want = {'dense': ('tri_pass_kernel', 'tri_reduce_kernel', 'quadratic_phi6_kernel', 'bfgs_move', 'finish_phi6_advance_kernel', 'norm2_pair_begin_kernel'), 'batched': ('batch_step_kernel',),
         'adgd': ('adgd_fused_rosen_kernel',), 'lse': ('gram_pass_lanes_kernel', 'gram_reduce_finish_kernel', 'combine_kernel')}
+table = {}
 lines = [f'# PMC traffic and rocprofv3 kernel times of the secondary workloads ({tag})', '',
          'Separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (`--kernel-trace` only) and one `--kernel-trace --stats` pass per',
          'workload (`tools/collect_pmc_secondary.sh`); read = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md), write =',
@@ -51,7 +52,11 @@ for name, pats in want.items():
         half = lambda v: v[len(v) // 2:] if v else []
         m = lambda v: sum(half(v)) / len(half(v)) if half(v) else float('nan')
         lines.append(f'| {name} | `{k}` | {len(du.get(k, []))} | {m(du.get(k, [])):.2f} | {2 * m(fe.get(k, [])) * 1024 / 1e6:.2f} MB | {m(wr.get(k, [])) * 1024 / 1e6:.2f} MB |')
+        table.setdefault(name, {})[k] = {'launches': len(du.get(k, [])), 'avg_us': round(m(du.get(k, [])), 2),
+                                          'read_bytes_per_launch': round(2 * m(fe.get(k, [])) * 1024), 'write_bytes_per_launch': round(m(wr.get(k, [])) * 1024)}
 open(f'profiles/{tag}_pmc_secondary.md', 'w').write('\n'.join(lines) + '\n')
+table['_source'] = f'profiles/{tag}_pmc_secondary.md (tools/collect_pmc_secondary.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)'
+json.dump(table, open('profiles/pmc_secondary_latest.json', 'w'), indent=1)
 print('\n'.join(lines))
 PY
-mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_pmc_secondary.md gpurun_out/profiles_$TAG/
+mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_pmc_secondary.md profiles/pmc_secondary_latest.json gpurun_out/profiles_$TAG/

@@ -6,7 +6,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
 KEYS = "name|vgpr_count|agpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size"
 with tempfile.TemporaryDirectory() as tmp:
-    shutil.copy(os.path.join(ROOT, "dzoptimization.jl_amd", "libdzo_hip.so"), os.path.join(tmp, "lib.so"))
+    shutil.copy(os.environ.get("DZO_LIB_PATH", os.path.join(ROOT, "dzoptimization.jl_amd", "libdzo_hip.so")), os.path.join(tmp, "lib.so"))
     subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rows = {}
     for f in sorted(os.listdir(tmp)):
