@@ -770,6 +770,7 @@ class AdGDOptimizer(_OptBase):
     pipelined_passes = property(lambda s: s._i(5))     # passes adopted that were enqueued before the previous decision was seen
     pipeline_discards = property(lambda s: s._i(6))    # passes in flight dropped (a pointer was handed out, an option changed)
     pipeline_corrections = property(lambda s: s._i(7)) # adopted passes whose device-side step size differed from the host's evaluation
+    host_gradient_steps = property(lambda s: s._i(8))  # steps on the generic kernels because the host had written current_gradient
 
 
 class BFGSOptimizer(_OptBase):

@@ -42,6 +42,13 @@ struct dzo_adgd_s {
     bool g_valid[3] = {true, true, true};    // gbuf[i] holds the gradient of xbuf[i] (the one-pass step writes points only)
     void *x_user = nullptr, *g_user = nullptr;
     bool unsettled = false;
+    // The fused pass walks along the gradient it RECOMPUTES from the point; the reference walks along
+    // opt.current_gradient, which is the caller's array (:216-239, :301).  Whenever the host may have written into that
+    // array -- the initial_gradient it passed to the constructor, or anything after a settle handed the arrays back --
+    // the next step first checks that it still is the gradient of the point, and takes the generic kernels (which read
+    // the array) when it is not.  (the L-BFGS point ring has lbfgs_adopt_host_writes for the same rule.)
+    bool g_host_may_write = true;
+    int64_t host_gradient_steps = 0; // steps that took the generic kernels because of it
     int device = 0;
     std::recursive_mutex mu;
     bool norms_ready = false;        // |delta_point|^2, |delta_gradient|^2 of the last step are in norm2[]
@@ -306,7 +313,28 @@ static int32_t adgd_settle(dzo_adgd_s *o) {
         o->cur = 0; c.x = o->x_user; c.g = o->g_user;
         o->g_valid[0] = true;
     }
+    o->g_host_may_write = true;                                              // (whoever asked may write into the arrays)
     adgd_mark_unsettled(o);
+    return DZO_OK;
+}
+
+// is the caller's gradient array still the gradient of the caller's point?  (only asked with the live pair in the
+// caller's arrays, i.e. right after a settle or the constructor; pair 1's gradient array is free then and serves as
+// scratch.)  One gradient kernel, one compare, one host round trip -- paid by the step that follows a look at the arrays.
+static int32_t adgd_gradient_array_is_current(dzo_adgd_s *o, bool *current) {
+    OptCore &c = o->core;
+    *current = true;
+    if (o->cur != 0 || !o->twin) return DZO_OK;
+    DZO_TRY(problem_grad_async(c.problem, c.stream, o->gbuf[1], o->xbuf[0]));
+    o->g_valid[1] = false;
+    int32_t *flag = reinterpret_cast<int32_t *>(c.partials());               // (idle between two steps)
+    DZO_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), c.stream));
+    DZO_DISPATCH(c.dtype, launch_isequal<T>(c.stream, c.n, (const T *)o->gbuf[1], (const T *)o->gbuf[0], flag));
+    DZO_HIP(hipGetLastError());
+    int32_t differs = 0;
+    DZO_HIP(hipMemcpyAsync(&differs, flag, sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+    DZO_HIP(hipStreamSynchronize(c.stream));
+    *current = differs == 0;
     return DZO_OK;
 }
 
@@ -497,7 +525,14 @@ static int32_t adgd_step(dzo_adgd_s *o) {
         c.box_on = c.problem->cons_on; c.box_lo = c.problem->cons_lo; c.box_hi = c.problem->cons_hi;
     }
     const int32_t dt = c.dtype;
-    const bool fused_ok = adgd_fused_ok(o);                          // (may allocate; before any state changes)
+    bool fused_ok = adgd_fused_ok(o);                                // (may allocate; before any state changes)
+    if (fused_ok && o->g_host_may_write) {                           // :301 walks along the caller's array, whatever it holds
+        bool current = true;
+        DZO_TRY(adgd_cancel_pipeline(o));
+        DZO_TRY(adgd_gradient_array_is_current(o, &current));
+        if (!current) { fused_ok = false; o->host_gradient_steps += 1; }
+    }
+    o->g_host_may_write = false;
     if (!fused_ok) DZO_TRY(adgd_cancel_pipeline(o));
     const double half = 0.5;
     const double inv_sqrt_two = dt == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);   // :283
@@ -656,6 +691,7 @@ int32_t dzo_adgd_get_i(dzo_adgd_t o, int32_t what, int64_t *value) {
     case 5: *value = o->spec_adopted; break;
     case 6: *value = o->spec_discarded; break;
     case 7: *value = o->spec_corrected; break;
+    case 8: *value = o->host_gradient_steps; break;
     default: set_error("dzo_adgd_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
     return DZO_OK;

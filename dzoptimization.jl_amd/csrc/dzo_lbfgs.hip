@@ -1363,6 +1363,10 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     // ring, whose five streams of non-reused outputs are better kept out of the cache); non-temporal beyond
     // (n = 3e7, 480 MB per pass: plain stores lose 8 %)
     auto flush_stage = [&]() {
+        // (stage_row_s is written by lane 0 and read by every lane of the same wave: a wave's LDS operations execute in
+        // order, and the wavefront-scope fence pair -- no instruction, an ordering for the compiler -- makes the hand-off
+        // well defined in the memory model too)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int b = 0; b < staged; ++b) {
             const int64_t r = stage_row_s[wave][b];
             const int64_t v = r * kOwn - kLead + lane;
@@ -1522,6 +1526,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
                 // the trial point and its gradient into this wave's LDS slice (every lane: the slice is private to
                 // the wave, no barrier); they reach the spare slot's tiles in flush_stage()
                 if (lane == 0) stage_row_s[wave][staged] = row;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 char *sl = stage + (size_t)staged * (kStageTiles * kTileBytes) + toff;
                 store16(reinterpret_cast<T *>(sl), xn);
                 if constexpr (kWriteG) store16(reinterpret_cast<T *>(sl + kTileBytes), gn);

@@ -155,6 +155,8 @@ __device__ __forceinline__ void decide_body(const DecideArgs &a, double *lds) {
         const unsigned long long sw = (unsigned long long)(uint32_t)st, cw = (unsigned long long)(uint32_t)ch;
         a.host_out[0] = f_raw;
         a.host_out[1] = f_second;
+        a.host_out[2] = 0; a.host_out[5] = 0;                    // (core_wait_decision's seal covers words 0..5: the two this block does not use are
+                                                                 // written too, whatever a host-driven trial's copy of result() left there)
         reinterpret_cast<unsigned long long *>(a.host_out)[3] = sw;
         reinterpret_cast<unsigned long long *>(a.host_out)[4] = cw;
         store_seal(a.host_out + 6, seal_bits(f_raw) ^ seal_bits(f_second) ^ sw ^ cw ^ seal_bits(a.ticket));

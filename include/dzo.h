@@ -338,7 +338,10 @@ int32_t dzo_adgd_step(dzo_adgd_t opt);
  *        5 passes that were already in flight when their step! was called (the next pass is enqueued behind
  *        every decision, its step size from the device-side evaluation of :285-299 / :152)
  *        6 passes in flight that were dropped (a pointer was handed out, an option changed)
- *        7 adopted passes whose device-side step size differed from the host's evaluation (expected 0);
+ *        7 adopted passes whose device-side step size differed from the host's evaluation (expected 0)
+ *        8 steps that took the generic kernels because the caller's current_gradient array (which the optimizer
+ *          aliases, src/DZOptimization.jl:216-239, and step! walks along, :301) no longer held the gradient of the
+ *          current point when the step began -- the host wrote into it, or passed its own initial_gradient;
  * get_s: 0 f 1 delta_f 2 current_step_size 3 previous_step_size;
  * get_ptr: 0 x 1 delta_point 2 g 3 delta_gradient.  0 and 2 are the constructor's arrays (aliased, :261)
  * for the optimizer's life: get_ptr / dzo_synchronize / dzo_memcpy_* settle the live copy into them.

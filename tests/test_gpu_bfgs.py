@@ -180,6 +180,44 @@ def test_adgd_matches_oracle():
         assert opt.previous_step_size == pytest.approx(ref.previous_step_size, rel=1e-9)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_adgd_walks_along_what_the_host_wrote_into_current_gradient(dtype):
+    """step! walks along opt.current_gradient (src/DZOptimization.jl:301), which is the caller's aliased array (:216-239).
+    The fused pass recomputes the gradient from the point, so a host write into the array would be ignored: the step
+    that follows a look at the arrays checks the array against the point and takes the generic kernels when it was
+    changed (the AdGD counterpart of test_point_ring_adopts_what_the_host_wrote_into_the_aliased_arrays)."""
+    n = 4100 if dtype == np.float64 else 8200
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    ref = orc.AdGD(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype), x0.copy(), 0.1)
+    opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), 0.1)
+    tol = 1e-10 if dtype == np.float64 else 1e-5
+    for _ in range(6):
+        opt.step(); ref.step()
+    assert opt.fused_steps == 6 and opt.host_gradient_steps == 0
+    # looking is free of consequences ...
+    g = opt.current_gradient.to_host()
+    assert np.array_equal(g, ref.problem.grad(opt.current_point.to_host()))
+    opt.step(); ref.step()
+    assert opt.fused_steps == 7 and opt.host_gradient_steps == 0
+    assert rel(opt.current_point.to_host(), ref.current_point) <= tol
+    # ... writing is not: both sides get the same (wrong on purpose) gradient array
+    g2 = (ref.current_gradient * dtype(0.5) + dtype(1e-3) * np.sin(np.arange(n))).astype(dtype)
+    x_before = opt.current_point.to_host()
+    opt.current_gradient.upload(g2); ref.current_gradient[:] = g2
+    opt.step(); ref.step()
+    assert opt.host_gradient_steps == 1 and opt.fused_steps == 7        # this step ran on the generic kernels, along g2
+    assert opt.is_stuck == ref.is_stuck and opt.iteration_count == ref.iteration_count
+    x_after = opt.current_point.to_host()
+    assert rel(x_after, ref.current_point) <= tol
+    t = ref.current_step_size
+    assert rel(x_after - x_before, -dtype(t) * g2) <= (1e-9 if dtype == np.float64 else 1e-3)     # x_new = x - t g2 (:301), not x - t grad f(x)
+    # the step after is a fused one again, from the gradient the generic step computed
+    opt.step(); ref.step()
+    assert opt.fused_steps == 8 and opt.host_gradient_steps == 1
+    assert rel(opt.current_point.to_host(), ref.current_point) <= tol
+    assert opt.current_step_size == pytest.approx(ref.current_step_size, rel=1e-9 if dtype == np.float64 else 1e-4)
+
+
 # ------------------------------------------------------------------------------ batched (K11)
 @pytest.mark.parametrize("n,B", [(2, 5), (16, 7), (256, 3)])
 def test_batched_bfgs_matches_single_instance_oracle(n, B):

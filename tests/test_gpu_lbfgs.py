@@ -378,6 +378,35 @@ def test_split_entry_points_reproduce_step(monkeypatch):
     assert np.array_equal(opt_a.rho_history, opt_b.rho_history)
 
 
+def test_host_driven_trial_followed_by_a_speculative_step_on_the_same_optimizer():
+    """The split entry points copy five result words into the pinned outcome buffer (no seal); the step!() after them waits
+    on a SEALED outcome over words 0..5 of the same buffer (core_wait_decision): the decision kernel writes all six
+    (ADVICE r3), so the mixture works whatever the copy left behind."""
+    n, m = 4100, 4
+    opt, ref, prob = _gpu_and_oracle(n, m)
+    for _ in range(3):
+        opt.step(); ref.step()
+    # a host-driven step (what the Julia module does around its callbacks) ...
+    opt.compute_step_direction(); opt.begin_search()
+    t = 1.0
+    while True:
+        assert opt.trial(t)
+        f_new = prob(opt.current_point)
+        if f_new < opt.current_objective_value:
+            opt.accept(f_new)
+            break
+        t *= 0.5
+    opt.pre_gradient(); prob.gradient_(opt.current_gradient, opt.current_point); opt.post_gradient()
+    ref.step()
+    assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-11
+    # ... then library-driven ones, whose decisions are read through the seal
+    for _ in range(4):
+        opt.step(); ref.step()
+        assert opt.last_trials == ref.last_trials
+        assert rel(opt.current_point.to_host(), ref.current_point) <= 1e-9
+    assert dzo.unsealed_first_reads() >= 0
+
+
 def test_fused_and_speculative_step_equal_the_plain_kernel_sequence(monkeypatch):
     """The fused accept+gradient+delta kernel and the speculative (device-decided) tail are
     pure re-schedulings: from the same state one step gives bit-identical x, delta_point, g,
