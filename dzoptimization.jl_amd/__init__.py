@@ -31,7 +31,7 @@ LIB_PATH = os.environ.get("DZO_LIB_PATH") or os.path.join(_HERE, "libdzo_hip.so"
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 F32, F64 = 0, 1
-ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE = 0, 1, 2, 3
+ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE, QUADRATIC_CHAIN = 0, 1, 2, 3, 4
 TWOLOOP_CHAIN, TWOLOOP_GRAM = 0, 1
 LINE_SEARCH_BACKTRACKING, LINE_SEARCH_WOLFE = 0, 1
 STEP_NULL, STEP_GRADIENT_DESCENT, STEP_BFGS = 0, 1, 2

@@ -763,7 +763,8 @@ static int32_t batch_create_on_device(const BatchObjective &ob, int64_t batch, i
 int32_t dzo_bfgs_batch_create_problem(dzo_problem_t problem, int64_t batch, const void *x0_dev, double initial_step_length,
                                       int32_t device, dzo_bfgs_batch_t *out) {
     DZO_REQUIRE(problem && out, DZO_ERR_INVALID, "null argument");
-    DZO_REQUIRE(problem->kind != DZO_PROBLEM_LSE, DZO_ERR_UNSUPPORTED, "batched mode does not implement the log-sum-exp objective");
+    DZO_REQUIRE(problem->kind != DZO_PROBLEM_LSE && problem->kind != DZO_PROBLEM_QUADRATIC_CHAIN, DZO_ERR_UNSUPPORTED,
+                "batched mode implements the chained Rosenbrock and the dense quadratic objectives only");
     BatchObjective ob;
     ob.kind = problem->kind; ob.A = problem->A;
     ob.l2 = problem->l2;

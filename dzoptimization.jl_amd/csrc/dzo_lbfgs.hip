@@ -158,6 +158,8 @@ struct dzo_lbfgs_s {
     // were in force when those gradients were first formed.  A change on the user's problem handle (this build lets
     // them be changed between steps) therefore turns the ring into the pair ring under the OLD set (lbfgs_step).
     dzo::RingDecor ring_dec;
+    int ring_obj = 0;               // the chained objective the passes recompute (ChainObj: 0 Rosenbrock, 1 chained quadratic) ...
+    double ring_obj_lambda = 0;     // ... and its parameter
     // The caller's arrays ARE current_point / current_gradient (:393): what the host writes into them between two
     // steps must be what the next step starts from.  On the point ring they are copies of point 0, so whenever the
     // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
@@ -985,6 +987,7 @@ template <typename T> struct FusedParams {
     int leftover_even;                         // point pass: the last, partial round of rows goes to the even XCDs' blocks first
     int debug_skip;                            // dev ablation only: 1 = no pair dots, 2 = no stores, 4 = no combine chain, 64 = no tile stores, 128 = no gradient-tile stores (point pass)
     PointDecor<T> dec;                         // point pass, DEC instantiations: the decorators of legacy/DZOptimization.jl:219-296
+    T obj_lambda;                              // point pass, OBJ = 1: the chained quadratic's lambda
 };
 
 // PLAIN: ablation build with plain instead of non-temporal history loads (DZO_TUNE_SP_DEBUG bit 256,
@@ -1285,8 +1288,11 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
 // m = 8: 161 against 160, m = 10 / 12 (K = 12): 222 / 235 against 203 / 214; n = 1e6 slower throughout.  What did help the
 // small instantiations is asking the occupancy query with the dynamic LDS the launch really uses, see points_grid.)
 // DEC: the decorators ride along (PointDecor above); separate instantiations, so that the undecorated pass is untouched.
-template <typename T, int K, bool FIRST = false, int SETS = 2, bool DEC = false>
+// OBJ: the chained objective (ChainObj, dzo_rosen.h): 0 the chained Rosenbrock, 1 the chained quadratic -- the pass asks
+// the objective for per-element coefficients, the gradient stencil and the objective terms and knows nothing else of it.
+template <typename T, int K, bool FIRST = false, int SETS = 2, bool DEC = false, int OBJ = 0>
 __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_kernel(FusedParams<T> p) {
+    using Obj = ChainObj<T, OBJ>;
     constexpr int N = Vec16<T>::N;
     constexpr int kOwn = kRowOwn, kLead = kRowLead;
     __shared__ T a_s[kFusedMaxK], c_s[kFusedMaxK];
@@ -1433,9 +1439,9 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         // (337 -> 322 us), and the younger half of the grid one level higher still there (-> 316 us, both halves
         // done within 1 us of each other).  Scheduling only: rows, sums and results are what they were.
         if (p.prio) __builtin_amdgcn_s_setprio(0);
-        RosenCoef<T> rc[N];                                       // rosen_grad_elem's index tests as coefficients, once per row
+        typename Obj::Coef rc[N];                                 // the objective's index tests as coefficients, once per row
 #pragma unroll
-        for (int e = 0; e < N; ++e) rc[e] = rosen_coef<T>(e0 + e, p.n);
+        for (int e = 0; e < N; ++e) rc[e] = Obj::coef(e0 + e, p.n, p.obj_lambda);
         if constexpr (kRegrad) {
             // the gradients of this row's K + 1 points, every lane (a halo lane's outer element: see above)
 #pragma unroll
@@ -1446,7 +1452,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
                 for (int e = 0; e < N; ++e) {
                     const T xl = e > 0 ? xv[j][(e + N - 1) % N] : xp;
                     const T xr = e + 1 < N ? xv[j][(e + 1) % N] : xq;
-                    gv[j][e] = rosen_grad_coef<T>(rc[e], xl, xv[j][e], xr);
+                    gv[j][e] = Obj::grad(rc[e], xl, xv[j][e], xr);
                     if constexpr (DEC) gv[j][e] = decor_grad<T>(p.dec, gv[j][e], xv[j][e]);
                 }
                 __builtin_amdgcn_sched_barrier(0);               // point by point (the temporaries of 21 stencils at once do not fit)
@@ -1500,7 +1506,7 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const T xq = j + 1 < N ? xh[(j + 1) % N] : xhnext;
-                if (owner && e0 + j + 1 < p.n) fobj_h += rosen_term<T>(xh[j], xq);
+                if (owner && Obj::has_term(e0 + j, p.n)) fobj_h += Obj::term(rc[j], xh[j], xq);
             }
         }
         // ---- objective terms and gradient of the trial point; neighbours from the adjacent lanes
@@ -1511,14 +1517,14 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
         for (int j = 0; j < N; ++j) {
             const T xp = j > 0 ? xn[(j + N - 1) % N] : xprev;
             const T xq = j + 1 < N ? xn[(j + 1) % N] : xnext;
-            gn[j] = rosen_grad_coef<T>(rc[j], xp, xn[j], xq);
+            gn[j] = Obj::grad(rc[j], xp, xn[j], xq);
             if constexpr (DEC) {
                 gn[j] = decor_grad<T>(p.dec, gn[j], xn[j]);
                 if (owner) fsq = __builtin_fma((double)xn[j], (double)xn[j], fsq);
             }
             sn[j] = xn[j] - xv[0][j];                               // :145
             yn[j] = gn[j] - gv[0][j];                               // :478-480
-            if (owner && e0 + j + 1 < p.n) fobj += rosen_term<T>(xn[j], xq);
+            if (owner && Obj::has_term(e0 + j, p.n)) fobj += Obj::term(rc[j], xn[j], xq);
         }
         if (!(p.debug_skip & 2)) {
             if constexpr (!FIRST) { if (owner && p.store_d) store16_nt(atw(p.d, boff), q); }
@@ -1725,7 +1731,7 @@ __global__ __launch_bounds__(kBlock) void ring_diff_kernel(int64_t rows, T *__re
 // halo copies included, evaluates rosen_grad_elem on its vector -- the bits the pass had in registers
 template <typename T>
 __global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t nvec, const T *__restrict__ xs, T *__restrict__ gs, int64_t rowbytes,
-                                                             PointDecor<T> dec, int dec_on) {
+                                                             PointDecor<T> dec, int dec_on, int obj, T obj_lambda) {
     constexpr int N = Vec16<T>::N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
@@ -1738,8 +1744,11 @@ __global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t 
         const T xl = v > 0 ? hist_ptr<true>(xs, v - 1, rowbytes)[N - 1] : (T)0;
         const T xr = v + 1 < nvec ? hist_ptr<true>(xs, v + 1, rowbytes)[0] : (T)0;
 #pragma unroll
-        for (int e = 0; e < N; ++e)             // (an element past n -- the padding of a ragged last vector -- has gradient +0)
-            g[e] = v * N + e < n ? rosen_grad_elem<T>(v * N + e, n, e > 0 ? x[(e + N - 1) % N] : xl, x[e], e + 1 < N ? x[(e + 1) % N] : xr) : (T)0;
+        for (int e = 0; e < N; ++e) {           // (an element past n -- the padding of a ragged last vector -- has gradient +0)
+            const T xp = e > 0 ? x[(e + N - 1) % N] : xl, xq = e + 1 < N ? x[(e + 1) % N] : xr;
+            if (obj == 1) g[e] = qchain_grad_coef<T>(qchain_coef<T>(v * N + e, n, obj_lambda), xp, x[e], xq);
+            else g[e] = v * N + e < n ? rosen_grad_elem<T>(v * N + e, n, xp, x[e], xq) : (T)0;
+        }
         if (dec_on) {                                       // (the decorated gradient, as the DEC pass forms it)
 #pragma unroll
             for (int e = 0; e < N; ++e) g[e] = decor_grad<T>(dec, g[e], x[e]);
@@ -2226,6 +2235,11 @@ static inline RingDecor ring_decor_of(const dzo_problem_s *p) {
     if (p) { r.l2 = p->l2; r.bg_on = p->bg_on; r.bg_lo = p->bg_lo; r.bg_hi = p->bg_hi; r.cons_on = p->cons_on; r.cons_lo = p->cons_lo; r.cons_hi = p->cons_hi; }
     return r;
 }
+// the chained objectives the point pass serves (ChainObj): -1 = none of them
+static inline int ring_obj_of(const dzo_problem_s *p) {
+    if (!p) return -1;
+    return p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN ? 0 : (p->kind == DZO_PROBLEM_QUADRATIC_CHAIN ? 1 : -1);
+}
 // vectors of 16 bytes a ring stream holds: the last one is padded with phantom elements when n is ragged (see load_vec_tail)
 template <typename T> static inline int64_t ring_nvec(const dzo_lbfgs_s *o) { return (o->core.n + Vec16<T>::N - 1) / Vec16<T>::N; }
 static inline bool ring_ragged(const dzo_lbfgs_s *o) { return o->core.n % (16 / (int64_t)dtype_size(o->core.dtype)) != 0; }
@@ -2261,7 +2275,8 @@ static int32_t lbfgs_ensure_g(dzo_lbfgs_s *o, int slot) {
     DZO_TIMED("lbfgs_ring_regrad", c.stream);
     const int grid = stream_grid(o->ring_rows * 64, 1);
     DZO_DISPATCH(c.dtype, hipLaunchKernelGGL(ring_regrad_kernel<T>, dim3(grid), dim3(kBlock), 0, c.stream, c.n, ring_nvec<T>(o),
-                                             (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes, point_decor<T>(o->ring_dec), o->ring_dec.any() ? 1 : 0));
+                                             (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes, point_decor<T>(o->ring_dec), o->ring_dec.any() ? 1 : 0,
+                                             o->ring_obj, (T)o->ring_obj_lambda));
     DZO_HIP(hipGetLastError());
     o->g_valid |= 1u << slot;
     return DZO_OK;
@@ -2625,7 +2640,8 @@ static bool points_ok(dzo_lbfgs_s *o) {
     if (!o->points || !o->single_pass || !o->blocked || o->mode != DZO_TWOLOOP_GRAM || o->line_search != 0 || o->descent_check || o->sd_fallback) return false;
     if (c.objective || c.gradient || c.constraint || !o->speculate || !o->fused_post || !c.problem) return false;
     // (the decorators of legacy :219-296 ride on the pass: its DEC instantiations, under the set the ring was stored with)
-    if (c.problem->kind != DZO_PROBLEM_ROSENBROCK_CHAIN || !(ring_decor_of(c.problem) == o->ring_dec)) return false;
+    if (ring_obj_of(c.problem) != o->ring_obj || !(ring_decor_of(c.problem) == o->ring_dec)) return false;
+    if (o->ring_obj == 1 && (o->ring_dec.any() || c.problem->lambda != o->ring_obj_lambda)) return false;   // (no DEC instantiations of that objective)
     if (o->k > point_max_k(c.dtype) || o->m > point_max_k(c.dtype) || !al16v(o->d)) return false;
     if (o->k > 0 && !o->spec_scalars) return false;       // (the scalars come from the previous pass; anything else goes through Gram passes)
     return true;
@@ -2811,6 +2827,23 @@ template <typename T> static bool point_one_set(const dzo_lbfgs_s *o) { return o
 // the instantiation of the point pass for this optimizer: the smallest K that holds m pairs; one or two register sets
 // (DZO_TUNE_POINT_SETS; see the kernel)
 template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(FusedParams<T>) {
+    if (o->ring_obj == 1) {
+        // the chained quadratic (ChainObj<T, 1>): the same ladder of history lengths as the decorated pass
+        if (point_one_set<T>(o)) {
+            if constexpr (sizeof(T) == 8) {
+                return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1, false, 1>
+                       : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 1, false, 1>
+                       : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 1, false, 1>
+                       : lbfgs_point_pass_kernel<T, 20, false, 1, false, 1>;
+            } else {
+                return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 1, false, 1> : lbfgs_point_pass_kernel<T, 12, false, 1, false, 1>;
+            }
+        }
+        if constexpr (sizeof(T) == 8) { if (o->m > 20) return lbfgs_point_pass_kernel<T, 24, false, 2, false, 1>; }
+        return o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 2, false, 1>
+               : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 2, false, 1>
+               : lbfgs_point_pass_kernel<T, 20, false, 2, false, 1>;
+    }
     if (o->ring_dec.any()) {
         // the decorated pass (DEC): fewer instantiations, the next larger K serves the history lengths in between
         if (point_one_set<T>(o)) {
@@ -2854,7 +2887,8 @@ template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(Fused
 }
 // first: the first step's kernel
 template <typename T> static void (*point_pass_kernel_for(dzo_lbfgs_s *o, bool first))(FusedParams<T>) {
-    if (first) return o->ring_dec.any() ? lbfgs_point_pass_kernel<T, 8, true, 2, true> : lbfgs_point_pass_kernel<T, 8, true>;
+    if (first) return o->ring_obj == 1 ? lbfgs_point_pass_kernel<T, 8, true, 2, false, 1>
+                      : o->ring_dec.any() ? lbfgs_point_pass_kernel<T, 8, true, 2, true> : lbfgs_point_pass_kernel<T, 8, true>;
     return point_pass_kernel_sel<T>(o);
 }
 
@@ -2879,6 +2913,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.changed = c.flag();
     fp.debug_skip = 1 | 64;                               // no pair dots, no tile stores (and with them no halo copies)
     fp.dec = point_decor<T>(o->ring_dec);
+    fp.obj_lambda = (T)o->ring_obj_lambda;
     fp.stage_rows = 1;
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, false);
     const int grid = points_grid<T>(o, kern);
@@ -2920,6 +2955,7 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     fp.changed = c.flag();
     fp.debug_skip = tune("DZO_TUNE_SP_DEBUG", 0);
     fp.dec = point_decor<T>(o->ring_dec);
+    fp.obj_lambda = (T)o->ring_obj_lambda;
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, k == 0);
     fp.store_d = o->lazy_d ? 0 : 1;
     {
@@ -3135,6 +3171,8 @@ using namespace dzo;
 
 static thread_local bool tl_want_blocked = false;       // dzo_lbfgs_create_problem -> dzo_lbfgs_create
 static thread_local RingDecor tl_ring_dec;              // ... and the decorators the start point's gradient was formed under
+static thread_local int tl_ring_obj = 0;                // ... and the chained objective (ChainObj) with its parameter
+static thread_local double tl_ring_obj_lambda = 0;
 
 // ============================================================================ C ABI
 extern "C" {
@@ -3154,7 +3192,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     OptCore &c = o->core;
     c.n = n; c.dtype = dtype; c.x = x_dev; c.g = g_dev;
     o->x_user = x_dev; o->g_user = g_dev; o->device = ctx().device;
-    o->ring_dec = tl_ring_dec;
+    o->ring_dec = tl_ring_dec; o->ring_obj = tl_ring_obj; o->ring_obj_lambda = tl_ring_obj_lambda;
     c.f = round_to_dtype(dtype, initial_objective_value);
     o->m = history_length;
     const size_t es = dtype_size(dtype);
@@ -3357,11 +3395,13 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
     DZO_HIP(hipMalloc(&g, (size_t)((problem->n + 63) / 64 * 64) * dtype_size(problem->dtype)));
     int32_t rc = dzo_problem_grad(problem, g, x_dev);     // :421
     // the single-pass step will apply (built-in chained Rosenbrock, no decorators): tile-major history ring
-    tl_want_blocked = problem->kind == DZO_PROBLEM_ROSENBROCK_CHAIN && (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
+    tl_want_blocked = (problem->kind == DZO_PROBLEM_ROSENBROCK_CHAIN ||
+                       (problem->kind == DZO_PROBLEM_QUADRATIC_CHAIN && !ring_decor_of(problem).any())) && (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
     tl_ring_dec = ring_decor_of(problem);
+    tl_ring_obj = ring_obj_of(problem) == 1 ? 1 : 0; tl_ring_obj_lambda = problem->lambda;
     if (rc == DZO_OK) rc = dzo_lbfgs_create(problem->n, history_length, problem->dtype, x_dev, g, f0, initial_step_length, out);
     tl_want_blocked = false;
-    tl_ring_dec = RingDecor();
+    tl_ring_dec = RingDecor(); tl_ring_obj = 0; tl_ring_obj_lambda = 0;
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
     rc = problem_view_create(problem, &(*out)->core.problem);    // private partial-sum workspace per optimizer

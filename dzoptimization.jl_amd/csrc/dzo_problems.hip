@@ -81,6 +81,25 @@ __global__ __launch_bounds__(kBlock) void rosen_chain_grad_kernel(int64_t n, T *
     if (t < n) g[t] = rosen_grad_elem<T>(t, n, t > 0 ? x[t - 1] : (T)0, x[t], t + 1 < n ? x[t + 1] : (T)0);
 }
 
+// ------------------------------------------------------------------ chained quadratic (dzo_rosen.h)
+// (plain elementwise kernels: this objective's fast path is the L-BFGS point pass, which recomputes these in registers)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void qchain_eval_kernel(int64_t n, const T *__restrict__ x, T lambda, double *__restrict__ partials) {
+    __shared__ double lds[kWaves];
+    double acc = 0;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads)
+        acc += qchain_term<T>(qchain_coef<T>(i, n, lambda), x[i], i + 1 < n ? x[i + 1] : (T)0);
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void qchain_grad_kernel(int64_t n, T *__restrict__ g, const T *__restrict__ x, T lambda) {
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += nthreads)
+        g[i] = qchain_grad_coef<T>(qchain_coef<T>(i, n, lambda), i > 0 ? x[i - 1] : (T)0, x[i], i + 1 < n ? x[i + 1] : (T)0);
+}
+
 // Fused tail of an accepted L-BFGS step for the chained Rosenbrock objective (K3 + K5 + K12):
 //   delta_point    = x - x_old                       (src/DZOptimization.jl:145)
 //   g_new          = grad f(x)                       (:479)
@@ -678,6 +697,13 @@ template <typename T> static int32_t eval_async_t(dzo_problem_s *p, hipStream_t 
         hipLaunchKernelGGL(finish_scaled_sum_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, n, 0.5, result_dev);
         break;
     }
+    case DZO_PROBLEM_QUADRATIC_CHAIN: {
+        DZO_TIMED("objective_quadratic_chain", s);
+        const int grid = stream_grid(n, 4);
+        hipLaunchKernelGGL(qchain_eval_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, x, (T)p->lambda, p->scratch);
+        hipLaunchKernelGGL(finish_scaled_sum_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, (int64_t)grid, 1.0, result_dev);
+        break;
+    }
     case DZO_PROBLEM_LSE: {
         DZO_TIMED("objective_lse", s);
         const int grid = stream_grid(n, 4);
@@ -717,6 +743,11 @@ template <typename T> static int32_t grad_async_t(dzo_problem_s *p, hipStream_t 
         const int grid = (int)(n < 65535 ? n : 65535);
         hipLaunchKernelGGL((quadratic_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x, g,
                            (double *)nullptr);
+        break;
+    }
+    case DZO_PROBLEM_QUADRATIC_CHAIN: {
+        DZO_TIMED("gradient_quadratic_chain", s);
+        hipLaunchKernelGGL(qchain_grad_kernel<T>, dim3(stream_grid(n, 4)), dim3(kBlock), 0, s, n, g, x, (T)p->lambda);
         break;
     }
     case DZO_PROBLEM_LSE: {
@@ -858,6 +889,14 @@ bool problem_eval_partials_async(dzo_problem_s *p, hipStream_t s, const void *x,
         *partials = p->scratch; *count = grid; *scale = 1.0;
         return true;
     }
+    if (p->kind == DZO_PROBLEM_QUADRATIC_CHAIN) {
+        DZO_TIMED("objective_quadratic_chain", s);
+        const int grid = stream_grid(n, 4);
+        if (p->dtype == DZO_F64) hipLaunchKernelGGL(qchain_eval_kernel<double>, dim3(grid), dim3(kBlock), 0, s, n, (const double *)x, (double)p->lambda, p->scratch);
+        else hipLaunchKernelGGL(qchain_eval_kernel<float>, dim3(grid), dim3(kBlock), 0, s, n, (const float *)x, (float)p->lambda, p->scratch);
+        *partials = p->scratch; *count = grid; *scale = 1.0;
+        return true;
+    }
     if (p->kind == DZO_PROBLEM_QUADRATIC) {
         DZO_TIMED("objective_quadratic", s);
         const int grid = (int)(n < 65535 ? n : 65535);
@@ -944,7 +983,8 @@ int32_t dzo_problem_create(int32_t kind, int64_t n, int32_t dtype, const void *A
     DZO_TRY(require_init());
     DZO_REQUIRE(out, DZO_ERR_INVALID, "null out");
     DZO_REQUIRE(dtype == DZO_F32 || dtype == DZO_F64, DZO_ERR_INVALID, "bad dtype %d", dtype);
-    DZO_REQUIRE(kind >= 0 && kind <= DZO_PROBLEM_LSE, DZO_ERR_INVALID, "unknown problem kind %d", kind);
+    DZO_REQUIRE(kind >= 0 && kind <= DZO_PROBLEM_QUADRATIC_CHAIN, DZO_ERR_INVALID, "unknown problem kind %d", kind);
+    DZO_REQUIRE(kind != DZO_PROBLEM_QUADRATIC_CHAIN || lambda > 0, DZO_ERR_INVALID, "the chained quadratic needs lambda > 0 (it is what makes it strictly convex)");
     DZO_REQUIRE(n >= 1, DZO_ERR_INVALID, "n must be >= 1");
     DZO_REQUIRE(kind != DZO_PROBLEM_ROSENBROCK2D || n == 2, DZO_ERR_INVALID, "2-D Rosenbrock needs n == 2");
     DZO_REQUIRE(kind != DZO_PROBLEM_QUADRATIC || A_dev, DZO_ERR_INVALID, "quadratic problem needs A");

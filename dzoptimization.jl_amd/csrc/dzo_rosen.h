@@ -50,4 +50,48 @@ template <typename T> __device__ __forceinline__ T rosen_grad_coef(const RosenCo
     return dfma(c.c200, t2p, gi);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Chained QUADRATIC (DZO_PROBLEM_QUADRATIC_CHAIN; north_star: "synthetic quadratic/Rosenbrock-N problems" -- the dense
+// quadratic of config 2 cannot be stored at n = 1e7, this one is its large-n member):
+//   f = sum_{i<n-1} 1/2 (x[i+1] - x[i])^2 + sum_{i<n} lambda/2 (x[i] - 1)^2        convex, tridiagonal Hessian,
+//   g_i = (x_i - x_{i+1}) [i+1 < n] + (x_i - x_{i-1}) [i > 0] + lambda (x_i - 1)    minimiser x = 1, condition (4 + lambda) / lambda
+// Like the chained Rosenbrock it is a radius-1 stencil, so the L-BFGS point pass serves it through the same code
+// (ChainObj below).  The index tests are per-element coefficients here too; operation order = oracle/dzo_oracle_impl.h.
+template <typename T> struct QChainCoef { T cR, cL, cD, hk, hm; };
+template <typename T> __device__ __forceinline__ QChainCoef<T> qchain_coef(int64_t i, int64_t n, T lambda) {
+    QChainCoef<T> c;
+    const bool real = i >= 0 && i < n, nx = real && i + 1 < n, pv = real && i > 0;
+    c.cR = nx ? (T)1 : (T)0; c.cL = pv ? (T)1 : (T)0; c.cD = real ? lambda : (T)0;
+    c.hk = nx ? (T)0.5 : (T)0; c.hm = real ? (T)0.5 * lambda : (T)0;
+    return c;
+}
+template <typename T> __device__ __forceinline__ T qchain_grad_coef(const QChainCoef<T> &c, T xp, T xi, T xn) {
+    return dfma(c.cD, xi - (T)1, dfma(c.cL, xi - xp, c.cR * (xi - xn)));
+}
+// the terms attributed to element i: its diagonal term and the pair term with its right neighbour
+template <typename T> __device__ __forceinline__ double qchain_term(const QChainCoef<T> &c, T xi, T xn) {
+    const T d = xi - (T)1;
+    const T p = xn - xi;
+    return (double)dfma(c.hk * p, p, (c.hm * d) * d);
+}
+
+// What the point pass needs of a chained objective (radius-1 stencil): per-element coefficients formed once per
+// wave-row, the gradient of an element from its two neighbours, the objective terms attributed to an element and
+// whether an element carries terms at all.  OBJ = 0: chained Rosenbrock, 1: chained quadratic.
+template <typename T, int OBJ> struct ChainObj;
+template <typename T> struct ChainObj<T, 0> {
+    using Coef = RosenCoef<T>;
+    static __device__ __forceinline__ Coef coef(int64_t i, int64_t n, T) { return rosen_coef<T>(i, n); }
+    static __device__ __forceinline__ T grad(const Coef &c, T xp, T xi, T xn) { return rosen_grad_coef<T>(c, xp, xi, xn); }
+    static __device__ __forceinline__ bool has_term(int64_t i, int64_t n) { return i + 1 < n; }
+    static __device__ __forceinline__ double term(const Coef &, T xi, T xn) { return rosen_term<T>(xi, xn); }
+};
+template <typename T> struct ChainObj<T, 1> {
+    using Coef = QChainCoef<T>;
+    static __device__ __forceinline__ Coef coef(int64_t i, int64_t n, T lambda) { return qchain_coef<T>(i, n, lambda); }
+    static __device__ __forceinline__ T grad(const Coef &c, T xp, T xi, T xn) { return qchain_grad_coef<T>(c, xp, xi, xn); }
+    static __device__ __forceinline__ bool has_term(int64_t i, int64_t n) { return i < n; }
+    static __device__ __forceinline__ double term(const Coef &c, T xi, T xn) { return qchain_term<T>(c, xi, xn); }
+};
+
 }  // namespace dzo

@@ -22,7 +22,7 @@ import LinearAlgebra: axpy!, axpby!, dot, norm, rmul!
 export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentOptimizer, QuadraticLineSearch,
        UniformBoxConstraint, with_l2!, with_box_gradient!, with_box_constraint!, step!,
        set_safeguards!, set_line_search!, BACKTRACKING, STRONG_WOLFE,
-       RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, BuiltinProblem,
+       RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, QuadraticChain, BuiltinProblem,
        BatchedBFGSOptimizer, count_active, LineSearchEvaluator, compute_lbfgs_step_direction!,
        update_inverse_hessian!, reset_inverse_hessian!, synchronize,
        norm2, inv_norm, negate!, scale!, HipBackend, install_state!, ShardComm, all_done
@@ -205,6 +205,9 @@ Rosenbrock2D(::Type{T}=Float64) where {T} = _problem(0, 2, T)
 RosenbrockChain(n::Integer, ::Type{T}=Float64) where {T} = _problem(1, n, T)
 DenseQuadratic(A::HipVector{T}, n::Integer) where {T} = _problem(2, n, T; A=A)      # A column-major n*n
 LogSumExp(c::HipVector{T}, lambda) where {T} = _problem(3, length(c), T; c=c, lambda=lambda)
+# sum 1/2 (x[i+1]-x[i])^2 + lambda/2 (x[i]-1)^2: the large-n convex quadratic (tridiagonal Hessian); like RosenbrockChain it runs on
+# the L-BFGS point pass (DZO_PROBLEM_QUADRATIC_CHAIN)
+QuadraticChain(n::Integer, lambda, ::Type{T}=Float64) where {T} = _problem(4, n, T; lambda=lambda)
 function (p::BuiltinProblem{T})(x::HipVector{T}) where {T}                           # objective_function(x)
     f = Ref{Cdouble}(0)
     check(ccall((:dzo_problem_eval, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), p.handle, x.ptr, f))

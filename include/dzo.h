@@ -57,6 +57,7 @@ extern "C" {
 #define DZO_PROBLEM_ROSENBROCK_CHAIN 1  /* sum 100(x[i+1]-x[i]^2)^2 + (1-x[i])^2 */
 #define DZO_PROBLEM_QUADRATIC 2         /* 1/2 x'Ax, dense symmetric A */
 #define DZO_PROBLEM_LSE 3               /* log sum exp(x) + lambda/2 |x-c|^2 */
+#define DZO_PROBLEM_QUADRATIC_CHAIN 4   /* sum 1/2 (x[i+1]-x[i])^2 + lambda/2 (x[i]-1)^2: the large-n convex quadratic (tridiagonal Hessian) */
 
 /* how compute_lbfgs_step_direction! is executed on the device */
 #define DZO_TWOLOOP_CHAIN 0 /* 2k+1 fused axpy+dot links in the reference's op order */

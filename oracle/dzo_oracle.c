@@ -24,6 +24,7 @@
 #define ORC_PROBLEM_ROSENBROCK_CHAIN 1
 #define ORC_PROBLEM_QUADRATIC 2
 #define ORC_PROBLEM_LSE 3
+#define ORC_PROBLEM_QUADRATIC_CHAIN 4
 
 /* 0 sequential | 1 eight-lane | 2 wide accumulator; see orc_dot. */
 static int orc_dot_mode = 0;

@@ -152,6 +152,21 @@ static inline ACC FN(rosen_term)(T xi, T xn) {
     return (ACC)T_FMA((T)100 * t2, t2, t1 * t1);
 }
 
+/* Chained quadratic (build-defined synthetic objective, the large-n member of north_star's "synthetic quadratic"
+ * problems; dzoptimization.jl_amd/csrc/dzo_rosen.h uses the same expressions):
+ *   f = sum_{i<n-1} 1/2 (x[i+1]-x[i])^2 + sum_{i<n} lambda/2 (x[i]-1)^2
+ * index tests as 0 / 1 coefficients, so that every element runs the same operations in the same order */
+static inline ACC FN(qchain_term)(int64_t i, int64_t n, T lambda, T xi, T xn) {
+    const T hk = i + 1 < n ? (T)0.5 : (T)0, hm = (T)0.5 * lambda;
+    const T d = xi - (T)1;
+    const T pr = xn - xi;
+    return (ACC)T_FMA(hk * pr, pr, (hm * d) * d);
+}
+static inline T FN(qchain_grad)(int64_t i, int64_t n, T lambda, T xp, T xi, T xn) {
+    const T cR = i + 1 < n ? (T)1 : (T)0, cL = i > 0 ? (T)1 : (T)0;
+    return T_FMA(lambda, xi - (T)1, T_FMA(cL, xi - xp, cR * (xi - xn)));
+}
+
 static T FN(problem_eval_base)(const FN(orc_problem) *p, const T *x) {
     const int64_t n = p->n;
     switch (p->kind) {
@@ -178,6 +193,12 @@ static T FN(problem_eval_base)(const FN(orc_problem) *p, const T *x) {
             acc += col * (ACC)x[j];
         }
         return (T)((ACC)0.5 * acc);
+    }
+    case ORC_PROBLEM_QUADRATIC_CHAIN: {
+        ACC acc = 0;
+#pragma omp parallel for reduction(+ : acc) num_threads(orc_threads) schedule(static) if (orc_threads > 1)
+        for (int64_t i = 0; i < n; ++i) acc += FN(qchain_term)(i, n, p->lambda, x[i], i + 1 < n ? x[i + 1] : (T)0);
+        return (T)acc;
     }
     case ORC_PROBLEM_LSE: {
         /* f = log sum exp(x_i) + lambda/2 |x - c|^2, max-subtracted */
@@ -232,6 +253,12 @@ static void FN(problem_grad_base)(const FN(orc_problem) *p, T *g, const T *x) {
             for (int64_t i = 0; i < n; ++i) col += (ACC)a[i] * (ACC)x[i];
             g[j] = (T)col;
         }
+        return;
+    }
+    case ORC_PROBLEM_QUADRATIC_CHAIN: {
+#pragma omp parallel for num_threads(orc_threads) schedule(static) if (orc_threads > 1)
+        for (int64_t i = 0; i < n; ++i)
+            g[i] = FN(qchain_grad)(i, n, p->lambda, i > 0 ? x[i - 1] : (T)0, x[i], i + 1 < n ? x[i + 1] : (T)0);
         return;
     }
     case ORC_PROBLEM_LSE: {

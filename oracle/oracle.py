@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("DZO_ORACLE_LIB") or os.path.join(_HERE, "libdzo_oracle.so")   # (DZO_ORACLE_LIB: the sanitizer build)
 
-ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE = 0, 1, 2, 3
+ROSENBROCK2D, ROSENBROCK_CHAIN, QUADRATIC, LSE, QUADRATIC_CHAIN = 0, 1, 2, 3, 4
 DOT_SEQUENTIAL, DOT_EIGHT_LANE, DOT_WIDE = 0, 1, 2
 
 

@@ -362,3 +362,26 @@ def test_legacy_gradient_descent_invariants():
         assert np.allclose(opt.next_step_direction, want_d, rtol=1e-13)
         prev_x, prev_g, prev_f = x, g, opt.current_objective_value
     assert opt.iteration_count > 20
+
+
+def test_chained_quadratic_follows_its_formula_and_lbfgs_solves_it():
+    """The chained quadratic (build-defined synthetic objective, DZO_PROBLEM_QUADRATIC_CHAIN: the large-n member of
+    north_star's "synthetic quadratic" problems): f = sum 1/2 (x[i+1]-x[i])^2 + lambda/2 (x[i]-1)^2, its gradient against
+    the closed form and central differences (legacy/ExampleFunctions.jl:290-303's idea), and L-BFGS (:454-509) converging
+    to its minimiser x = 1."""
+    n, lam = 37, 0.25
+    x = orc.pcg_fill(n, 3) * 2
+    p = orc.Problem(orc.QUADRATIC_CHAIN, n, lam=lam)
+    f_ref = 0.5 * np.sum(np.diff(x) ** 2) + 0.5 * lam * np.sum((x - 1) ** 2)
+    assert abs(p.eval(x) - f_ref) <= 1e-14 * abs(f_ref)
+    g_ref = lam * (x - 1); g_ref[:-1] += x[:-1] - x[1:]; g_ref[1:] += x[1:] - x[:-1]
+    assert np.allclose(p.grad(x), g_ref, rtol=1e-14, atol=1e-15)
+    h = 1e-6
+    fd = np.array([(p.eval(x + h * e) - p.eval(x - h * e)) / (2 * h) for e in np.eye(n)])
+    assert np.allclose(p.grad(x), fd, atol=1e-7)
+    opt = orc.LBFGS(p, x.copy(), 1.0, 6)
+    for _ in range(400):
+        opt.step()
+        if opt.is_stuck:
+            break
+    assert np.abs(opt.current_point - 1).max() <= 1e-6 and opt.current_objective_value <= 1e-12
