@@ -759,11 +759,12 @@ def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
                  closures do), i.e. the GENERAL two-pass step: Gram pass + reduce + finish + combine, trial, accept, delta kernels;
     `decorated`  the built-in objective with L2 regularisation + box gradient mask + box projection (legacy :219-296) riding
                  on the point pass (its DEC instantiation);
-    `ragged`     n + 1 (not a multiple of the 16-byte vector), phantom-padded point ring.
+    `ragged`     n + 1 (not a multiple of the 16-byte vector), phantom-padded point ring;
+    `quadratic_chain`  the point pass's second objective: the chained quadratic (lambda = 1e-4, same start point).
     Rate from a stretch without any event record; the per-kernel table from a second, untimed stretch."""
     nn = n + 1 if kind == "ragged" else n
     decor = dict(l2=1e-3, box_gradient=(-1.15, 0.95), box_constraint=(-1.15, 0.95)) if kind == "decorated" else {}
-    prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, nn, **decor)
+    prob = dzo.Problem(dzo.QUADRATIC_CHAIN, nn, lam=1e-4) if kind == "quadratic_chain" else dzo.Problem(dzo.ROSENBROCK_CHAIN, nn, **decor)
     x = dzo.DeviceArray.from_host(rosenbrock_chain_x0(nn, seed=5))
     if kind == "callbacks":
         opt = dzo.LBFGSOptimizer(None, prob.native_callbacks(), None, x, 1.0, m)
@@ -789,7 +790,7 @@ def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
     k = opt.history_count
     kern = {nm: {"launches": c, "avg_us": round(1e3 * ms / c, 2)} for nm, (c, ms) in sorted(tab.items(), key=lambda kv: -kv[1][1]) if c}
     out = {"metric": "step!() calls/s", "value": round(steps / el, 2), "unit": "step!() calls/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
-           "dtype": "f64", "config": {"workload": f"L-BFGS m={m} on N-D chained Rosenbrock, n={nn}, fp64: {kind}", "n": nn, "m": m,
+           "dtype": "f64", "config": {"workload": f"L-BFGS m={m} on N-D " + ("chained quadratic" if kind == "quadratic_chain" else "chained Rosenbrock") + f", n={nn}, fp64: {kind}", "n": nn, "m": m,
                                       "history_layout": {0: "slabs", 1: "tiles of pairs", 2: "tiles of points"}[opt.ring_layout],
                                       "objective_evals_per_step": round(trials / steps, 3), "any_stuck": bool(opt.is_stuck),
                                       "decorators": decor or None},
@@ -835,7 +836,7 @@ def main():
                     help="default line at N = 1: skip the `secondary` object (configs 2, 4, 5 and AdGD measured after the headline)")
     ap.add_argument("--decorators", default="", help="lbfgs (sweep rows only, never the default line): decorators of legacy/DZOptimization.jl:219-296 "
                                                       "on the objective, e.g. 'l2=0.001,box=-1.15:0.95' (box = gradient mask + projection)")
-    ap.add_argument("--variant", default="", choices=["", "callbacks", "decorated", "ragged"],
+    ap.add_argument("--variant", default="", choices=["", "callbacks", "decorated", "ragged", "quadratic_chain"],
                     help="lbfgs: print only the line of one variant leg of the `secondary` object (dev)")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
     ap.add_argument("--batched-steps", type=int, default=0,
@@ -1065,7 +1066,7 @@ def main():
         # profiling / A-B commands all pass --no-cpu-baseline and stay as they were)
         opt.close()
         out["secondary"] = secondary_in_line(args, dzo, sharding, info)
-        for kind in ("callbacks", "decorated", "ragged"):
+        for kind in ("callbacks", "decorated", "ragged", "quadratic_chain"):
             t_leg = time.perf_counter()
             try:
                 leg = _lbfgs_variant_leg(dzo, n, m, esize, args, kind)

@@ -34,11 +34,13 @@ def rel(a, b):
 
 
 DECOR = {}                 # decorators of the problem in the cases that set them (legacy/DZOptimization.jl:219-296)
+QCHAIN = {}                # {"lam": ...}: the cases on the chained quadratic (the point pass's second objective)
 
 
 def _make(n, m, dtype, step0=1.0):
     x0 = orc.rosenbrock_chain_x0(n, dtype)
-    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype, **DECOR), None, dzo.DeviceArray.from_host(x0), step0, m)
+    prob = dzo.Problem(dzo.QUADRATIC_CHAIN, n, dtype, **QCHAIN) if QCHAIN else dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype, **DECOR)
+    opt = dzo.LBFGSOptimizer(None, prob, None, dzo.DeviceArray.from_host(x0), step0, m)
     return x0, opt
 
 
@@ -236,6 +238,41 @@ def test_decorated_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n,
         opt.close(); ref.close()
     finally:
         DECOR.clear()
+        orc.set_dot_mode(orc.DOT_SEQUENTIAL)
+        orc.set_threads(1)
+
+
+_QCHAIN_AT_SCALE = [(np.float64, 400_000, 12), (np.float64, 2_500_001, 20), (np.float64, 10_000_000, 20), (np.float64, 400_000, 23),
+                    (np.float32, 500_000, 10), (np.float32, 1_000_003, 16)]
+
+
+@pytest.mark.parametrize("dtype,n,m", _QCHAIN_AT_SCALE, ids=[f"{np.dtype(d).name}-n{n}-m{m}" for d, n, m in _QCHAIN_AT_SCALE])
+def test_chained_quadratic_point_pass_at_scale_matches_the_oracle_step_by_step(dtype, n, m):
+    """The point pass's second objective (ChainObj<T, 1>: the chained quadratic) at the sizes where a
+    wave takes many rows: the oracle follows the GPU's state through the first two steps with a full history and two
+    later ones (lambda = 1e-4: a condition number of 4e4, so the run is still far from its minimiser there)."""
+    QCHAIN.clear(); QCHAIN.update(lam=1e-4)
+    orc.set_threads(8)
+    if dtype == np.float32:
+        orc.set_dot_mode(orc.DOT_WIDE)
+    try:
+        x0, opt = _make(n, m, dtype)
+        assert opt.ring_layout == 2
+        ref_p = orc.Problem(orc.QUADRATIC_CHAIN, n, dtype, lam=1e-4)
+        ref = orc.LBFGS(ref_p, x0.copy(), 1.0, m)
+        it = 0
+        for target in (m, m + 1, m + 7, m + 8):
+            while it < target:
+                opt.step(); it += 1
+                assert not opt.is_stuck
+            _checked_step(opt, ref, n, dtype, (n, m, "step", target))
+            x = opt.current_point.to_host()
+            assert np.array_equal(opt.current_gradient.to_host(), ref_p.grad(x))      # the stencil, bit-exact
+            it += 1
+        assert opt.single_pass_steps == it and opt.ring_layout == 2
+        opt.close(); ref.close()
+    finally:
+        QCHAIN.clear()
         orc.set_dot_mode(orc.DOT_SEQUENTIAL)
         orc.set_threads(1)
 
