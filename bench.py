@@ -752,6 +752,31 @@ def _two_pass_leg(dzo, n, m, esize, args):
     return out
 
 
+def julia_host_probe(n):
+    """cpu_baseline.julia (SURVEY 8(c) last row): is there a `julia` on this box?  If so, the build's own
+    host module (DZOptimizationAMD.jl) is driven through tools/julia_host_check.jl -- in a child process started after this
+    process has finished its own GPU work -- and its config-3 step rate is reported; nothing of /root/reference is involved.
+    If not (the build container and every GPU box seen so far), the line says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    julia = shutil.which("julia")
+    if julia is None:
+        return {"julia": "absent on this box", "kind_note": "cpu_baseline.kind stays \"port\": no Julia runtime to time the reference's own LinearAlgebra calls with"}
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            x0 = os.path.join(tmp, "x0.txt")
+            with open(x0, "w") as f:
+                f.write("\n".join(repr(float(v)) for v in rosenbrock_chain_x0(64, seed=5)) + "\n")
+            r = subprocess.run([julia, os.path.join(ROOT, "tools", "julia_host_check.jl"), x0, "5", "10", str(n)],
+                               capture_output=True, text=True, timeout=600)
+        rate = [float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith("rate ")]
+        return {"julia": julia, "returncode": r.returncode, "host_module_step_calls_per_s": rate[0] if rate else None,
+                "stderr_tail": r.stderr[-300:] if r.returncode else ""}
+    except Exception as e:                                      # noqa: BLE001 -- reported in the line
+        return {"julia": julia, "error": f"{type(e).__name__}: {e}"}
+
+
 def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
     """Config 3 as the callers beside the headline see it, measured after the timed region:
     `callbacks`  the reference's real API -- constraint / objective / gradient supplied as C function pointers
@@ -1042,6 +1067,7 @@ def main():
                                          f"steps to fill the history, then {args.cpu_steps} timed step!() calls with OpenMP x{threads} "
                                          f"(= the host cores this job may use) and {args.cpu_steps_single} more on one core"
                                          + ("" if cn == n else f"; rates scaled by {cn}/{n}")}
+        out["cpu_baseline"]["julia"] = julia_host_probe(n)
     if world == 1 and not args.no_cpu_baseline and not args.no_secondary and not opt.is_stuck:
         # The same optimizer run on: 1000 more step!() calls, timed as a block without any event record.  `value` above is
         # the contract's window (W warm-up steps after the history filled, then K steps); early in this trajectory more

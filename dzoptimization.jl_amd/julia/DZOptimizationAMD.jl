@@ -531,26 +531,56 @@ end
 
 ################################################################################ AdGD
 
-"""`AdGDOptimizer(constraint!, objective, gradient!, x0, initial_step_length)`
-(src/DZOptimization.jl:245-251); built-in objectives only in this thin binding."""
-mutable struct AdGDOptimizer{T}
+"""`AdGDOptimizer(constraint!, objective, gradient!, x0, initial_step_length)` (src/DZOptimization.jl:245-272) or the full
+form with `f0, g0` (:203-243).  The struct of :179-200: the three callbacks are fields, the state fields are read
+through `getproperty`.  `objective` may be a `BuiltinProblem` (then the step runs on the device's fused pass).  Aliases
+`x0` as `current_point` and `g0` as `current_gradient` (:232, :235)."""
+mutable struct AdGDOptimizer{T,A,C,F,G} <: AbstractOptimizer{T,A}
     handle::Ptr{Cvoid}
-    current_point::HipVector{T}
+    constraint_function!::C
+    objective_function::F
+    gradient_function!::G
+    current_point::A
     keep::Any
-    AdGDOptimizer{T}(h, x, keep) where {T} =
-        finalizer(o -> ccall((:dzo_adgd_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)), new{T}(h, x, keep))
+    AdGDOptimizer{T,A,C,F,G}(h, c, f, g, x, keep) where {T,A,C,F,G} =
+        finalizer(o -> ccall((:dzo_adgd_destroy, libdzo), Cint, (Ptr{Cvoid},), getfield(o, :handle)), new{T,A,C,F,G}(h, c, f, g, x, keep))
 end
-function AdGDOptimizer(::Nothing, objective::BuiltinProblem{T}, ::Any, x0::HipVector{T}, step::Real) where {T}
+# full form (:203-243)
+function AdGDOptimizer(constraint!::C, objective::F, gradient!::G, x0::HipVector{T}, f0::Real, g0::HipVector{T},
+                       initial_step_length::Real) where {T,C,F,G}
     ensure_init()
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:dzo_adgd_create_problem, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), objective.handle, x0.ptr, step, h))
-    return AdGDOptimizer{T}(h[], x0, objective)
+    check(ccall((:dzo_adgd_create, libdzo), Cint, (Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Ptr{Cvoid}}),
+                length(x0), dtype_code(T), x0.ptr, g0.ptr, f0, initial_step_length, h))
+    cb = Ref(Callbacks{C,F,G,T}(constraint!, objective, gradient!, length(x0)))
+    cf = constraint! === nothing ? C_NULL : @cfunction(_c_constraint, Cint, (Ptr{Cvoid}, Ptr{Cvoid}))
+    check(ccall((:dzo_adgd_set_callbacks, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                h[], cf, @cfunction(_c_objective, Cdouble, (Ptr{Cvoid}, Ptr{Cvoid})),
+                @cfunction(_c_gradient, Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid})), pointer_from_objref(cb)))
+    return AdGDOptimizer{T,HipVector{T},C,F,G}(h[], constraint!, objective, gradient!, x0, (cb, g0))
+end
+# short form (:245-272)
+function AdGDOptimizer(constraint!::C, objective::F, gradient!::G, x0::HipVector{T}, initial_step_length::Real) where {T,C,F,G}
+    ensure_init()
+    if objective isa BuiltinProblem && constraint! === nothing
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dzo_adgd_create_problem, libdzo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), objective.handle, x0.ptr, initial_step_length, h))
+        return AdGDOptimizer{T,HipVector{T},C,F,G}(h[], constraint!, objective, gradient!, x0, objective)
+    end
+    if constraint! !== nothing
+        @assert constraint!(x0)                                                    # :256-258
+    end
+    f0 = objective(x0)                                                             # :260
+    g0 = similar(x0)                                                               # :262
+    objective isa BuiltinProblem ? gradient!(objective, g0, x0) : gradient!(g0, x0)   # :265
+    return AdGDOptimizer(constraint!, objective, objective isa BuiltinProblem ? ((g, x) -> gradient!(objective, g, x)) : gradient!,
+                         x0, f0, g0, initial_step_length)
 end
 step!(opt::AdGDOptimizer) = (check(ccall((:dzo_adgd_step, libdzo), Cint, (Ptr{Cvoid},), getfield(opt, :handle))); opt)
 _ad_i(o, w) = (v = Ref{Int64}(0); check(ccall((:dzo_adgd_get_i, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), getfield(o, :handle), w, v)); v[])
 _ad_s(o, w) = (v = Ref{Cdouble}(0); check(ccall((:dzo_adgd_get_s, libdzo), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), getfield(o, :handle), w, v)); v[])
 # public fields of src/DZOptimization.jl:179-200
-function Base.getproperty(o::AdGDOptimizer{T}, s::Symbol) where {T}
+function Base.getproperty(o::AdGDOptimizer{T,A,C,F,G}, s::Symbol) where {T,A,C,F,G}
     s in (:is_stuck, :has_terminated, :has_converged) && return fill(_ad_i(o, 0) != 0)
     s === :iteration_count && return fill(Int(_ad_i(o, 1)))
     s === :current_objective_value && return fill(T(_ad_s(o, 0)))

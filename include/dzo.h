@@ -192,7 +192,7 @@ int32_t dzo_problem_eval(dzo_problem_t p, const void *x_dev, double *f);
 int32_t dzo_problem_grad(dzo_problem_t p, void *g_dev, const void *x_dev);
 /* The built-in objectives in the SHAPE of the reference's three callbacks (src/DZOptimization.jl:323-325,
  * called at :134-138 and :479): pass these function pointers with ctx = the dzo_problem_t to
- * dzo_lbfgs_create_callbacks / dzo_adgd_create_callbacks and the optimizer runs its general (callback)
+ * dzo_lbfgs_create_callbacks / dzo_adgd_set_callbacks and the optimizer runs its general (callback)
  * path on a device-side objective -- what a Julia host does when its callbacks are closures over
  * dzo_problem_eval / dzo_problem_grad, without a host-language frame in the loop.  The constraint
  * callback projects into the problem's box (legacy/DZOptimization.jl:264-272) when one is set and
