@@ -990,6 +990,15 @@ template <typename T> struct FusedParams {
     T obj_lambda;                              // point pass, OBJ = 1: the chained quadratic's lambda
 };
 
+// Every pointer a pass dereferences, checked on the host before the launch: a null here must be an error code, never a
+// GPU memory fault (round 3 saw one "Memory access fault ... on address (nil)" from an uncommitted working tree of the
+// edge-array experiment; a fault can reset every GPU of the host).  `pair`: the pair-ring pass also
+// reads x / g and writes the twin buffers and d.
+template <typename T> static inline bool fused_params_ok(const FusedParams<T> &fp, bool pair) {
+    const bool common = fp.ring && fp.alpha && fp.coef && fp.scale && fp.gram_partials && fp.obj_partials && fp.changed && fp.rowbytes != 0 && fp.n > 0;
+    return common && (!pair || (fp.x && fp.g && fp.x_out && fp.g_out && fp.d)) && (pair || fp.d);
+}
+
 // PLAIN: ablation build with plain instead of non-temporal history loads (DZO_TUNE_SP_DEBUG bit 256,
 // fp64 K = 20 only); a run-time switch inside the kernel costs SGPRs the production kernel does not have
 template <typename T, int K, bool PLAIN = false>
@@ -2731,6 +2740,8 @@ template <typename T> static int32_t lbfgs_step_single_pass(dzo_lbfgs_s *o) {
     // decrease, once more at t = 1/2 -- the loop of take_backtracking_step! (:121-152) on the same kernel, x and g
     // untouched in between.  Deeper halvings continue on the cheap trial kernels.
     const bool retry_pass = tune("DZO_TUNE_SP_RETRY", 1) != 0;
+    DZO_REQUIRE(fused_params_ok<T>(fp, true), DZO_ERR_STATE, "single-pass step: a null operand (ring %p, x %p, g %p, twins %p %p, d %p)",
+                (void *)fp.ring, (const void *)fp.x, (const void *)fp.g, (void *)fp.x_out, (void *)fp.g_out, (void *)fp.d);
     double t = 1.0;
     for (int attempt = 0;; ++attempt) {
     fp.t = (T)t; fp.t_half = (T)round_to_dtype(c.dtype, t * 0.5);
@@ -2917,6 +2928,7 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     fp.stage_rows = 1;
     void (*kern)(FusedParams<T>) = point_pass_kernel_for<T>(o, false);
     const int grid = points_grid<T>(o, kern);
+    DZO_REQUIRE(fused_params_ok<T>(fp, false), DZO_ERR_STATE, "direction on demand: a null operand (ring %p, d %p)", (void *)fp.ring, (void *)fp.d);
     {
         DZO_TIMED("lbfgs_direction_on_demand", s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fp);
@@ -2992,6 +3004,8 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     // second round behind the others (n = 1e7, m = 5: 172 -> 144 us per pass, 4400 -> 5500 step!()/s)
     const int grid = points_grid<T>(o, kern, stage_bytes);
     const int pgrid = grid;                               // columns of per-block partial sums
+    DZO_REQUIRE(fused_params_ok<T>(fp, false), DZO_ERR_STATE, "point pass: a null operand (ring %p, d %p, scalars %p %p %p)",
+                (void *)fp.ring, (void *)fp.d, (const void *)fp.alpha, (const void *)fp.coef, (const void *)fp.scale);
     o->d_stale = false;                                   // (whatever was pending belonged to the previous step)
     const int view_k = k, view_newest = o->newest;
     auto direction_pending = [&]() { if (k > 0 && o->lazy_d) { o->d_stale = true; o->dview_k = view_k; o->dview_newest = view_newest; } };
