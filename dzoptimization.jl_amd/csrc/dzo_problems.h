@@ -22,6 +22,7 @@ struct dzo_problem_s {
     int64_t scratch_doubles = 0;   // usable partials in scratch
     double *result = nullptr;  // device: [f, ...] inside scratch
     double *host = nullptr;    // pinned host scalars
+    double *tri_part = nullptr; // QUADRATIC: row / column parts of the lower-triangle evaluations (quadratic_tri6_kernel)
 };
 
 namespace dzo {

@@ -385,6 +385,23 @@ template <typename T> struct PhiDir {
     int active[3];
 };
 
+// device-driven searches: the requests as the previous round's finish kernel posted them (see quadratic_phi6_kernel)
+template <typename T> __device__ __forceinline__ int phi6_take_requests(PhiDir<T> &a, PhiDir<T> &b, const PhiReqDev *__restrict__ dreq) {
+    int any = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        a.ts[r] = (T)dreq->ts[0][r]; a.active[r] = dreq->active[0][r]; a.ref_req[r] = dreq->ref_req[0][r];
+        b.ts[r] = (T)dreq->ts[1][r]; b.active[r] = dreq->active[1][r]; b.ref_req[r] = dreq->ref_req[1][r];
+        any |= a.active[r] | b.active[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { a.ref[r] = nullptr; b.ref[r] = nullptr; }
+    const int ra = dreq->use_ref[0][0], rb = dreq->use_ref[1][0];
+    if (ra) a.ref[0] = ra == 1 ? a.point_out[0] : (ra == 2 ? a.point_out[1] : a.point_out[2]);
+    if (rb) b.ref[0] = rb == 1 ? b.point_out[0] : (rb == 2 ? b.point_out[1] : b.point_out[2]);
+    return any;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
                                                                 PhiDir<T> a, PhiDir<T> b,
@@ -392,25 +409,9 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
                                                                 const PhiReqDev *__restrict__ dreq) {
     constexpr int N = Vec16<T>::N;
     __shared__ double lds6[6 * kWaves];
-    if (dreq) {
-        // device-driven search (dzo_bfgs.hip): which requests run, their step sizes and their :150 references were
-        // posted by the previous round's finish kernel; a round behind a finished search does nothing
-        int any = 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            a.ts[r] = (T)dreq->ts[0][r]; a.active[r] = dreq->active[0][r]; a.ref_req[r] = dreq->ref_req[0][r];
-            b.ts[r] = (T)dreq->ts[1][r]; b.active[r] = dreq->active[1][r]; b.ref_req[r] = dreq->ref_req[1][r];
-            any |= a.active[r] | b.active[r];
-        }
-        if (!any) return;
-        // the :150 reference of a primary request: none, or one of the direction's own trial-point buffers as the
-        // previous launch left it (no copy of the reference point between the rounds)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { a.ref[r] = nullptr; b.ref[r] = nullptr; }
-        const int ra = dreq->use_ref[0][0], rb = dreq->use_ref[1][0];
-        if (ra) a.ref[0] = ra == 1 ? a.point_out[0] : (ra == 2 ? a.point_out[1] : a.point_out[2]);
-        if (rb) b.ref[0] = rb == 1 ? b.point_out[0] : (rb == 2 ? b.point_out[1] : b.point_out[2]);
-    }
+    // device-driven search (dzo_bfgs.hip): which requests run, their step sizes and their :150 references were posted by the
+    // previous round's finish kernel; a round behind a finished search does nothing
+    if (dreq) { if (!phi6_take_requests<T>(a, b, dreq)) return; }
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
         const T *col = A + j * n;
         double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -465,6 +466,213 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
                     if (d.ref[r]) { if (!is_equal(xt[r], refv[r])) flags[slot * 3 + 2] = 1; }
                     else if (d.ref_req[r] >= 0) { if (!is_equal(xt[r], xt[d.ref_req[r]])) flags[slot * 3 + 2] = 1; }
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same evaluations on the LOWER TRIANGLE of A (round 4).  A is symmetric by definition (f = 1/2 x'Ax, "dense
+// symmetric A", include/dzo.h), so c = A x_t needs every element of the triangle once:
+//     row part   c_i += A[i,j] x_t[j]   (j <= i)   thread-local
+//     col part   c_j += A[i,j] x_t[i]   (i >  j)   summed across the wave
+// -- the split of tri_pass_kernel (dzo_bfgs.hip), here for up to six trial points x_t = fma(ts, dir, x) at once (the two
+// line searches' requests of a round, legacy/DZOptimization.jl:922-932) and with a block walking kQtWPB windows, so that
+// the row part leaves one value per 128 columns instead of one per 32.  At config 2 a round reads 67 MB of A instead of
+// 135 MB (both from the Infinity Cache); a second, small kernel adds the parts in a fixed order and does what thread 0
+// of quadratic_phi6_kernel does per element (objective partial, trial point, its gradient, the bracket's flags).
+// EVERY evaluation of the dense quadratic goes this way when the triangle form is on (objective, gradient, phi, phi6):
+// the stored gradient of a point and a recomputed one are then the same bits (run_and_test!, legacy :1025-1032).
+constexpr int kQtPH = 256;           // rows per panel (128 row pairs)
+constexpr int kQtCW = 32;            // columns per window (16 per parity)
+constexpr int kQtUJ = 8;             // columns of one parity per chunk
+#ifndef DZO_QT_WPB
+#define DZO_QT_WPB 4
+#endif
+constexpr int kQtWPB = DZO_QT_WPB;   // windows per block
+
+template <typename T> __device__ __forceinline__ void qt_load2(const T *p, T (&hv)[2]) {
+    if constexpr (sizeof(T) == 8) { const double2 q = *reinterpret_cast<const double2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+    else { const float2 q = *reinterpret_cast<const float2 *>(p); hv[0] = q.x; hv[1] = q.y; }
+}
+
+// rowpart: [6][ranges][n], colpart: [6][panels][n] (ranges = ceil(n / (kQtCW kQtWPB)), panels = ceil(n / kQtPH))
+template <typename T>
+__global__ __launch_bounds__(kBlock, 2) void quadratic_tri6_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
+                                                                   PhiDir<T> a, PhiDir<T> b, double *__restrict__ rowpart,
+                                                                   double *__restrict__ colpart, const PhiReqDev *__restrict__ dreq) {
+    const int P = blockIdx.y, R = blockIdx.x;
+    const int64_t r_first = (int64_t)R * (kQtCW * kQtWPB);
+    if (r_first >= ((int64_t)P + 1) * kQtPH || r_first >= n) return;         // the range lies right of the panel's diagonal
+    if (dreq) { if (!phi6_take_requests<T>(a, b, dreq)) return; }
+    __shared__ double wp[6][kWaves][kQtCW];
+    __shared__ double rp[6][kQtPH];
+    // (wave-uniform, and told so: the column index of a load then is a scalar, and x[j] / dir[j] arrive through the scalar cache)
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / 128);
+    const int lane_h = threadIdx.x % 128;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int64_t row = (int64_t)P * kQtPH + 2 * lane_h;
+    const int64_t ranges = (n + kQtCW * kQtWPB - 1) / (kQtCW * kQtWPB), panels = (n + kQtPH - 1) / kQtPH;
+    int act[6]; T ts[6]; const T *dir[6];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        act[q] = a.active[q]; ts[q] = a.ts[q]; dir[q] = a.dir;
+        act[3 + q] = b.active[q]; ts[3 + q] = b.ts[q]; dir[3 + q] = b.dir;
+    }
+    // the trial points at this thread's two rows
+    double v0[6], v1[6];
+    {
+        const bool in = row < n;
+        const T x0 = in ? x[row] : (T)0, x1 = in ? x[row + 1] : (T)0;
+        const T a0 = in ? a.dir[row] : (T)0, a1 = in ? a.dir[row + 1] : (T)0;
+        const T b0 = in ? b.dir[row] : (T)0, b1 = in ? b.dir[row + 1] : (T)0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            v0[q] = in ? (double)dfma(ts[q], q < 3 ? a0 : b0, x0) : 0.0;
+            v1[q] = in ? (double)dfma(ts[q], q < 3 ? a1 : b1, x1) : 0.0;
+        }
+    }
+    double acc[6][2];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { acc[q][0] = 0; acc[q][1] = 0; }
+    // loads: unconditional (masked lanes read the first bytes of A), a chunk of eight columns per request, one chunk ahead
+    auto issue = [&](int64_t c_first, int c0, T (&hv)[kQtUJ][2]) {
+#pragma unroll
+        for (int u = 0; u < kQtUJ; ++u) {
+            const int64_t j = c_first + half + 2 * (c0 + u);
+            const bool on = c0 + u < kQtCW / 2 && j < n && row < n && row + 1 >= j;
+            qt_load2<T>(on ? A + j * n + row : A, hv[u]);
+        }
+    };
+    auto chunk = [&](int64_t c_first, int c0, const T (&hv)[kQtUJ][2]) {
+        double h0[kQtUJ], h1[kQtUJ], m0[kQtUJ], m1[kQtUJ];
+        T xj[kQtUJ], aj[kQtUJ], bj[kQtUJ];
+#pragma unroll
+        for (int u = 0; u < kQtUJ; ++u) {
+            const int64_t j = c_first + half + 2 * (c0 + u);
+            const bool inw = c0 + u < kQtCW / 2 && j < n;
+            const bool on = inw && row < n && row + 1 >= j;
+            const bool lo0 = on && row >= j;                                 // (row == j - 1: an upper element of the pair, left alone)
+            const int64_t jc = inw ? j : 0;
+            xj[u] = x[jc]; aj[u] = a.dir[jc]; bj[u] = b.dir[jc];
+            h0[u] = lo0 ? (double)hv[u][0] : 0.0; h1[u] = on ? (double)hv[u][1] : 0.0;
+            m0[u] = row > j ? h0[u] : 0.0; m1[u] = row + 1 > j ? h1[u] : 0.0;   // strictly lower: the mirror part
+            if (!inw) { xj[u] = (T)0; aj[u] = (T)0; bj[u] = (T)0; }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (!act[q]) continue;                                          // (wave-uniform: later rounds carry one or two requests per direction)
+            double col[8];
+#pragma unroll
+            for (int u = 0; u < kQtUJ; ++u) {
+                const double vj = (double)dfma(ts[q], q < 3 ? aj[u] : bj[u], xj[u]);
+                acc[q][0] = __builtin_fma(h0[u], vj, acc[q][0]);
+                acc[q][1] = __builtin_fma(h1[u], vj, acc[q][1]);
+                col[u] = __builtin_fma(m1[u], v1[q], m0[u] * v0[q]);
+            }
+            const double tot = wave_sum8(col, ln);
+            const int cw = 2 * (c0 + wave_sum8_owner(ln)) + half;           // column within the window
+            if (ln < 8 && cw < kQtCW) wp[q][wv][cw] = tot;
+        }
+    };
+    // chunks of a block in order: window w = c / 2, columns (c % 2) kQtUJ ... of each parity; two buffers, one chunk ahead
+    T hvA[kQtUJ][2], hvB[kQtUJ][2];
+    auto window_on = [&](int w) { const int64_t c = r_first + (int64_t)w * kQtCW; return w < kQtWPB && c < n && c < ((int64_t)P + 1) * kQtPH; };
+    auto flush_window = [&](int w) {                                        // the window's column parts: the two waves of a parity
+        __syncthreads();
+        if (threadIdx.x < kQtCW) {
+            const int cw = threadIdx.x, hw = cw & 1;                        // parity hw lives in waves 2 hw, 2 hw + 1
+            const int64_t j = r_first + (int64_t)w * kQtCW + cw;
+            if (j < n) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) if (act[q]) colpart[((int64_t)q * panels + P) * n + j] = wp[q][2 * hw][cw] + wp[q][2 * hw + 1][cw];
+            }
+        }
+        __syncthreads();
+    };
+    int nwin = 0;
+    while (window_on(nwin)) ++nwin;                                         // (uniform)
+    const int nchunks = 2 * nwin;
+    issue(r_first, 0, hvA);
+    for (int c = 0; c < nchunks; c += 2) {
+        const int w = c / 2;
+        const int64_t c_first = r_first + (int64_t)w * kQtCW;
+        issue(c_first, kQtUJ, hvB);                                         // chunk c + 1: the second half of window w
+        chunk(c_first, 0, hvA);
+        if (c + 2 < nchunks) issue(c_first + kQtCW, 0, hvA);               // chunk c + 2: the first half of window w + 1
+        chunk(c_first, kQtUJ, hvB);
+        flush_window(w);
+    }
+    // row part: the two column parities of a row pair
+    if (half == 1) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { rp[q][2 * lane_h] = acc[q][0]; rp[q][2 * lane_h + 1] = acc[q][1]; }
+    }
+    __syncthreads();
+    if (half == 0 && row < n) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (!act[q]) continue;
+            double *dst = rowpart + ((int64_t)q * ranges + R) * n + row;
+            dst[0] = acc[q][0] + rp[q][2 * lane_h];
+            dst[1] = acc[q][1] + rp[q][2 * lane_h + 1];
+        }
+    }
+}
+
+// c_i of every active request = its row parts of the ranges up to the diagonal + its column parts of the panels from
+// the diagonal on, fixed order; then, per element, what thread 0 of quadratic_phi6_kernel does for its column.
+// partials: [6][n] (the objective's x_t[i] c_i); flags may be null (plain objective / gradient evaluations).
+constexpr int kQtRI = 32, kQtRG = kBlock / kQtRI;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void quadratic_tri6_reduce_kernel(int64_t n, const T *__restrict__ x, PhiDir<T> a, PhiDir<T> b,
+                                                                       const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                                       double *__restrict__ partials, int32_t *__restrict__ flags,
+                                                                       const PhiReqDev *__restrict__ dreq) {
+    if (dreq) { if (!phi6_take_requests<T>(a, b, dreq)) return; }
+    __shared__ double grp[6][kQtRG][kQtRI];
+    const int li = threadIdx.x % kQtRI, gq = threadIdx.x / kQtRI;
+    const int64_t i = (int64_t)blockIdx.x * kQtRI + li;
+    const int64_t ranges = (n + kQtCW * kQtWPB - 1) / (kQtCW * kQtWPB), panels = (n + kQtPH - 1) / kQtPH;
+    int act[6];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { act[q] = a.active[q]; act[3 + q] = b.active[q]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        double s = 0;
+        if (act[q] && i < n) {
+            for (int64_t r = gq; r <= i / (kQtCW * kQtWPB); r += kQtRG) s += rowpart[((int64_t)q * ranges + r) * n + i];
+            for (int64_t pp = i / kQtPH + gq; pp < panels; pp += kQtRG) s += colpart[((int64_t)q * panels + pp) * n + i];
+        }
+        grp[q][gq][li] = s;
+    }
+    __syncthreads();
+    if (gq != 0 || i >= n) return;
+    const T xo = x[i];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const PhiDir<T> &d = side ? b : a;
+        const T dj = d.dir[i];
+        T xt[3], refv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xt[r] = dfma(d.ts[r], dj, xo);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) refv[r] = (d.active[r] && d.ref[r]) ? d.ref[r][i] : (T)0;   // first: a reference may be one of this launch's own output buffers
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (!d.active[r]) continue;
+            const int slot = side * 3 + r;
+            double c = 0;
+#pragma unroll
+            for (int g8 = 0; g8 < kQtRG; ++g8) c += grp[slot][g8][li];
+            partials[(int64_t)slot * n + i] = c * (double)xt[r];
+            if (d.point_out[r]) d.point_out[r][i] = xt[r];
+            if (d.grad_out[r]) d.grad_out[r][i] = (T)c;
+            if (flags) {
+                if (xo != xt[r]) flags[slot * 3 + 0] = 1;
+                if (dj != (T)0) flags[slot * 3 + 1] = 1;
+                if (d.ref[r]) { if (!is_equal(xt[r], refv[r])) flags[slot * 3 + 2] = 1; }
+                else if (d.ref_req[r] >= 0) { if (!is_equal(xt[r], xt[d.ref_req[r]])) flags[slot * 3 + 2] = 1; }
             }
         }
     }
@@ -673,6 +881,42 @@ int32_t box_clamp_async(hipStream_t s, int64_t n, int32_t dtype, void *x, double
 }
 
 // ------------------------------------------------------------------ host side
+// ---- the triangle form of the dense quadratic's evaluations (quadratic_tri6_kernel)
+// MEASURED (round 4, config 2, rocprofv3) and OFF by default (DZO_TUNE_QUAD_TRI=1 selects it, read when a
+// problem handle is created): the round's six evaluations take 26.7 us in quadratic_tri6_kernel + 21.1 us in its reduce
+// kernel (one window per block: 25 MB of row parts) or 50.6 us in all with four windows per block, against 32.8 us for
+// quadratic_phi6_kernel + its share of the finish reading the FULL matrix -- 5250-5330 against 6430-6460 step!()/s.  The
+// full matrix streams out of the Infinity Cache at 4.4 TB/s from 4096 independent column blocks; the triangle halves the
+// bytes but pays for six transposed wave reductions per chunk and a second kernel, and has 272 (or 1100) tiles to hide
+// its load latency with.  Bit-compatible with every search variant (the whole BFGS suite passes with it on).
+static bool quad_tri_knob() { return getenv("DZO_TUNE_QUAD_TRI") ? atoi(getenv("DZO_TUNE_QUAD_TRI")) != 0 : false; }
+static bool quad_tri_on(const dzo_problem_s *p) {
+    static const int min_n = getenv("DZO_TUNE_QUAD_TRI_MIN_N") ? atoi(getenv("DZO_TUNE_QUAD_TRI_MIN_N")) : 1024;
+    return p->tri_part != nullptr && p->n % 2 == 0 && p->n >= min_n && (reinterpret_cast<uintptr_t>(p->A) & 15u) == 0;
+}
+static inline int64_t quad_tri_doubles(int64_t n) {
+    const int64_t ranges = (n + kQtCW * kQtWPB - 1) / (kQtCW * kQtWPB), panels = (n + kQtPH - 1) / kQtPH;
+    return 6 * (ranges + panels) * n;
+}
+template <typename T>
+static void quad_tri_launch(dzo_problem_s *p, hipStream_t s, const T *x, const PhiDir<T> &a, const PhiDir<T> &b, int32_t *flags, const PhiReqDev *dreq) {
+    const int64_t n = p->n;
+    const int64_t ranges = (n + kQtCW * kQtWPB - 1) / (kQtCW * kQtWPB), panels = (n + kQtPH - 1) / kQtPH;
+    double *rowpart = p->tri_part, *colpart = p->tri_part + 6 * ranges * n;
+    hipLaunchKernelGGL(quadratic_tri6_kernel<T>, dim3((unsigned)ranges, (unsigned)panels), dim3(kBlock), 0, s, n, (const T *)p->A, x, a, b, rowpart, colpart, dreq);
+    hipLaunchKernelGGL(quadratic_tri6_reduce_kernel<T>, dim3((unsigned)((n + kQtRI - 1) / kQtRI)), dim3(kBlock), 0, s, n, x, a, b,
+                       (const double *)rowpart, (const double *)colpart, p->scratch, flags, dreq);
+}
+// one plain evaluation at x itself (objective partials in scratch[0 .. n), gradient to g when given): request 0 of side a with dir = x, ts = 0
+template <typename T> static void quad_tri_eval(dzo_problem_s *p, hipStream_t s, const T *x, T *g) {
+    PhiDir<T> a, b;
+    memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
+    a.dir = x; b.dir = x;
+    for (int r = 0; r < 3; ++r) { a.ref_req[r] = -1; b.ref_req[r] = -1; }
+    a.active[0] = 1; a.grad_out[0] = g;                     // x_t = fma(0, x, x) = x
+    quad_tri_launch<T>(p, s, x, a, b, nullptr, nullptr);
+}
+
 template <typename T> static int32_t eval_async_t(dzo_problem_s *p, hipStream_t s, const T *x, double *result_dev) {
     const int64_t n = p->n;
     switch (p->kind) {
@@ -692,8 +936,9 @@ template <typename T> static int32_t eval_async_t(dzo_problem_s *p, hipStream_t 
     case DZO_PROBLEM_QUADRATIC: {
         DZO_TIMED("objective_quadratic", s);
         const int grid = (int)(n < 65535 ? n : 65535);
-        hipLaunchKernelGGL((quadratic_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x,
-                           (T *)nullptr, p->scratch);
+        if (quad_tri_on(p)) quad_tri_eval<T>(p, s, x, (T *)nullptr);
+        else hipLaunchKernelGGL((quadratic_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x,
+                                (T *)nullptr, p->scratch);
         hipLaunchKernelGGL(finish_scaled_sum_kernel, dim3(1), dim3(kBlock), 0, s, p->scratch, n, 0.5, result_dev);
         break;
     }
@@ -741,8 +986,9 @@ template <typename T> static int32_t grad_async_t(dzo_problem_s *p, hipStream_t 
     case DZO_PROBLEM_QUADRATIC: {
         DZO_TIMED("gradient_quadratic", s);
         const int grid = (int)(n < 65535 ? n : 65535);
-        hipLaunchKernelGGL((quadratic_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x, g,
-                           (double *)nullptr);
+        if (quad_tri_on(p)) quad_tri_eval<T>(p, s, x, g);
+        else hipLaunchKernelGGL((quadratic_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, x, g,
+                                (double *)nullptr);
         break;
     }
     case DZO_PROBLEM_QUADRATIC_CHAIN: {
@@ -830,7 +1076,19 @@ bool problem_phi_async(dzo_problem_s *p, hipStream_t s, const void *x, const voi
     const int64_t n = p->n;
     DZO_TIMED("objective_quadratic_phi", s);
     const int grid = (int)(n < 65535 ? n : 65535);
-    if (p->dtype == DZO_F64)
+    if (quad_tri_on(p)) {
+        auto go = [&](auto tag) {
+            using T = decltype(tag);
+            PhiDir<T> a, b;
+            memset(&a, 0, sizeof(a)); memset(&b, 0, sizeof(b));
+            a.dir = (const T *)dir; b.dir = (const T *)dir;
+            for (int r = 0; r < 3; ++r) { a.ref_req[r] = -1; b.ref_req[r] = -1; }
+            a.active[0] = 1; a.ts[0] = (T)ts; a.point_out[0] = (T *)point_out; a.ref[0] = (const T *)ref;
+            // (single-request flags live in flags[0..2]: the same words request 0 of side a uses)
+            quad_tri_launch<T>(p, s, (const T *)x, a, b, flags, nullptr);
+        };
+        if (p->dtype == DZO_F64) go(double{}); else go(float{});
+    } else if (p->dtype == DZO_F64)
         hipLaunchKernelGGL(quadratic_phi_kernel<double>, dim3(grid), dim3(kBlock), 0, s, n, (const double *)p->A, (const double *)x,
                            (const double *)dir, ts, (double *)point_out, p->scratch, flags, (const double *)ref);
     else
@@ -864,8 +1122,9 @@ bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const Ph
                 d[side].active[r] = req[side].active[r] ? 1 : 0;
             }
         }
-        hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
-                           p->scratch, flags, dreq);
+        if (quad_tri_on(p)) quad_tri_launch<T>(p, s, (const T *)x, d[0], d[1], flags, dreq);
+        else hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
+                                p->scratch, flags, dreq);
     };
     if (p->dtype == DZO_F64) launch(double{}); else launch(float{});
     if (dreq) return true;                                       // (the caller's finish kernel sums, advances the searches and posts the next requests)
@@ -900,7 +1159,8 @@ bool problem_eval_partials_async(dzo_problem_s *p, hipStream_t s, const void *x,
     if (p->kind == DZO_PROBLEM_QUADRATIC) {
         DZO_TIMED("objective_quadratic", s);
         const int grid = (int)(n < 65535 ? n : 65535);
-        if (p->dtype == DZO_F64) hipLaunchKernelGGL((quadratic_kernel<double, false>), dim3(grid), dim3(kBlock), 0, s, n, (const double *)p->A, (const double *)x, (double *)nullptr, p->scratch);
+        if (quad_tri_on(p)) { if (p->dtype == DZO_F64) quad_tri_eval<double>(p, s, (const double *)x, (double *)nullptr); else quad_tri_eval<float>(p, s, (const float *)x, (float *)nullptr); }
+        else if (p->dtype == DZO_F64) hipLaunchKernelGGL((quadratic_kernel<double, false>), dim3(grid), dim3(kBlock), 0, s, n, (const double *)p->A, (const double *)x, (double *)nullptr, p->scratch);
         else hipLaunchKernelGGL((quadratic_kernel<float, false>), dim3(grid), dim3(kBlock), 0, s, n, (const float *)p->A, (const float *)x, (float *)nullptr, p->scratch);
         *partials = p->scratch; *count = n; *scale = 0.5;
         return true;
@@ -944,13 +1204,18 @@ static int32_t problem_alloc_workspace(dzo_problem_s *p) {
     e = hipHostMalloc((void **)&p->host, sizeof(double) * 4, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipFree(p->scratch); p->scratch = nullptr; p->host = nullptr; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
     p->result = p->scratch + scratch - 8;
+    p->tri_part = nullptr;
+    if (p->kind == DZO_PROBLEM_QUADRATIC && n % 2 == 0 && n >= 512 && quad_tri_knob()) {
+        // row / column parts of the triangle form (2.3 % of A's own size); without them the full-matrix kernels serve
+        if (hipMalloc((void **)&p->tri_part, sizeof(double) * (size_t)quad_tri_doubles(n)) != hipSuccess) { (void)hipGetLastError(); p->tri_part = nullptr; }
+    }
     return DZO_OK;
 }
 
 int32_t problem_view_create(dzo_problem_s *parent, dzo_problem_s **out) {
     dzo_problem_s *root = parent->parent ? parent->parent : parent;
     dzo_problem_s *v = new dzo_problem_s(*root);
-    v->parent = root; v->scratch = nullptr; v->result = nullptr; v->host = nullptr;
+    v->parent = root; v->scratch = nullptr; v->result = nullptr; v->host = nullptr; v->tri_part = nullptr;
     const int32_t rc = problem_alloc_workspace(v);
     if (rc != DZO_OK) { delete v; return rc; }
     *out = v;
@@ -968,6 +1233,7 @@ void problem_view_sync(dzo_problem_s *v) {
 void problem_view_destroy(dzo_problem_s *v) {
     if (!v || !v->parent) return;                            // only views are owned by optimizers
     if (v->scratch) (void)hipFree(v->scratch);
+    if (v->tri_part) (void)hipFree(v->tri_part);
     if (v->host) (void)hipHostFree(v->host);
     delete v;
 }
@@ -1029,6 +1295,7 @@ int32_t dzo_box_clamp(int64_t n, int32_t dtype, void *x_dev, double lower_bound,
 int32_t dzo_problem_destroy(dzo_problem_t p) {
     if (!p) return DZO_OK;
     (void)hipFree(p->scratch);
+    if (p->tri_part) (void)hipFree(p->tri_part);
     (void)hipHostFree(p->host);
     delete p;
     return DZO_OK;

@@ -331,3 +331,30 @@ def test_per_instance_matrices_constructor_rejects_what_it_cannot_run():
     xb = dzo.DeviceArray((B, n), np.float64, ptr=p.value, owner=False).to_host()
     assert np.array_equal(xb, a.current_point.to_host())
     dzo._check(dzo.lib().dzo_bfgs_batch_destroy(h))
+
+
+def test_dense_step_on_the_lower_triangle_of_A_matches_the_oracle(monkeypatch):
+    """DZO_TUNE_QUAD_TRI=1 (off by default: measured slower, csrc/dzo_problems.hip): every evaluation of the dense quadratic
+    -- objective, gradient and the line searches' rounds of up to six trial points -- reads the LOWER triangle of the
+    symmetric A only (quadratic_tri6_kernel).  Per step from the oracle's installed state, as the default path is tested."""
+    monkeypatch.setenv("DZO_TUNE_QUAD_TRI", "1")
+    n = 1024
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((n, 8))
+    A = np.diag(1.0 + 99.0 * rng.random(n)) + U @ U.T / 8
+    A = 0.5 * (A + A.T)
+    x0 = rng.random(n) - 0.5
+    ref = orc.BFGS(orc.Problem(orc.QUADRATIC, n, A=A), x0.copy(), 1.0)
+    prob = dzo.Problem(dzo.QUADRATIC, n, A=A)
+    opt = dzo.BFGSOptimizer(prob, None, dzo.DeviceArray.from_host(x0), 1.0)
+    dx = dzo.DeviceArray.from_host(x0)
+    assert abs(prob(dx) - ref.current_objective_value) <= 1e-12 * abs(ref.current_objective_value)
+    g = prob.gradient_(dzo.DeviceArray(n, np.float64), dx).to_host()
+    assert np.linalg.norm(g - ref.current_gradient) <= 1e-12 * np.linalg.norm(ref.current_gradient)
+    for it in range(8):
+        opt.step(); ref.step()
+        assert opt.last_step_type == ref.last_step_type and opt.iteration_count == ref.iteration_count, it
+        x = opt.current_point.to_host()
+        assert np.linalg.norm(x - ref.current_point) <= 1e-9 * np.linalg.norm(ref.current_point), it
+        assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-9)
+        assert np.array_equal(opt.current_gradient.to_host(), prob.gradient_(dzo.DeviceArray(n, np.float64), opt.current_point).to_host())   # run_and_test! :1025-1032
