@@ -1870,6 +1870,58 @@ __global__ __launch_bounds__(kBlock) void delta_rho_kernel(int64_t n, const T *_
     if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
+// The tail of an accepted step on the GENERAL path (callbacks, any objective) in one pass: after the gradient callback has
+// written g_new into the optimizer's other gradient buffer,
+//     delta_point    = x - x_old            (:145; x_old is what the first trial saved in delta_point, :118)
+//     delta_gradient = g_new - g_old        (:478-480 without the copy of :478: g_old is simply the buffer that was current)
+//     partials of rho = delta_point . delta_gradient   (:505)
+// 4 reads + 2 writes per element instead of axpby (3) + copy (2) + delta_rho_kernel (4); same elementwise operations, so
+// the same bits (x - x_old and g_new - g_old are single roundings either way).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void accept_delta_rho_kernel(int64_t n, const T *__restrict__ x, T *__restrict__ dx,
+                                                                  const T *__restrict__ g_new, const T *__restrict__ g_old,
+                                                                  T *__restrict__ dg, double *__restrict__ partials) {
+    using L = Ld<T, VEC>;
+    constexpr int N = L::N;
+    __shared__ double lds[kWaves];
+    double acc = 0;
+    const int64_t nvec = n / N;
+    const int64_t nthreads = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * 2; base < nvec; base += nthreads * 2) {
+        T xv[2][N], ov[2][N], gn[2][N], go[2][N];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                      // all loads of the two vectors first
+            const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
+            if (vi >= nvec) continue;
+            L::load(x + vi * N, xv[u]); L::load(dx + vi * N, ov[u]); L::load(g_new + vi * N, gn[u]); L::load(g_old + vi * N, go[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
+            if (vi >= nvec) continue;
+            T sv[N], yv[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                sv[j] = xv[u][j] - ov[u][j];
+                yv[j] = gn[u][j] - go[u][j];
+                acc = __builtin_fma((double)sv[j], (double)yv[j], acc);
+            }
+            L::store(dx + vi * N, sv);
+            L::store(dg + vi * N, yv);
+        }
+    }
+    if constexpr (VEC) {
+        const int64_t i = nvec * N + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i < n) {
+            const T sv = x[i] - dx[i], yv = g_new[i] - g_old[i];
+            dx[i] = sv; dg[i] = yv;
+            acc = __builtin_fma((double)sv, (double)yv, acc);
+        }
+    }
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 __global__ __launch_bounds__(kBlock) void finish_to_kernel(const double *__restrict__ partials, int count,
                                                            double *__restrict__ dst, int to_f32,
                                                            const int32_t *__restrict__ gate) {
@@ -2547,6 +2599,8 @@ static int32_t lbfgs_wolfe_search(dzo_lbfgs_s *o, bool *accepted) {
     return DZO_OK;
 }
 
+static bool lbfgs_ensure_twins(dzo_lbfgs_s *o);
+static void lbfgs_mark_unsettled(dzo_lbfgs_s *o);
 // one line search along o->d followed, when it succeeds, by the post-gradient phase and the push
 static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
     OptCore &c = o->core;
@@ -2571,7 +2625,11 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
     }
     const bool fused = o->fused_post && !c.objective && !c.gradient && !c.constraint &&
                        problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg);
-    c.defer_delta = fused;
+    // General path (callbacks, any objective without a fused tail): the accepted step's tail as ONE pass
+    // (accept_delta_rho_kernel) with the gradient callback writing into the other gradient buffer -- no axpby, no copy of
+    // g_old (DZO_TUNE_GENERIC_POST=0: the separate kernels, :145 / :478 / :480 / :505 one launch each)
+    const bool one_pass_tail = !fused && tune("DZO_TUNE_GENERIC_POST", 1) != 0 && lbfgs_ensure_twins(o);
+    c.defer_delta = fused || one_pass_tail;
     c.speculative_tail = (fused && o->speculate) ? lbfgs_speculative_tail : nullptr;
     c.speculative_self = o;
     int32_t rc = core_backtracking_step(c, 1.0, o->d, trials_rejected);    // :473
@@ -2601,6 +2659,24 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
         int grid = 0;
         DZO_TRY(problem_fused_post_async(c.problem, c.stream, c.x, c.dx, c.g, c.dg, c.partials(), &grid, nullptr));
         done = lbfgs_finish_push(o, grid, false);
+    } else if (one_pass_tail) {
+        void *g_old = c.g;
+        c.g = o->g_twin;                                  // :479 gradient!(g, x) into the other buffer (the caller's array is settled when somebody looks)
+        int32_t rcg = core_gradient(c);
+        if (rcg != DZO_OK) { c.g = g_old; return rcg; }
+        o->g_twin = g_old;
+        const bool vec = al16(c.x) && al16(c.dx) && al16(c.g) && al16(g_old) && al16(c.dg);
+        const int grid = stream_grid(c.n, (vec ? 16 / (int)dtype_size(c.dtype) : 1) * 2);
+        {
+            DZO_TIMED("lbfgs_accept_delta_rho", c.stream);
+            if (vec) DZO_DISPATCH(c.dtype, hipLaunchKernelGGL((accept_delta_rho_kernel<T, true>), dim3(grid), dim3(kBlock), 0, c.stream, c.n, (const T *)c.x, (T *)c.dx,
+                                                              (const T *)c.g, (const T *)g_old, (T *)c.dg, c.partials()));
+            else DZO_DISPATCH(c.dtype, hipLaunchKernelGGL((accept_delta_rho_kernel<T, false>), dim3(grid), dim3(kBlock), 0, c.stream, c.n, (const T *)c.x, (T *)c.dx,
+                                                          (const T *)c.g, (const T *)g_old, (T *)c.dg, c.partials()));
+        }
+        DZO_HIP(hipGetLastError());
+        lbfgs_mark_unsettled(o);
+        done = lbfgs_finish_push(o, grid, false);
     } else {
         DZO_HIP(hipMemcpyAsync(c.dg, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream)); // :478
         DZO_TRY(core_gradient(c));                        // :479
@@ -2617,6 +2693,22 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
 
 static inline bool al16v(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// the twin buffers of x and g (the pair-ring pass writes its trial point / gradient there; the general path's gradient
+// callback writes g_new there): one slab, allocated on first use; false when the allocation fails
+static bool lbfgs_ensure_twins(dzo_lbfgs_s *o) {
+    if (o->twin_slab) return true;
+    OptCore &c = o->core;
+    const size_t padded = (size_t)((c.n + 63) / 64 * 64) * dtype_size(c.dtype);
+    // the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator hands out: x, g, d and the twins are
+    // accessed at the same element offset at the same time, and equal offsets into equally aligned buffers hit the same
+    // HBM channel
+    const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;
+    if (hipMalloc(&o->twin_slab, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->twin_slab = nullptr; return false; }
+    o->x_twin = (char *)o->twin_slab + 5 * 1024;
+    o->g_twin = (char *)o->x_twin + slot;
+    return true;
+}
+
 // can this step run as one pass over the history?  (built-in chained Rosenbrock, plain options)
 static bool single_pass_ok(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
@@ -2630,16 +2722,7 @@ static bool single_pass_ok(dzo_lbfgs_s *o) {
     if (!problem_has_fused_post(c.problem, c.x, c.dx, c.g, c.dg) || !al16v(o->d)) return false;
     // the twin buffers of x and g: allocated here, before the step touches anything; a failed allocation
     // only switches this optimizer to the two-pass kernels
-    if (!o->twin_slab) {
-        const size_t padded = (size_t)((c.n + 63) / 64 * 64) * dtype_size(c.dtype);
-        // one slab, the two vectors an odd number of KiB apart and off the 2-MiB grid the allocator
-        // hands out: x, g, d and the twins are accessed at the same element offset at the same
-        // time, and equal offsets into equally aligned buffers hit the same HBM channel
-        const size_t slot = ((padded + 1023) / 1024 | 1) * 1024;
-        if (hipMalloc(&o->twin_slab, 2 * slot + 16 * 1024) != hipSuccess) { (void)hipGetLastError(); o->twin_slab = nullptr; o->single_pass = false; return false; }
-        o->x_twin = (char *)o->twin_slab + 5 * 1024;
-        o->g_twin = (char *)o->x_twin + slot;
-    }
+    if (!lbfgs_ensure_twins(o)) { o->single_pass = false; return false; }
     return true;
 }
 

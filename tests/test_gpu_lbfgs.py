@@ -1137,6 +1137,40 @@ def test_point_ring_turns_into_the_pair_ring_without_changing_a_bit(monkeypatch)
         assert np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i - 1])
 
 
+@pytest.mark.parametrize("n", [4100, 4099])
+def test_decorators_changed_between_steps_turn_the_point_ring_into_pairs_under_the_old_set(n):
+    """The passes recompute every stored point's gradient under the decorators the ring was created with (ring_dec).  This
+    build lets a problem handle's decorators be changed between steps (dzo_problem_set_l2 ...): the stored pairs
+    y_i = g_i - g_i+1 must stay what they were -- gradients under the OLD set -- so the ring is turned into pairs before
+    the new set takes effect, and the step continues exactly as the oracle does from the same fields with the new set."""
+    m = 5
+    x0 = orc.rosenbrock_chain_x0(n)
+    dev_p = dzo.Problem(dzo.ROSENBROCK_CHAIN, n, l2=0.01)
+    opt = dzo.LBFGSOptimizer(None, dev_p, None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    for _ in range(m + 3):
+        opt.step()
+    assert opt.ring_layout == 2
+    x, g, f = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value
+    S = np.stack([h.to_host() for h in opt.delta_point_history]); Y = np.stack([h.to_host() for h in opt.delta_gradient_history])
+    rho, its = opt.rho_history.copy(), opt.iteration_count
+    assert np.array_equal(g, orc.Problem(orc.ROSENBROCK_CHAIN, n, l2=0.01).grad(x))              # (gradient under the old set)
+    dzo._check(dzo.lib().dzo_problem_set_l2(dev_p.h, 0.03))
+    dzo._check(dzo.lib().dzo_problem_set_box_gradient(dev_p.h, 1, -1.5, 1.5))
+    new_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, l2=0.03, box_gradient=(-1.5, 1.5))
+    ref = orc.LBFGS(new_p, x0.copy(), 1.0, m)
+    ref.install_state(x, g, f, S, Y, rho, its)
+    opt.step(); ref.step()
+    assert opt.ring_layout in (0, 1)                      # pairs (slabs when n is ragged)
+    assert opt.last_trials == ref.last_trials and opt.iteration_count == ref.iteration_count
+    assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION
+    x1 = opt.current_point.to_host()
+    assert rel(x1, ref.current_point) <= 1e-12
+    assert np.array_equal(opt.current_gradient.to_host(), new_p.grad(x1))                          # the new set from here on
+    for i in range(1, opt.history_count):                 # the stored pairs are the old ones, bit for bit
+        assert np.array_equal(opt.delta_point_history[i].to_host(), S[i - 1])
+        assert np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i - 1])
+
+
 @pytest.mark.parametrize("dtype,n", [(np.float64, 4099), (np.float32, 4097), (np.float32, 4098), (np.float32, 100_003)])
 def test_ragged_point_ring_continues_on_the_slabs_when_it_leaves_the_points(dtype, n):
     """A ragged n lives on the tile ring as a POINT ring only (phantom padding in the last vector); what the passes do
