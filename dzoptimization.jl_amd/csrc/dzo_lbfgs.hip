@@ -158,8 +158,10 @@ struct dzo_lbfgs_s {
     // were in force when those gradients were first formed.  A change on the user's problem handle (this build lets
     // them be changed between steps) therefore turns the ring into the pair ring under the OLD set (lbfgs_step).
     dzo::RingDecor ring_dec;
-    int ring_obj = 0;               // the chained objective the passes recompute (ChainObj: 0 Rosenbrock, 1 chained quadratic) ...
+    int ring_obj = 0;               // the objective the passes recompute (ChainObj: 0 Rosenbrock, 1 chained quadratic; 2: log-sum-exp, its own kernels) ...
     double ring_obj_lambda = 0;     // ... and its parameter
+    double *pscal = nullptr;        // log-sum-exp: [nslots][2] max / sum exp of the point in each slot (device)
+    const void *lse_c = nullptr;    // ... the caller's centre vector (its tiles live in ring slot `nslots`)
     // The caller's arrays ARE current_point / current_gradient (:393): what the host writes into them between two
     // steps must be what the next step starts from.  On the point ring they are copies of point 0, so whenever the
     // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
@@ -1700,6 +1702,274 @@ __global__ __launch_bounds__(kBlock, (SETS == 1 ? 2 : 1)) void lbfgs_point_pass_
     if ((p.debug_skip & 1024) && blockIdx.x < 1024) { if (lane == 0) g_dev_wave_times[(blockIdx.x * kWaves + wave) * 2 + 1] = wall_clock64(); }
 }
 
+// ============================================================================ log-sum-exp on the point ring (round 4)
+// f = log sum exp(x) + lambda/2 |x - c|^2 (BASELINE configs[3]), g = softmax(x) + lambda (x - c): elementwise GIVEN two
+// global scalars of the point (max, sum exp).  The k + 1 stored points carry theirs (pscal, by slot); the trial point's
+// exist only when a pass over it has ended, so the dots of the next two-loop cannot ride in the pass that forms the trial
+// point.  A step therefore is TWO passes over the POINT ring:
+//   lse_trial_kernel   k + 1 points + c -> gradients in registers, d (:438-449), the trial point (its tiles into the spare
+//                      slot), and per block: max(x_new), sum exp(x_new - max_0), sum (x_new - c)^2, the change flag (:128)
+//   lse_decide_kernel  one block: the trial point's scalars, f_new, the decision of :128 / :139
+//   lse_dots_kernel    (accepted) k + 2 points + c -> the gradients again, pairs by subtraction, the 5 (k_next) dot products
+//                      of the NEXT two-loop in the point pass's layout (gram_reduce_kernel / gram_finish_kernel take over)
+// (2k + 5) n T of traffic against the pair path's (4k + 18) n T, for 2 (k + 1) exponentials per element.  Per element the
+// arithmetic is lse_grad_kernel's (dzo_problems.hip); the sum of exponentials of an accepted point is carried RELATIVE to
+// the previous point's maximum and rescaled on the scalars (softmax is shift-invariant; the two forms differ by roundings).
+// No stencil: the halo positions of a tile are neither read nor written here.
+constexpr int kLseMaxK = 24;
+template <typename T> struct LseParams {
+    int64_t n;
+    int k, k_next;
+    T t;
+    T *ring;
+    uint32_t rowbytes;
+    uint32_t soff[kLseMaxK + 1];               // point j (0 = current) -> byte offset of its x tile within a row (beyond k: point k)
+    uint32_t new_off, c_off;                   // the spare slot's x tile; the tiles of c
+    uint8_t slot[kLseMaxK + 1];                // point j -> ring slot (for pscal)
+    uint8_t new_slot;
+    double *pscal;                             // [slots][2]: max, sum exp(x - max) of the point in each slot
+    double lambda;
+    const double *alpha, *coef, *scale;
+    T *d;                                      // step_direction (contiguous, padded): read by the first step, written when store_d
+    int store_d, store_tile;
+    double *partials;                          // trial pass: [3][grid] max / sum exp / sum squares
+    int32_t *changed;
+    double *gram_partials;                     // dots pass: [kGramValues * k_next][grid]
+    double f_cur;                              // decide
+};
+
+template <typename T> __device__ __forceinline__ T lse_grad_elem(T x, T c, T mxT, double se, double lambda) {
+    const double sm = exp((double)(x - mxT)) / se;            // lse_grad_kernel's expression
+    return (T)(sm + lambda * (double)(x - c));
+}
+
+// (The history length is a RUN-TIME loop count here: a point's tile is requested where the recurrence needs it -- the second
+// loop re-reads the tiles the first one used, out of the cache, 1 KiB per wave and point -- so the kernel holds two tiles
+// at a time instead of k + 1; with all of them in registers the inlined exponentials of k + 1 gradients pushed the fp64
+// K = 24 and fp32 K = 20 instantiations past 512 registers.)
+template <typename T, bool FIRST>
+__global__ __launch_bounds__(kBlock, 2) void lse_trial_kernel(LseParams<T> p) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ T a_s[kLseMaxK], c_s[kLseMaxK], mx_s[kLseMaxK + 1];
+    __shared__ double se_s[kLseMaxK + 1];
+    __shared__ uint32_t off_s[kLseMaxK + 1];
+    __shared__ double lds[kWaves];
+    __shared__ int lds_flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = p.k;
+    if ((int)threadIdx.x < k) {
+        a_s[threadIdx.x] = (T)(-p.alpha[threadIdx.x]);
+        c_s[threadIdx.x] = (T)(-p.coef[threadIdx.x]);
+    }
+    if ((int)threadIdx.x <= k) {
+        const int sl = p.slot[threadIdx.x];
+        mx_s[threadIdx.x] = (T)p.pscal[2 * sl];
+        se_s[threadIdx.x] = p.pscal[2 * sl + 1];
+        off_s[threadIdx.x] = p.soff[threadIdx.x];
+    }
+    __syncthreads();
+    const bool scaled = k > 0;
+    const T scale = scaled ? (T)p.scale[0] : (T)1;
+    const int64_t nvec = (p.n + N - 1) / N;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    const uint32_t toff = (uint32_t)lane * 16u;
+    double mx_loc = -1.7976931348623157e308, se_loc = 0, sq_loc = 0;
+    bool diff = false;
+    for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < rows; row += (int64_t)gridDim.x * kWaves) {
+        const int64_t v = row * kRowOwn - kRowLead + lane;
+        const bool owner = v >= 0 && v < nvec && lane >= kRowLead && lane < kRowLead + kRowOwn;
+        char *rb = reinterpret_cast<char *>(p.ring) + (uint64_t)row * p.rowbytes;
+        auto tile = [&](int j, T (&dst)[N]) { load16(reinterpret_cast<const T *>(rb + off_s[j] + toff), dst); };
+        T cv[N], x0v[N];
+        load16_nt(reinterpret_cast<const T *>(rb + p.c_off + toff), cv);
+        tile(0, x0v);
+        const int64_t e0 = v * N;
+        T q[N];
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) q[e] = (owner && e0 + e < p.n) ? p.d[e0 + e] : (T)0;    // :463 the constructor's direction
+        } else {
+            T gprev[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) { gprev[e] = lse_grad_elem<T>(x0v[e], cv[e], mx_s[0], se_s[0], p.lambda); q[e] = gprev[e]; }   // :438
+            for (int i = 0; i < k; ++i) {                     // :439-442
+                T xb[N];
+                tile(i + 1, xb);
+                const T a = a_s[i];
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const T gi1 = lse_grad_elem<T>(xb[e], cv[e], mx_s[i + 1], se_s[i + 1], p.lambda);
+                    q[e] = dfma(a, gprev[e] - gi1, q[e]);
+                    gprev[e] = gi1;
+                }
+            }
+            if (scaled) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) q[e] = scale * q[e];                              // :443-445
+            }
+            T xhi[N];
+            tile(k, xhi);
+            for (int i = k - 1; i >= 0; --i) {                // :446-449
+                T xlo[N];
+                tile(i, xlo);
+                const T c = c_s[i];
+#pragma unroll
+                for (int e = 0; e < N; ++e) { q[e] = dfma(c, xlo[e] - xhi[e], q[e]); xhi[e] = xlo[e]; }
+            }
+        }
+        T xn[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const bool real = owner && e0 + e < p.n;
+            xn[e] = real ? dfma(p.t, q[e], x0v[e]) : (T)0;                                    // :124 (the padding of a ragged n stays +0)
+            if (real) {
+                diff |= !is_equal(xn[e], x0v[e]);                                             // :128
+                mx_loc = fmax(mx_loc, (double)xn[e]);
+                se_loc += exp((double)(xn[e] - mx_s[0]));                                     // relative to the CURRENT point's maximum
+                const T dlt = xn[e] - cv[e];
+                sq_loc = __builtin_fma((double)dlt, (double)dlt, sq_loc);
+            }
+        }
+        if (owner) {
+            if (p.store_tile) store16(reinterpret_cast<T *>(rb + p.new_off + toff), xn);
+            if (p.store_d && !FIRST) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) if (e0 + e < p.n) p.d[e0 + e] = q[e];
+            }
+        }
+    }
+    // per block: max, sum exp, sum of squares
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx_loc = fmax(mx_loc, __shfl_xor(mx_loc, off, 64));
+    if (lane == 0) lds[wave] = mx_loc;
+    __syncthreads();
+    double bmx = lds[0];
+    for (int w = 1; w < kWaves; ++w) bmx = fmax(bmx, lds[w]);
+    __syncthreads();
+    const double bse = block_sum(se_loc, lds);
+    const double bsq = block_sum(sq_loc, lds);
+    if (threadIdx.x == 0) { p.partials[blockIdx.x] = bmx; p.partials[gridDim.x + blockIdx.x] = bse; p.partials[2 * gridDim.x + blockIdx.x] = bsq; }
+    block_raise_flag(diff, p.changed, &lds_flag);
+}
+
+// the trial point's scalars, f_new = max + log(sum exp) + lambda/2 |x - c|^2 (lse_finish_kernel's expression) and the decision
+__global__ __launch_bounds__(kBlock) void lse_decide_kernel(const double *__restrict__ partials, int grid, double *__restrict__ pscal,
+                                                            int cur_slot, int new_slot, double lambda, int cur_is_f32, DecideArgs dec) {
+    __shared__ double lds[kWaves];
+    double mx = -1.7976931348623157e308;
+    for (int i = threadIdx.x; i < grid; i += kBlock) mx = fmax(mx, partials[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    double mx_new = lds[0];
+    for (int w = 1; w < kWaves; ++w) mx_new = fmax(mx_new, lds[w]);
+    __syncthreads();
+    const double se_rel = reduce_partials_all(partials + grid, grid, lds);
+    const double sq = reduce_partials_all(partials + 2 * grid, grid, lds);
+    // (the exponentials were taken relative to the current point's maximum as the kernels see it, i.e. rounded to T)
+    const double mx_cur = cur_is_f32 ? (double)(float)pscal[2 * cur_slot] : pscal[2 * cur_slot];
+    const double se_new = se_rel * exp(mx_cur - mx_new);
+    if (threadIdx.x == 0) {
+        pscal[2 * new_slot] = mx_new; pscal[2 * new_slot + 1] = se_new;
+        // no decrease can be claimed from a sum that left the range of exp (a trial point hundreds of units away): NaN fails :139
+        const bool usable = se_rel > 0.0 && se_new > 0.0 && se_new < 1.7976931348623157e308;
+        dec.result[0] = usable ? mx_new + log(se_new) + 0.5 * lambda * sq : __builtin_nan("");
+    }
+    __syncthreads();
+    decide_body(dec, lds);
+}
+
+// the dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1), point pass layout of the partials
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock, (sizeof(T) * (K + 2) <= 100 ? 2 : 1)) void lse_dots_kernel(LseParams<T> p) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ T mx_s[kLseMaxK + 2];
+    __shared__ double se_s[kLseMaxK + 2];
+    __shared__ double wacc[kWaves][kFusedMaxK + 1][kGramValues];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kn = p.k_next;
+    if (threadIdx.x <= K) {
+        const int sl = p.slot[threadIdx.x];
+        mx_s[threadIdx.x + 1] = (T)p.pscal[2 * sl];
+        se_s[threadIdx.x + 1] = p.pscal[2 * sl + 1];
+    }
+    if (threadIdx.x == 0) { mx_s[0] = (T)p.pscal[2 * p.new_slot]; se_s[0] = p.pscal[2 * p.new_slot + 1]; }
+    __syncthreads();
+    const int64_t nvec = (p.n + N - 1) / N;
+    const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
+    const uint32_t toff = (uint32_t)lane * 16u;
+    TreeSum<kGramValues * (K + 1)> dots;
+    dots.init();
+    for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < rows; row += (int64_t)gridDim.x * kWaves) {
+        const int64_t v = row * kRowOwn - kRowLead + lane;
+        const bool owner = v >= 0 && v < nvec && lane >= kRowLead && lane < kRowLead + kRowOwn;
+        char *rb = reinterpret_cast<char *>(p.ring) + (uint64_t)row * p.rowbytes;
+        const int64_t e0 = v * N;
+        T cv[N], xn[N], xa[N], ga[N];
+        load16_nt(reinterpret_cast<const T *>(rb + p.c_off + toff), cv);
+        load16(reinterpret_cast<const T *>(rb + p.new_off + toff), xn);
+        load16_nt(reinterpret_cast<const T *>(rb + p.soff[0] + toff), xa);
+        T gn[N], sn[N], yn[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const bool real = owner && e0 + e < p.n;
+            gn[e] = real ? lse_grad_elem<T>(xn[e], cv[e], mx_s[0], se_s[0], p.lambda) : (T)0;
+            ga[e] = real ? lse_grad_elem<T>(xa[e], cv[e], mx_s[1], se_s[1], p.lambda) : (T)0;
+            sn[e] = real ? xn[e] - xa[e] : (T)0;                                              // :145
+            yn[e] = real ? gn[e] - ga[e] : (T)0;                                              // :478-480
+        }
+        {
+            double t5[kGramValues] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const double sx = (double)sn[e], yx = (double)yn[e], gx = (double)gn[e];
+                t5[0] = __builtin_fma(sx, gx, t5[0]); t5[1] = __builtin_fma(yx, gx, t5[1]); t5[2] = __builtin_fma(yx, yx, t5[2]);
+                t5[3] = __builtin_fma(yx, sx, t5[3]); t5[4] = __builtin_fma(sx, yx, t5[4]);
+            }
+            dots.template push<0>(t5[0], lane); dots.template push<1>(t5[1], lane); dots.template push<2>(t5[2], lane);
+            dots.template push<3>(t5[3], lane); dots.template push<4>(t5[4], lane);
+        }
+        auto pair_dots = [&](auto ic) {                       // old pair i = point i - point i + 1 (xa / ga hold point i)
+            constexpr int i = decltype(ic)::value;
+            T xb[N], gb[N];
+            load16_nt(reinterpret_cast<const T *>(rb + p.soff[i + 1] + toff), xb);
+            double t5[kGramValues] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const bool real = owner && e0 + e < p.n;
+                gb[e] = real ? lse_grad_elem<T>(xb[e], cv[e], mx_s[i + 2], se_s[i + 2], p.lambda) : (T)0;
+                const double sx = real ? (double)(xa[e] - xb[e]) : 0.0, yx = real ? (double)(ga[e] - gb[e]) : 0.0;
+                t5[0] = __builtin_fma(sx, (double)gn[e], t5[0]); t5[1] = __builtin_fma(yx, (double)gn[e], t5[1]);
+                t5[2] = __builtin_fma(yx, (double)yn[e], t5[2]); t5[3] = __builtin_fma(yx, (double)sn[e], t5[3]);
+                t5[4] = __builtin_fma(sx, (double)yn[e], t5[4]);
+            }
+#pragma unroll
+            for (int e = 0; e < N; ++e) { xa[e] = xb[e]; ga[e] = gb[e]; }
+            constexpr int v0 = kGramValues * (i + 1);
+            dots.template push<v0 + 0>(t5[0], lane); dots.template push<v0 + 1>(t5[1], lane); dots.template push<v0 + 2>(t5[2], lane);
+            dots.template push<v0 + 3>(t5[3], lane); dots.template push<v0 + 4>(t5[4], lane);
+        };
+        static_for<K>(pair_dots);
+        dots.finish_row(lane);
+    }
+    {
+        double *wflat = &wacc[0][0][0];
+        constexpr int kValues = kGramValues * (K + 1);
+#pragma unroll
+        for (int g = 0; g < TreeSum<kValues>::kGroups; ++g) {
+            const int v = TreeSum<kValues>::value_of(g, lane);
+            if (v < kValues) wflat[wave * (kGramValues * (kFusedMaxK + 1)) + v] = dots.acc[g];
+        }
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < kGramValues * kn; v += kBlock) {
+        const double *wflat = &wacc[0][0][0];
+        constexpr int ws = kGramValues * (kFusedMaxK + 1);
+        p.gram_partials[(int64_t)v * gridDim.x + blockIdx.x] = (wflat[v] + wflat[ws + v]) + (wflat[2 * ws + v] + wflat[3 * ws + v]);
+    }
+}
+
 // Ragged n on the tile ring: a vector length that is not a multiple of the 16-byte vector gets a last vector padded with
 // PHANTOM elements.  They are +0 in every point of the ring and stay +0: their stencil coefficients are all zero
 // (rosen_coef), so their gradient is +0, their direction +-0 and their trial point fma(t, +-0, +0) = +0; they add exact
@@ -1740,7 +2010,8 @@ __global__ __launch_bounds__(kBlock) void ring_diff_kernel(int64_t rows, T *__re
 // halo copies included, evaluates rosen_grad_elem on its vector -- the bits the pass had in registers
 template <typename T>
 __global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t nvec, const T *__restrict__ xs, T *__restrict__ gs, int64_t rowbytes,
-                                                             PointDecor<T> dec, int dec_on, int obj, T obj_lambda) {
+                                                             PointDecor<T> dec, int dec_on, int obj, T obj_lambda,
+                                                             const T *__restrict__ cs = nullptr, const double *__restrict__ pscal2 = nullptr, double lse_lambda = 0) {
     constexpr int N = Vec16<T>::N;
     const int64_t rows = (nvec + kRowOwn - 1) / kRowOwn;
     for (int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x; id < rows * 64; id += (int64_t)gridDim.x * kBlock) {
@@ -1750,6 +2021,16 @@ __global__ __launch_bounds__(kBlock) void ring_regrad_kernel(int64_t n, int64_t 
         if (v < 0 || v >= nvec) continue;
         T x[N], g[N];
         load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(xs) + row * rowbytes + pos * 16), x);
+        if (obj == 2) {                                   // log-sum-exp: elementwise given the point's two scalars (lse_grad_elem)
+            T cvv[N];
+            load16(reinterpret_cast<const T *>(reinterpret_cast<const char *>(cs) + row * rowbytes + pos * 16), cvv);
+            const T mxT = (T)pscal2[0];
+            const double se = pscal2[1];
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] = v * N + e < n ? lse_grad_elem<T>(x[e], cvv[e], mxT, se, lse_lambda) : (T)0;
+            store16(reinterpret_cast<T *>(reinterpret_cast<char *>(gs) + row * rowbytes + pos * 16), g);
+            continue;
+        }
         const T xl = v > 0 ? hist_ptr<true>(xs, v - 1, rowbytes)[N - 1] : (T)0;
         const T xr = v + 1 < nvec ? hist_ptr<true>(xs, v + 1, rowbytes)[0] : (T)0;
 #pragma unroll
@@ -2299,7 +2580,7 @@ static inline RingDecor ring_decor_of(const dzo_problem_s *p) {
 // the chained objectives the point pass serves (ChainObj): -1 = none of them
 static inline int ring_obj_of(const dzo_problem_s *p) {
     if (!p) return -1;
-    return p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN ? 0 : (p->kind == DZO_PROBLEM_QUADRATIC_CHAIN ? 1 : -1);
+    return p->kind == DZO_PROBLEM_ROSENBROCK_CHAIN ? 0 : (p->kind == DZO_PROBLEM_QUADRATIC_CHAIN ? 1 : (p->kind == DZO_PROBLEM_LSE ? 2 : -1));
 }
 // vectors of 16 bytes a ring stream holds: the last one is padded with phantom elements when n is ragged (see load_vec_tail)
 template <typename T> static inline int64_t ring_nvec(const dzo_lbfgs_s *o) { return (o->core.n + Vec16<T>::N - 1) / Vec16<T>::N; }
@@ -2337,7 +2618,8 @@ static int32_t lbfgs_ensure_g(dzo_lbfgs_s *o, int slot) {
     const int grid = stream_grid(o->ring_rows * 64, 1);
     DZO_DISPATCH(c.dtype, hipLaunchKernelGGL(ring_regrad_kernel<T>, dim3(grid), dim3(kBlock), 0, c.stream, c.n, ring_nvec<T>(o),
                                              (const T *)o->s_slot_v(slot), (T *)o->y_slot_v(slot), o->rowbytes, point_decor<T>(o->ring_dec), o->ring_dec.any() ? 1 : 0,
-                                             o->ring_obj, (T)o->ring_obj_lambda));
+                                             o->ring_obj, (T)o->ring_obj_lambda, (const T *)(o->ring_obj == 2 ? o->s_slot_v(o->nslots) : nullptr),
+                                             (const double *)(o->pscal ? o->pscal + 2 * slot : nullptr), o->ring_obj_lambda));
     DZO_HIP(hipGetLastError());
     o->g_valid |= 1u << slot;
     return DZO_OK;
@@ -2733,7 +3015,8 @@ static bool points_ok(dzo_lbfgs_s *o) {
     if (c.objective || c.gradient || c.constraint || !o->speculate || !o->fused_post || !c.problem) return false;
     // (the decorators of legacy :219-296 ride on the pass: its DEC instantiations, under the set the ring was stored with)
     if (ring_obj_of(c.problem) != o->ring_obj || !(ring_decor_of(c.problem) == o->ring_dec)) return false;
-    if (o->ring_obj == 1 && (o->ring_dec.any() || c.problem->lambda != o->ring_obj_lambda)) return false;   // (no DEC instantiations of that objective)
+    if (o->ring_obj >= 1 && (o->ring_dec.any() || c.problem->lambda != o->ring_obj_lambda)) return false;   // (no DEC instantiations of those objectives)
+    if (o->ring_obj == 2 && c.problem->c != o->lse_c) return false;
     if (o->k > point_max_k(c.dtype) || o->m > point_max_k(c.dtype) || !al16v(o->d)) return false;
     if (o->k > 0 && !o->spec_scalars) return false;       // (the scalars come from the previous pass; anything else goes through Gram passes)
     return true;
@@ -3022,9 +3305,11 @@ template <typename T> static int32_t lbfgs_materialize_d_t(dzo_lbfgs_s *o) {
     o->d_stale = false;
     return DZO_OK;
 }
+template <typename T> static int32_t lbfgs_materialize_d_lse(dzo_lbfgs_s *o);
 static int32_t lbfgs_materialize_d(dzo_lbfgs_s *o) {
     if (!o->points || !o->d_stale) return DZO_OK;
     std::lock_guard<std::recursive_mutex> lk(o->mu);
+    if (o->ring_obj == 2) { DZO_DISPATCH(o->core.dtype, return lbfgs_materialize_d_lse<T>(o)); }
     DZO_DISPATCH(o->core.dtype, return lbfgs_materialize_d_t<T>(o));
 }
 
@@ -3193,6 +3478,163 @@ template <typename T> static int32_t lbfgs_step_points(dzo_lbfgs_s *o) {
     }
 }
 
+// ---- step! on the point ring for the log-sum-exp objective (lse_trial_kernel / lse_decide_kernel / lse_dots_kernel)
+template <typename T> static void lse_fill_params(dzo_lbfgs_s *o, LseParams<T> &lp, int k, int view_newest) {
+    OptCore &c = o->core;
+    memset(&lp, 0, sizeof(lp));
+    auto slot_at = [&](int j) { return ((view_newest - j) % o->nslots + o->nslots) % o->nslots; };
+    lp.n = c.n; lp.k = k; lp.k_next = k < o->m ? k + 1 : o->m;
+    lp.ring = (T *)o->S; lp.rowbytes = (uint32_t)o->rowbytes;
+    for (int j = 0; j <= kLseMaxK; ++j) {
+        const int sl = slot_at(j < k ? j : k);
+        lp.soff[j] = (uint32_t)((uint64_t)(2 * sl) * (uint64_t)o->tile_stride);
+        lp.slot[j] = (uint8_t)sl;
+    }
+    lp.c_off = (uint32_t)((uint64_t)(2 * o->nslots) * (uint64_t)o->tile_stride);
+    lp.pscal = o->pscal; lp.lambda = o->ring_obj_lambda;
+    lp.alpha = o->alpha; lp.coef = o->coef; lp.scale = o->scale;
+    lp.d = (T *)o->d;
+    lp.partials = c.problem->scratch;
+    lp.changed = c.flag();
+    lp.gram_partials = o->gram_partials;
+}
+template <typename T> static void (*lse_trial_kernel_for(dzo_lbfgs_s *o, bool first))(LseParams<T>) {
+    (void)o;
+    return first ? lse_trial_kernel<T, true> : lse_trial_kernel<T, false>;
+}
+template <typename T> static void (*lse_dots_kernel_for(dzo_lbfgs_s *o))(LseParams<T>) {
+    if constexpr (sizeof(T) == 8) { if (o->m > 20) return lse_dots_kernel<T, 24>; }
+    return o->m <= 8 ? lse_dots_kernel<T, 8> : o->m <= 12 ? lse_dots_kernel<T, 12> : lse_dots_kernel<T, 20>;
+}
+template <typename T> static int lse_grid(dzo_lbfgs_s *o, const void *kern) {
+    const int64_t rows = o->ring_rows;
+    int64_t blocks = (rows + kWaves - 1) / kWaves;
+    const int64_t res = (int64_t)ctx().cus * resident_blocks(kern);
+    if (blocks > res) blocks = res;
+    if (blocks > (int64_t)o->gram_grid * kWaves) blocks = (int64_t)o->gram_grid * kWaves;
+    if (blocks > kMaxPartialBlocks / 2) blocks = kMaxPartialBlocks / 2;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// step_direction of the last step on demand (as lbfgs_materialize_d_t): the trial pass over the view that step started from,
+// writing d and nothing else
+template <typename T> static int32_t lbfgs_materialize_d_lse(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    LseParams<T> lp;
+    lse_fill_params<T>(o, lp, o->dview_k, o->dview_newest);
+    lp.t = (T)1; lp.store_d = 1; lp.store_tile = 0;
+    lp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); lp.new_slot = (uint8_t)o->spare();
+    auto kern = lse_trial_kernel_for<T>(o, false);
+    const int grid = lse_grid<T>(o, (const void *)kern);
+    {
+        DZO_TIMED("lbfgs_direction_on_demand", c.stream);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, c.stream, lp);
+    }
+    DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), c.stream));
+    c.flag_armed = true;
+    DZO_HIP(hipGetLastError());
+    o->d_stale = false;
+    return DZO_OK;
+}
+
+template <typename T> static int32_t lbfgs_step_points_lse(dzo_lbfgs_s *o) {
+    OptCore &c = o->core;
+    hipStream_t s = c.stream;
+    const int k = o->k;
+    if (k > 0) {
+        DZO_TRY(gram_scalars<T>(o));                      // alpha / coef / scale of THIS step (left by the previous step's dots pass)
+        o->scalars_ready = false;
+    }
+    LseParams<T> lp;
+    lse_fill_params<T>(o, lp, k, o->newest);
+    lp.new_off = (uint32_t)((uint64_t)(2 * o->spare()) * (uint64_t)o->tile_stride); lp.new_slot = (uint8_t)o->spare();
+    lp.store_d = (k > 0 && !o->lazy_d) ? 1 : 0; lp.store_tile = 1;
+    auto kern = lse_trial_kernel_for<T>(o, k == 0);
+    const int grid = lse_grid<T>(o, (const void *)kern);
+    o->d_stale = false;
+    const int view_k = k, view_newest = o->newest;
+    auto direction_pending = [&]() { if (k > 0 && o->lazy_d) { o->d_stale = true; o->dview_k = view_k; o->dview_newest = view_newest; } };
+    auto stuck_fields = [&]() -> int32_t {                // delta_point = x_old (:118), delta_gradient still the previous step's
+        if (o->k > 0) {
+            DZO_TRY(lbfgs_ensure_g(o, o->slot_of(0))); DZO_TRY(lbfgs_ensure_g(o, o->slot_of(1)));
+            ring_gather_diff<T>(o, o->y_slot_v(o->slot_of(0)), o->y_slot_v(o->slot_of(1)), o->dg_lin);
+        }
+        ring_gather<T>(o, o->s_slot_v(o->newest), o->dx_lin);
+        DZO_HIP(hipGetLastError());
+        o->lin_stale = false;
+        return DZO_OK;
+    };
+    c.last_trials = 0;
+    o->single_pass_steps += 1;
+    int64_t halvings = 0;
+    double t = 1.0;
+    for (int attempt = 0;; ++attempt) {
+        lp.t = (T)t;
+        if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
+        c.flag_armed = false;
+        {
+            DZO_TIMED(attempt == 0 ? "lbfgs_single_pass" : "lbfgs_single_pass_retry", s);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, lp);
+        }
+        {
+            DZO_TIMED("lbfgs_lse_decide", s);
+            DecideArgs da = decide_args(c, nullptr, 0, 1.0);
+            hipLaunchKernelGGL(lse_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)lp.partials, grid, o->pscal, (int)lp.slot[0], (int)lp.new_slot,
+                               o->ring_obj_lambda, c.dtype == DZO_F32 ? 1 : 0, da);
+            c.flag_armed = true;
+        }
+        DZO_HIP(hipGetLastError());
+        DZO_TRY(core_wait_decision(c));
+        const int32_t status = reinterpret_cast<int32_t *>(c.host + 3)[0];
+        if (status == 2) {                                // :128-131
+            c.is_stuck = true;
+            direction_pending();
+            return stuck_fields();
+        }
+        c.last_trials += 1;
+        if (status == 1) {                                // :139-146; then the dots of the next two-loop over the k + 2 points
+            const double f_new = round_to_dtype(c.dtype, c.host[0]);
+            c.df = round_to_dtype(c.dtype, f_new - c.f);
+            c.f = f_new;
+            auto dk = lse_dots_kernel_for<T>(o);
+            const int dgrid = lse_grid<T>(o, (const void *)dk);
+            {
+                DZO_TIMED("lbfgs_lse_dots", s);
+                hipLaunchKernelGGL(dk, dim3(dgrid), dim3(kBlock), 0, s, lp);
+            }
+            const int sv_newest = o->newest, sv_k = o->k;
+            o->newest = o->spare(); o->k = lp.k_next;     // as lbfgs_finish_push will leave them
+            double *vals = o->gram_partials + (size_t)kGramValues * kMaxHistory * o->gram_grid * kWaves;
+            {
+                DZO_TIMED("lbfgs_gram_reduce", s);
+                hipLaunchKernelGGL(gram_reduce_kernel, dim3(kGramValues * o->k), dim3(kBlock), 0, s, o->gram_partials, dgrid, vals, kGramValues * o->k,
+                                   (const double *)nullptr, 0, (double *)nullptr, 0);
+            }
+            DZO_HIP(hipGetLastError());
+            int32_t rc = gram_finish_launch(o, 0, true, vals, true, c.status());   // (status is 1: the gate only selects the *_sp scalar set)
+            o->newest = sv_newest; o->k = sv_k;
+            DZO_TRY(rc);
+            o->g_valid &= ~(1u << o->spare());            // (the trial pass writes no gradient tiles: formed on demand)
+            DZO_TRY(lbfgs_finish_push(o, 0, true, true, true));
+            o->spec_scalars = true;
+            o->gram_ready = false;
+            o->gram_stale = 0;
+            o->xg_lin_stale = true;
+            direction_pending();
+            lbfgs_mark_unsettled(o);
+            return DZO_OK;
+        }
+        if (attempt == 0) o->single_pass_rejections += 1;
+        t = round_to_dtype(c.dtype, t * 0.5);             // :151-152
+        if (c.max_halvings > 0 && ++halvings >= c.max_halvings) {
+            c.is_stuck = true;
+            direction_pending();
+            return stuck_fields();
+        }
+        o->single_pass_retries += 1;
+    }
+}
+
 // Point ring, before a step: if the host changed current_point / current_gradient since they were last gathered
 // (dzo_memcpy_*, its own kernels through the pointers of get_ptr, the arrays it passed to the constructor), the
 // step must start from the caller's values (:393 aliasing).  The ring keeps its own point 0 for the pairs --
@@ -3231,7 +3673,10 @@ static int32_t lbfgs_step(dzo_lbfgs_s *o) {
     o->last_step_kind = 0;
     DZO_TRY(lbfgs_adopt_host_writes(o));
     if (o->points) {
-        if (points_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_points<T>(o)); }
+        if (points_ok(o)) {
+            if (o->ring_obj == 2) { DZO_DISPATCH(c.dtype, return lbfgs_step_points_lse<T>(o)); }
+            DZO_DISPATCH(c.dtype, return lbfgs_step_points<T>(o));
+        }
         DZO_TRY(lbfgs_leave_points(o));                   // an option the passes do not serve: continue on the pair ring
     }
     if (single_pass_ok(o)) { DZO_DISPATCH(c.dtype, return lbfgs_step_single_pass<T>(o)); }
@@ -3323,13 +3768,14 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         o->ring_rows = (nvec + kRowOwn - 1) / kRowOwn;
         {
             const int64_t stream_bytes = ((o->ring_rows * kTileBytes + 1023) / 1024 | 1) * 1024;   // an odd number of KiB (HBM channel skew)
-            const uint64_t total = (uint64_t)2 * m1 * (uint64_t)stream_bytes;
+            const int ms = m1 + (o->ring_obj == 2 ? 1 : 0);      // (log-sum-exp: slot m1 holds the tiles of the centre vector c)
+            const uint64_t total = (uint64_t)2 * ms * (uint64_t)stream_bytes;
             // (few streams: the whole wave-row of a tile-major ring sits in a handful of DRAM pages and its reads win --
             // n = 1e7: m = 5 pass 234 us tile-major / 253 us stream-major, m = 10 398 / 383, m = 20 684 / 660)
             if (tune("DZO_TUNE_STREAM_MAJOR", o->m >= 9 ? 1 : 0) != 0 && total + (1u << 20) < (1ull << 32)) {      // 32-bit byte offsets in the passes
                 o->tile_stride = stream_bytes; o->rowbytes = kTileBytes; o->ring_bytes = (size_t)total;
             } else {
-                o->tile_stride = kTileBytes; o->rowbytes = (int64_t)2 * m1 * kTileBytes;
+                o->tile_stride = kTileBytes; o->rowbytes = (int64_t)2 * ms * kTileBytes;
                 o->ring_bytes = (size_t)o->ring_rows * (size_t)o->rowbytes;
             }
         }
@@ -3371,7 +3817,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
         const int64_t tiles = (n / (16 / (int64_t)es) + tile_v - 1) / tile_v;
         if (tiles < o->gram_grid) o->gram_grid = (int)(tiles > 0 ? tiles : 1);
     }
-    const size_t nscal = 2 + 2 + (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
+    const size_t nscal = 2 + 2 + 2 * ((size_t)m1 + 2) + (size_t)m1 + 3 * kMaxHistory + 8 + 2 * (size_t)m1 * m1 + 2 * kMaxHistory + (2 * kMaxHistory + 8) +
                          (size_t)kGramValues * kMaxHistory * (o->gram_grid * kWaves + 1) + 4 * (size_t)kMaxPartialBlocks;
     double *base = nullptr;
     ALLOC(base, nscal * sizeof(double));
@@ -3380,6 +3826,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     (void)hipDeviceSynchronize();
     o->gram_ticket = reinterpret_cast<unsigned int *>(base); base += 2;   // (zeroed with the rest; re-armed by the kernel)
     o->xg_differs = reinterpret_cast<int32_t *>(base); base += 2;
+    o->pscal = base; base += 2 * ((size_t)m1 + 2);
     o->rho = base; base += m1;
     o->alpha = base; base += kMaxHistory;
     o->coef = base; base += kMaxHistory;
@@ -3492,15 +3939,28 @@ int32_t dzo_lbfgs_create_problem(dzo_problem_t problem, int32_t history_length, 
     DZO_HIP(hipMalloc(&g, (size_t)((problem->n + 63) / 64 * 64) * dtype_size(problem->dtype)));
     int32_t rc = dzo_problem_grad(problem, g, x_dev);     // :421
     // the single-pass step will apply (built-in chained Rosenbrock, no decorators): tile-major history ring
+    const bool lse_points = problem->kind == DZO_PROBLEM_LSE && !ring_decor_of(problem).any() && ((uintptr_t)problem->c & 15u) == 0 &&
+                            tune("DZO_TUNE_LSE_POINTS", 1) != 0;
     tl_want_blocked = (problem->kind == DZO_PROBLEM_ROSENBROCK_CHAIN ||
-                       (problem->kind == DZO_PROBLEM_QUADRATIC_CHAIN && !ring_decor_of(problem).any())) && (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
+                       (problem->kind == DZO_PROBLEM_QUADRATIC_CHAIN && !ring_decor_of(problem).any()) || lse_points) && (((uintptr_t)x_dev | (uintptr_t)g) & 15u) == 0;
     tl_ring_dec = ring_decor_of(problem);
-    tl_ring_obj = ring_obj_of(problem) == 1 ? 1 : 0; tl_ring_obj_lambda = problem->lambda;
+    tl_ring_obj = ring_obj_of(problem) >= 1 ? ring_obj_of(problem) : 0; tl_ring_obj_lambda = problem->lambda;
     if (rc == DZO_OK) rc = dzo_lbfgs_create(problem->n, history_length, problem->dtype, x_dev, g, f0, initial_step_length, out);
     tl_want_blocked = false;
     tl_ring_dec = RingDecor(); tl_ring_obj = 0; tl_ring_obj_lambda = 0;
     if (rc != DZO_OK) { (void)hipFree(g); return rc; }
     (*out)->core.owns_g = true;
+    if ((*out)->ring_obj == 2 && (*out)->points) {
+        // log-sum-exp on the point ring: the centre vector's tiles, and the start point's two scalars as dzo_problem_grad
+        // just left them in the handle's workspace (lse_finish_max_kernel / lse_finish_kernel: [max], [f, sum exp])
+        dzo_lbfgs_s *o = *out;
+        o->lse_c = problem->c;
+        DZO_DISPATCH(o->core.dtype, ring_scatter<T>(o, problem->c, o->s_slot_v(o->nslots)));
+        const double *ws = problem->scratch + 2 * kMaxPartialBlocks;
+        DZO_HIP(hipMemcpyAsync(o->pscal + 2 * o->newest, ws, sizeof(double), hipMemcpyDeviceToDevice, o->core.stream));
+        DZO_HIP(hipMemcpyAsync(o->pscal + 2 * o->newest + 1, ws + 3, sizeof(double), hipMemcpyDeviceToDevice, o->core.stream));
+        DZO_HIP(hipStreamSynchronize(o->core.stream));
+    }
     rc = problem_view_create(problem, &(*out)->core.problem);    // private partial-sum workspace per optimizer
     if (rc != DZO_OK) { dzo_lbfgs_destroy(*out); *out = nullptr; return rc; }
     (*out)->core.box_on = problem->cons_on; (*out)->core.box_lo = problem->cons_lo; (*out)->core.box_hi = problem->cons_hi;

@@ -1037,6 +1037,20 @@ def test_chained_quadratic_point_ring_steps_match_the_oracle_from_the_same_state
     _point_ring_steps_against_the_oracle(n, m, step0, dtype, {}, kind="qchain")
 
 
+_LSE_CASES = [(n, m, s0, dt) for dt in (np.float64, np.float32)
+              for n, m, s0 in [(16, 3, 1.0), (385, 5, 1.0), (4100, 10, 1.0), (4099, 20, 1.0), (100_004, 10, 1.0), (4100, 6, 300.0), (4100, 23, 1.0)]
+              if not (dt == np.float32 and m > 20)]
+
+
+@pytest.mark.parametrize("n,m,step0,dtype", _LSE_CASES, ids=[f"{np.dtype(dt).name}-n{n}-m{m}-{s0}" for n, m, s0, dt in _LSE_CASES])
+def test_log_sum_exp_point_ring_steps_match_the_oracle_from_the_same_state(n, m, step0, dtype):
+    """BASELINE configs[3]'s objective on the point ring: log sum exp(x) + lambda/2 |x - c|^2 needs two global
+    scalars per point, so its step is a trial pass and a dots pass over the ring of points (lse_trial_kernel / lse_decide_kernel /
+    lse_dots_kernel) instead of one sweep.  Same protocol as the other point-ring cases; the gradient is compared to rounding,
+    not bit for bit (the sum of exponentials of an accepted point is carried relative to the previous point's maximum)."""
+    _point_ring_steps_against_the_oracle(n, m, step0, dtype, {}, kind="lse")
+
+
 def _point_ring_steps_against_the_oracle(n, m, step0, dtype, decor, kind="rosen"):
     """The default optimizer on the built-in chained Rosenbrock keeps the last k + 1 POINTS and GRADIENTS tile-major
     (ring_layout == 2) and forms the pairs in registers; every trial of a step, the first step included, is one pass.
@@ -1048,7 +1062,12 @@ def _point_ring_steps_against_the_oracle(n, m, step0, dtype, decor, kind="rosen"
     if dtype == np.float32:
         orc.set_dot_mode(orc.DOT_WIDE)                    # the device sums in fp64
     try:
-        if kind == "qchain":
+        if kind == "lse":
+            cc = (orc.pcg_fill(n, 6) - 0.5).astype(dtype)                          # c = u - 1/2 (seed 6), lambda = 1e-2
+            x0 = (0.5 * (orc.pcg_fill(n, 8) - 0.5)).astype(dtype)
+            ref_p = orc.Problem(orc.LSE, n, dtype, c=cc, lam=1e-2)
+            dev_p = dzo.Problem(dzo.LSE, n, dtype, c=cc, lam=1e-2)
+        elif kind == "qchain":
             ref_p = orc.Problem(orc.QUADRATIC_CHAIN, n, dtype, lam=0.05)
             dev_p = dzo.Problem(dzo.QUADRATIC_CHAIN, n, dtype, lam=0.05)
         else:
@@ -1063,6 +1082,8 @@ def _point_ring_steps_against_the_oracle(n, m, step0, dtype, decor, kind="rosen"
         box = decor.get("box_constraint")
         f0 = opt.current_objective_value
         for it in range(3 * m + 12):
+            if kind == "lse" and it > 0 and abs(opt.delta_objective_value) <= (1e-13 if dtype == np.float64 else 2e-6) * abs(f0):
+                break        # converged to rounding level
             if kind == "qchain" and opt.current_objective_value <= 1e-12 * f0:
                 break        # converged (a convex quadratic): what is left of the gradient is rounding noise, and so would the comparison be
             k = opt.history_count
@@ -1076,12 +1097,12 @@ def _point_ring_steps_against_the_oracle(n, m, step0, dtype, decor, kind="rosen"
             x_prev, g_prev = x, g
             opt.step(); ref.step()
             assert opt.ring_layout == 2
-            if (decor or kind == "qchain") and opt.is_stuck != ref.is_stuck and min(opt.last_trials, ref.last_trials) > 30:
+            if (decor or kind != "rosen") and opt.is_stuck != ref.is_stuck and min(opt.last_trials, ref.last_trials) > 30:
                 break        # (the same, one side halving on to x + t d == x)
             assert opt.is_stuck == ref.is_stuck, it
             if ref.is_stuck:
                 break
-            if (decor or kind == "qchain") and ref.last_trials > 30 and opt.last_trials != ref.last_trials:
+            if (decor or kind != "rosen") and ref.last_trials > 30 and opt.last_trials != ref.last_trials:
                 break        # dozens of halvings: f_new - f is at rounding level, the two summation orders may accept one trial apart
             assert opt.iteration_count == ref.iteration_count and opt.last_trials == ref.last_trials, it
             seen.add(opt.last_trials)
@@ -1095,6 +1116,11 @@ def _point_ring_steps_against_the_oracle(n, m, step0, dtype, decor, kind="rosen"
             assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-12 if dtype == np.float64 else 1e-5)
             if decor or kind == "qchain":                 # the (decorated) gradient of the new point, elementwise: bit-exact
                 assert np.array_equal(opt.current_gradient.to_host(), ref_p.grad(x_new)), it
+            if kind == "lse":
+                # softmax(x) and lambda (x - c) cancel near the minimiser: the error is measured against the terms, not their difference
+                g_ref = ref_p.grad(x_new).astype(np.float64)
+                terms = np.linalg.norm(1e-2 * (x_new.astype(np.float64) - cc.astype(np.float64))) + np.linalg.norm(g_ref)
+                assert np.linalg.norm(opt.current_gradient.to_host().astype(np.float64) - g_ref) <= (1e-13 if dtype == np.float64 else 1e-5) * terms, it
             if box:
                 assert x_new.min() >= dtype(box[0]) and x_new.max() <= dtype(box[1]), it
         assert opt.single_pass_steps == opt.iteration_count + (1 if opt.is_stuck else 0) or opt.is_stuck
