@@ -785,29 +785,51 @@ def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
     `decorated`  the built-in objective with L2 regularisation + box gradient mask + box projection (legacy :219-296) riding
                  on the point pass (its DEC instantiation);
     `ragged`     n + 1 (not a multiple of the 16-byte vector), phantom-padded point ring;
-    `quadratic_chain`  the point pass's second objective: the chained quadratic (lambda = 1e-4, same start point).
+    `quadratic_chain`  the point pass's second objective: the chained quadratic (lambda = 1e-4, same start point);
+    `lse`        config 4's objective and size as whole step!() calls (log-sum-exp, n = 10^6, m = 10, fp32, x0 = 0): a trial pass and a
+                 dots pass over the ring of points per step; `lse_two_pass` the same with DZO_TUNE_LSE_POINTS=0 (the general path).
     Rate from a stretch without any event record; the per-kernel table from a second, untimed stretch."""
     nn = n + 1 if kind == "ragged" else n
     decor = dict(l2=1e-3, box_gradient=(-1.15, 0.95), box_constraint=(-1.15, 0.95)) if kind == "decorated" else {}
-    prob = dzo.Problem(dzo.QUADRATIC_CHAIN, nn, lam=1e-4) if kind == "quadratic_chain" else dzo.Problem(dzo.ROSENBROCK_CHAIN, nn, **decor)
-    x = dzo.DeviceArray.from_host(rosenbrock_chain_x0(nn, seed=5))
-    if kind == "callbacks":
-        opt = dzo.LBFGSOptimizer(None, prob.native_callbacks(), None, x, 1.0, m)
+    lse = kind in ("lse", "lse_two_pass")
+    if lse:
+        nn, m, esize = (1_000_000 if n == 10_000_000 else n), (10 if m == 20 else m), 4
+        cvec = (pcg32_uniform(nn, 6) - 0.5).astype(np.float32)                  # SURVEY 8(d) C4
+        prob = dzo.Problem(dzo.LSE, nn, np.float32, c=cvec, lam=1e-2)
+        x = dzo.DeviceArray.from_host(np.zeros(nn, np.float32))
+        if kind == "lse_two_pass":
+            os.environ["DZO_TUNE_LSE_POINTS"] = "0"
+        try:
+            opt = dzo.LBFGSOptimizer(None, prob, None, x, 1.0, m)
+        finally:
+            os.environ.pop("DZO_TUNE_LSE_POINTS", None)
     else:
-        opt = dzo.LBFGSOptimizer(None, prob, None, x, 1.0, m)
-    for _ in range(m + args.warmup):
+        prob = dzo.Problem(dzo.QUADRATIC_CHAIN, nn, lam=1e-4) if kind == "quadratic_chain" else dzo.Problem(dzo.ROSENBROCK_CHAIN, nn, **decor)
+        x = dzo.DeviceArray.from_host(rosenbrock_chain_x0(nn, seed=5))
+        if kind == "callbacks":
+            opt = dzo.LBFGSOptimizer(None, prob.native_callbacks(), None, x, 1.0, m)
+        else:
+            opt = dzo.LBFGSOptimizer(None, prob, None, x, 1.0, m)
+    # (the log-sum-exp problem of config 4 is dominated by its quadratic term: L-BFGS is at the resolution of fp32 after a handful
+    # of steps and then stuck -- its leg times the steps it takes from x0 = 0 after ONE warm-up step, at most 8)
+    for _ in range(1 if lse else m + args.warmup):
         opt.step()
-    steps = max(20, min(args.steps, 50))
+    steps = 8 if lse else max(20, min(args.steps, 50))
     dzo.synchronize()
     trials = 0
+    done = 0
     t0 = time.perf_counter()
     for _ in range(steps):
         opt.step()
+        if opt.is_stuck:
+            break
         trials += opt.last_trials
+        done += 1
     dzo.synchronize()
     el = time.perf_counter() - t0
+    steps = max(done, 1)
     dzo.profile_reset(); dzo.profile_enable(2)
-    for _ in range(10):
+    for _ in range(2 if lse else 10):
         opt.step()
     dzo.synchronize()
     dzo.profile_enable(False)
@@ -815,7 +837,8 @@ def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
     k = opt.history_count
     kern = {nm: {"launches": c, "avg_us": round(1e3 * ms / c, 2)} for nm, (c, ms) in sorted(tab.items(), key=lambda kv: -kv[1][1]) if c}
     out = {"metric": "step!() calls/s", "value": round(steps / el, 2), "unit": "step!() calls/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 4),
-           "dtype": "f64", "config": {"workload": f"L-BFGS m={m} on N-D " + ("chained quadratic" if kind == "quadratic_chain" else "chained Rosenbrock") + f", n={nn}, fp64: {kind}", "n": nn, "m": m,
+           "dtype": "f32" if lse else "f64",
+           "config": {"workload": f"L-BFGS m={m} on " + ("log-sum-exp" if lse else "N-D chained quadratic" if kind == "quadratic_chain" else "N-D chained Rosenbrock") + f", n={nn}, {'fp32' if lse else 'fp64'}: {kind}", "n": nn, "m": m,
                                       "history_layout": {0: "slabs", 1: "tiles of pairs", 2: "tiles of points"}[opt.ring_layout],
                                       "objective_evals_per_step": round(trials / steps, 3), "any_stuck": bool(opt.is_stuck),
                                       "decorators": decor or None},
@@ -824,6 +847,8 @@ def _lbfgs_variant_leg(dzo, n, m, esize, args, kind):
     if dom in kern:
         us = kern[dom]["avg_us"]
         nb = _kernel_bytes(dom, nn, k, esize, opt.ring_layout, opt.pass_recomputes_gradients)
+        if lse and dom == "lbfgs_single_pass":
+            nb = (k + 3) * nn * esize                    # the trial pass: k + 1 points and c read, the trial point written
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(nb / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": nb, "avg_launch_us": us}
         names = ("lbfgs_gram_pass", "lbfgs_gram_reduce", "lbfgs_gram_finish", "lbfgs_gram_reduce_finish", "lbfgs_combine")
@@ -864,7 +889,7 @@ def main():
                     help="default line at N = 1: skip the `secondary` object (configs 2, 4, 5 and AdGD measured after the headline)")
     ap.add_argument("--decorators", default="", help="lbfgs (sweep rows only, never the default line): decorators of legacy/DZOptimization.jl:219-296 "
                                                       "on the objective, e.g. 'l2=0.001,box=-1.15:0.95' (box = gradient mask + projection)")
-    ap.add_argument("--variant", default="", choices=["", "callbacks", "decorated", "ragged", "quadratic_chain"],
+    ap.add_argument("--variant", default="", choices=["", "callbacks", "decorated", "ragged", "quadratic_chain", "lse", "lse_two_pass"],
                     help="lbfgs: print only the line of one variant leg of the `secondary` object (dev)")
     ap.add_argument("--batch", type=int, default=1024, help="bfgs_batched: instances per GPU (config 5 shard)")
     ap.add_argument("--batched-steps", type=int, default=0,
@@ -1102,7 +1127,7 @@ def main():
         # profiling / A-B commands all pass --no-cpu-baseline and stay as they were)
         opt.close()
         out["secondary"] = secondary_in_line(args, dzo, sharding, info)
-        for kind in ("callbacks", "decorated", "ragged", "quadratic_chain"):
+        for kind in ("callbacks", "decorated", "ragged", "quadratic_chain", "lse", "lse_two_pass"):
             t_leg = time.perf_counter()
             try:
                 leg = _lbfgs_variant_leg(dzo, n, m, esize, args, kind)

@@ -1748,7 +1748,7 @@ template <typename T> __device__ __forceinline__ T lse_grad_elem(T x, T c, T mxT
 // at a time instead of k + 1; with all of them in registers the inlined exponentials of k + 1 gradients pushed the fp64
 // K = 24 and fp32 K = 20 instantiations past 512 registers.)
 template <typename T, bool FIRST>
-__global__ __launch_bounds__(kBlock, 2) void lse_trial_kernel(LseParams<T> p) {
+__global__ __launch_bounds__(kBlock, 3) void lse_trial_kernel(LseParams<T> p) {
     constexpr int N = Vec16<T>::N;
     __shared__ T a_s[kLseMaxK], c_s[kLseMaxK], mx_s[kLseMaxK + 1];
     __shared__ double se_s[kLseMaxK + 1];
@@ -1792,9 +1792,10 @@ __global__ __launch_bounds__(kBlock, 2) void lse_trial_kernel(LseParams<T> p) {
             T gprev[N];
 #pragma unroll
             for (int e = 0; e < N; ++e) { gprev[e] = lse_grad_elem<T>(x0v[e], cv[e], mx_s[0], se_s[0], p.lambda); q[e] = gprev[e]; }   // :438
-            for (int i = 0; i < k; ++i) {                     // :439-442
-                T xb[N];
-                tile(i + 1, xb);
+            T xb[N], xnext[N];
+            if (k > 0) tile(1, xb);
+            for (int i = 0; i < k; ++i) {                     // :439-442 (the next point's tile is requested before this one's exponentials)
+                tile(i + 2 <= k ? i + 2 : k, xnext);
                 const T a = a_s[i];
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
@@ -1802,19 +1803,21 @@ __global__ __launch_bounds__(kBlock, 2) void lse_trial_kernel(LseParams<T> p) {
                     q[e] = dfma(a, gprev[e] - gi1, q[e]);
                     gprev[e] = gi1;
                 }
+#pragma unroll
+                for (int e = 0; e < N; ++e) xb[e] = xnext[e];
             }
             if (scaled) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) q[e] = scale * q[e];                              // :443-445
             }
-            T xhi[N];
+            T xhi[N], xlo[N], xlo2[N];
             tile(k, xhi);
-            for (int i = k - 1; i >= 0; --i) {                // :446-449
-                T xlo[N];
-                tile(i, xlo);
+            if (k > 0) tile(k - 1, xlo);
+            for (int i = k - 1; i >= 0; --i) {                // :446-449 (two tiles ahead of the fma)
+                tile(i > 0 ? i - 1 : 0, xlo2);
                 const T c = c_s[i];
 #pragma unroll
-                for (int e = 0; e < N; ++e) { q[e] = dfma(c, xlo[e] - xhi[e], q[e]); xhi[e] = xlo[e]; }
+                for (int e = 0; e < N; ++e) { q[e] = dfma(c, xlo[e] - xhi[e], q[e]); xhi[e] = xlo[e]; xlo[e] = xlo2[e]; }
             }
         }
         T xn[N];
@@ -1882,7 +1885,7 @@ __global__ __launch_bounds__(kBlock) void lse_decide_kernel(const double *__rest
 
 // the dots of the NEXT two-loop (post-push order: new pair = 0, old pair i = i + 1), point pass layout of the partials
 template <typename T, int K>
-__global__ __launch_bounds__(kBlock, (sizeof(T) * (K + 2) <= 100 ? 2 : 1)) void lse_dots_kernel(LseParams<T> p) {
+__global__ __launch_bounds__(kBlock, (K <= 20 ? 2 : 1)) void lse_dots_kernel(LseParams<T> p) {
     constexpr int N = Vec16<T>::N;
     __shared__ T mx_s[kLseMaxK + 2];
     __shared__ double se_s[kLseMaxK + 2];
@@ -1930,11 +1933,14 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) * (K + 2) <= 100 ? 2 : 1)) void 
             dots.template push<0>(t5[0], lane); dots.template push<1>(t5[1], lane); dots.template push<2>(t5[2], lane);
             dots.template push<3>(t5[3], lane); dots.template push<4>(t5[4], lane);
         }
-        auto pair_dots = [&](auto ic) {                       // old pair i = point i - point i + 1 (xa / ga hold point i)
+        T xb[N], xpre[N];
+        load16_nt(reinterpret_cast<const T *>(rb + p.soff[1] + toff), xb);
+        auto pair_dots = [&](auto ic) {                       // old pair i = point i - point i + 1 (xa / ga hold point i, xb point i + 1)
             constexpr int i = decltype(ic)::value;
-            T xb[N], gb[N];
-            load16_nt(reinterpret_cast<const T *>(rb + p.soff[i + 1] + toff), xb);
+            T gb[N];
             double t5[kGramValues] = {0, 0, 0, 0, 0};
+            if (i < p.k) {                                    // (uniform; a pair beyond the history is zero: no tile, no exponentials, zeros into the sums)
+            load16_nt(reinterpret_cast<const T *>(rb + p.soff[i + 2 <= K ? i + 2 : K] + toff), xpre);   // (one tile ahead of the exponentials)
 #pragma unroll
             for (int e = 0; e < N; ++e) {
                 const bool real = owner && e0 + e < p.n;
@@ -1945,7 +1951,8 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) * (K + 2) <= 100 ? 2 : 1)) void 
                 t5[4] = __builtin_fma(sx, (double)yn[e], t5[4]);
             }
 #pragma unroll
-            for (int e = 0; e < N; ++e) { xa[e] = xb[e]; ga[e] = gb[e]; }
+            for (int e = 0; e < N; ++e) { xa[e] = xb[e]; ga[e] = gb[e]; xb[e] = xpre[e]; }
+            }
             constexpr int v0 = kGramValues * (i + 1);
             dots.template push<v0 + 0>(t5[0], lane); dots.template push<v0 + 1>(t5[1], lane); dots.template push<v0 + 2>(t5[2], lane);
             dots.template push<v0 + 3>(t5[3], lane); dots.template push<v0 + 4>(t5[4], lane);
