@@ -1127,7 +1127,8 @@ def main():
         # profiling / A-B commands all pass --no-cpu-baseline and stay as they were)
         opt.close()
         out["secondary"] = secondary_in_line(args, dzo, sharding, info)
-        for kind in ("callbacks", "decorated", "ragged", "quadratic_chain", "lse", "lse_two_pass"):
+        # (the log-sum-exp variants stay out of the default line: config 4's problem is done after two or three steps, tools/lse_steps.py)
+        for kind in ("callbacks", "decorated", "ragged", "quadratic_chain"):
             t_leg = time.perf_counter()
             try:
                 leg = _lbfgs_variant_leg(dzo, n, m, esize, args, kind)
