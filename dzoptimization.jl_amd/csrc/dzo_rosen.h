@@ -66,7 +66,10 @@ template <typename T> __device__ __forceinline__ QChainCoef<T> qchain_coef(int64
     return c;
 }
 template <typename T> __device__ __forceinline__ T qchain_grad_coef(const QChainCoef<T> &c, T xp, T xi, T xn) {
-    return dfma(c.cD, xi - (T)1, dfma(c.cL, xi - xp, c.cR * (xi - xn)));
+    // (the innermost term as fma(cR, ., +0), not a product: an element without the term -- the last one, or the phantom padding of a
+    // ragged n, whose neighbour registers may hold anything finite -- then contributes +0 whatever the neighbour's sign, so a
+    // phantom's gradient is +0 bit for bit, as ring_compare_kernel expects; same value as the oracle's cR * (x - x_r) otherwise)
+    return dfma(c.cD, xi - (T)1, dfma(c.cL, xi - xp, dfma(c.cR, xi - xn, (T)0)));
 }
 // the terms attributed to element i: its diagonal term and the pair term with its right neighbour
 template <typename T> __device__ __forceinline__ double qchain_term(const QChainCoef<T> &c, T xi, T xn) {

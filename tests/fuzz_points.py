@@ -40,11 +40,25 @@ def run(cases=60, seed=2468):
             decor["box_gradient"] = (lo, hi)
             if rng.integers(0, 4):
                 decor["box_constraint"] = (lo, hi)
+        # every sixth case on one of the other objectives of the point ring: the chained quadratic (same pass, ChainObj<T, 1>) or
+        # log-sum-exp (trial pass + dots pass); no decorators there
+        other = int(rng.integers(0, 6))
         if dtype == np.float32:
             orc.set_dot_mode(orc.DOT_WIDE)
         try:
-            ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype, **decor), x0.copy(), step0, m)
-            opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype, **decor), None, dzo.DeviceArray.from_host(x0), step0, m)
+            if other == 0:
+                decor = {}
+                lam = float(rng.choice([1e-3, 0.05, 0.5]))
+                ref_p, dev_p = orc.Problem(orc.QUADRATIC_CHAIN, n, dtype, lam=lam), dzo.Problem(dzo.QUADRATIC_CHAIN, n, dtype, lam=lam)
+            elif other == 1:
+                decor = {}
+                cc = (orc.pcg_fill(n, int(rng.integers(0, 10**6))) - 0.5).astype(dtype)
+                lam = float(rng.choice([1e-2, 1e-4]))
+                ref_p, dev_p = orc.Problem(orc.LSE, n, dtype, c=cc, lam=lam), dzo.Problem(dzo.LSE, n, dtype, c=cc, lam=lam)
+            else:
+                ref_p, dev_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, dtype, **decor), dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype, **decor)
+            ref = orc.LBFGS(ref_p, x0.copy(), step0, m)
+            opt = dzo.LBFGSOptimizer(None, dev_p, None, dzo.DeviceArray.from_host(x0), step0, m)
             assert opt.ring_layout == 2, (n, m)
             for it in range(int(rng.integers(3, 2 * m + 8))):
                 k = opt.history_count
@@ -53,7 +67,10 @@ def run(cases=60, seed=2468):
                 ref.install_state(opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value,
                                   S, Y, opt.rho_history[:k], opt.iteration_count)
                 f_before = opt.current_objective_value
+                if other in (0, 1) and it > 0 and abs(opt.delta_objective_value) <= (1e-12 if dtype == np.float64 else 1e-5) * max(abs(f_before), 1e-30):
+                    break        # (a convex objective at its minimiser: what is left is rounding noise)
                 opt.step(); ref.step()
+                assert opt.ring_layout == 2, ("left the point ring", ex, it, n, m, step0, np.dtype(dtype).name, other, decor, opt.last_trials, ref.last_trials, opt.is_stuck)
                 if opt.is_stuck != ref.is_stuck:
                     # only after dozens of halvings, where f_new - f is one unit in the last place and the two summation
                     # orders may decide differently (seed 12, case 2: the oracle accepts trial 43 with f lower by 5e-14,
@@ -65,17 +82,19 @@ def run(cases=60, seed=2468):
                     # 47 steps in, f = 3.9858877695994894: the oracle accepts trial 14, the GPU halves on until x + t d == x)
                     moved = ref if opt.is_stuck else opt
                     decrease = f_before - moved.current_objective_value
-                    assert decrease <= 1e-13 * abs(f_before) or min(opt.last_trials, ref.last_trials) > 30, (
-                        ex, it, n, m, step0, decor, opt.last_trials, ref.last_trials, f_before, decrease, opt.is_stuck, ref.is_stuck)
+                    assert decrease <= (1e-13 if dtype == np.float64 else 1e-6) * abs(f_before) or min(opt.last_trials, ref.last_trials) > 30, (
+                        ex, it, n, m, step0, decor, other, opt.last_trials, ref.last_trials, f_before, decrease, opt.is_stuck, ref.is_stuck)
                     break
                 if ref.is_stuck:
                     break
                 if ref.last_trials > 30 and opt.last_trials != ref.last_trials:
                     break        # dozens of halvings: f_new - f is at rounding level, the two summation orders may decide differently
-                assert opt.last_trials == ref.last_trials, (ex, it, n, m, step0, decor, opt.last_trials, ref.last_trials)
+                if opt.last_trials != ref.last_trials and min(abs(ref.delta_objective_value), abs(opt.delta_objective_value)) <= (1e-12 if dtype == np.float64 else 1e-5) * abs(f_before):
+                    break        # a decrease at rounding level (a run at its minimiser, box constraints active): :139 may go either way for the two summation orders
+                assert opt.last_trials == ref.last_trials, (ex, it, n, m, step0, decor, other, opt.last_trials, ref.last_trials, ref.delta_objective_value, opt.delta_objective_value, f_before)
                 e = rel(opt.step_direction.to_host(), ref.step_direction)
                 worst[dtype] = max(worst[dtype], e)
-                assert e <= (1e-9 if dtype == np.float64 else 1e-3), (ex, it, n, m, step0, decor, e)
+                assert e <= (1e-9 if dtype == np.float64 else 1e-3), (ex, it, n, m, step0, decor, other, e)
                 ex_ = rel(opt.current_point.to_host(), ref.current_point)
                 # (x_new = x + t d: the point inherits at most the direction's relative error -- seed 404, case 299, fp32, n = 16:
                 # direction 2.2e-5 off, within its tolerance, and the point 8.9e-6)
@@ -85,7 +104,7 @@ def run(cases=60, seed=2468):
                 assert ex_ <= tol_x, (ex, it, n, m, step0, np.dtype(dtype).name, "direction", e, "point", ex_, "trials", opt.last_trials)
                 steps_total += 1
             retries += opt.single_pass_retries
-            assert opt.ring_layout == 2
+            assert opt.ring_layout == 2, (ex, n, m, step0, np.dtype(dtype).name, other, decor, opt.iteration_count, opt.is_stuck)
         finally:
             orc.set_dot_mode(orc.DOT_SEQUENTIAL)
     return {"worst": {k.__name__: v for k, v in worst.items()}, "steps": steps_total, "later_passes": retries}

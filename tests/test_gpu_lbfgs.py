@@ -1025,7 +1025,8 @@ def test_decorated_point_ring_steps_match_the_oracle_from_the_same_state(n, m, s
 
 
 _QCHAIN_CASES = [(n, m, s0, dt) for dt in (np.float64, np.float32)
-                 for n, m, s0 in [(16, 3, 1.0), (385, 5, 1.0), (4100, 20, 1.0), (4099, 8, 1.0), (100_004, 12, 1.0), (4100, 6, 300.0), (4100, 23, 1.0), (4098, 16, 30.0)]
+                 for n, m, s0 in [(16, 3, 1.0), (385, 5, 1.0), (4100, 20, 1.0), (4099, 8, 1.0), (100_004, 12, 1.0), (4100, 6, 300.0), (4100, 23, 1.0), (4098, 16, 30.0),
+                                  (1001, 11, 30.0)]       # (the last: found by the fuzz -- a phantom gradient of -0 made the host-write check see a difference)
                  if not (dt == np.float32 and m > 20)]
 
 
