@@ -1164,6 +1164,55 @@ def test_point_ring_turns_into_the_pair_ring_without_changing_a_bit(monkeypatch)
         assert np.array_equal(opt.delta_gradient_history[i].to_host(), Y[i - 1])
 
 
+@pytest.mark.parametrize("option", ["descent_check", "wolfe"])
+@pytest.mark.parametrize("kind,n", [("decorated", 4100), ("decorated", 4099), ("qchain", 4100), ("qchain", 4099), ("lse", 4100), ("lse", 4099)])
+def test_point_ring_objectives_continue_on_the_pair_kernels_after_an_option(kind, n, option):
+    """Every objective the point ring serves (decorated chained Rosenbrock, chained quadratic, log-sum-exp), aligned and ragged:
+    an option the passes do not serve turns the ring into pairs (tile ring; slabs for a ragged n) and the run continues on
+    the GENERAL kernels -- Gram / combine, trial, the one-pass accepted-step tail with the gradient in the other buffer --
+    step by step like the oracle from the same fields."""
+    m = 5
+    x0 = orc.rosenbrock_chain_x0(n)
+    if kind == "decorated":
+        kw = dict(l2=0.01, box_gradient=(-1.1, 0.9), box_constraint=(-1.1, 0.9))
+        ref_p, dev_p = orc.Problem(orc.ROSENBROCK_CHAIN, n, **kw), dzo.Problem(dzo.ROSENBROCK_CHAIN, n, **kw)
+    elif kind == "qchain":
+        ref_p, dev_p = orc.Problem(orc.QUADRATIC_CHAIN, n, lam=1e-3), dzo.Problem(dzo.QUADRATIC_CHAIN, n, lam=1e-3)
+    else:
+        cc = orc.pcg_fill(n, 6) - 0.5
+        x0 = 3.0 * (orc.pcg_fill(n, 8) - 0.5)
+        ref_p, dev_p = orc.Problem(orc.LSE, n, c=cc, lam=1e-4), dzo.Problem(dzo.LSE, n, c=cc, lam=1e-4)
+    opt = dzo.LBFGSOptimizer(None, dev_p, None, dzo.DeviceArray.from_host(x0), 1.0, m)
+    ref = orc.LBFGS(ref_p, x0.copy(), 1.0, m)
+    assert opt.ring_layout == 2
+    for _ in range(3):
+        opt.step()
+    assert opt.ring_layout == 2 and not opt.is_stuck
+    if option == "descent_check":
+        opt.set_safeguards(descent_check=True); ref.set_safeguards(descent_check=True)
+    else:
+        opt.set_line_search(dzo.LINE_SEARCH_WOLFE); ref.set_line_search(1)
+    for it in range(4):
+        x, g, f = opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value
+        k = opt.history_count
+        S = np.stack([h.to_host() for h in opt.delta_point_history]); Y = np.stack([h.to_host() for h in opt.delta_gradient_history])
+        ref.install_state(x, g, f, S, Y, opt.rho_history[:k], opt.iteration_count)
+        opt.step(); ref.step()
+        assert opt.ring_layout == (0 if n % 2 else 1), it
+        assert opt.is_stuck == ref.is_stuck, it
+        if ref.is_stuck:
+            break
+        assert opt.iteration_count == ref.iteration_count, it
+        assert rel(opt.step_direction.to_host(), ref.step_direction) <= TOL_DIRECTION, it
+        x1 = opt.current_point.to_host()
+        assert rel(x1, ref.current_point) <= 1e-11, it
+        assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-11)
+        if kind != "lse":
+            assert np.array_equal(opt.current_gradient.to_host(), ref_p.grad(x1)), it
+        assert np.array_equal(opt.delta_point.to_host(), x1 - x), it                                  # run_and_test! :1035-1046, exact
+        assert np.array_equal(opt.delta_gradient.to_host(), opt.current_gradient.to_host() - g), it
+
+
 @pytest.mark.parametrize("n", [4100, 4099])
 def test_decorators_changed_between_steps_turn_the_point_ring_into_pairs_under_the_old_set(n):
     """The passes recompute every stored point's gradient under the decorators the ring was created with (ring_dec).  This

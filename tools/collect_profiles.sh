@@ -32,7 +32,7 @@ with open(f'profiles/{tag}_two_pass_kernel_stats.csv', 'w') as f:
         r['pmc_read_bytes_per_launch'] = p.get('read_bytes_per_launch', ''); r['pmc_write_bytes_per_launch'] = p.get('write_bytes_per_launch', '')
         w.writerow(r)
 PY
-bash tools/sq_counters.sh ${TAG} "lbfgs_point_pass_kernel<double, 20, false, 1>" > profiles/${TAG}_sq_counters_pass.txt 2>&1 || true
+bash tools/sq_counters.sh ${TAG} "lbfgs_point_pass_kernel<double, 20, false, 1, false, 0>" > profiles/${TAG}_sq_counters_pass.txt 2>&1 || true
 python3 bench.py > profiles/${TAG}_bench_line.json 2> $OUT/bench.err
 echo "bench line done"
 for w in bfgs_dense bfgs_batched lbfgs_lse_f32; do python3 bench.py --workload $w > profiles/${TAG}_bench_$w.json 2> $OUT/bench_$w.err; echo "$w done"; done
