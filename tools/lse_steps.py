@@ -13,13 +13,13 @@ dt = np.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else np.float64
 dzo.init(0)
 c = (bench.pcg32_uniform(n, 6) - 0.5).astype(dt)
 x0 = (5.0 * (bench.pcg32_uniform(n, 8) - 0.5)).astype(dt)
-for points in (1, 0, 1, 0):
+for points, events in ((1, 0), (0, 0), (1, 0), (0, 0), (1, 2), (0, 2)):
     os.environ["DZO_TUNE_LSE_POINTS"] = str(points)
     prob = dzo.Problem(dzo.LSE, n, dt, c=c, lam=1e-2)
     opt = dzo.LBFGSOptimizer(None, prob, None, dzo.DeviceArray.from_host(x0), 1.0, m)
     opt.step()
     dzo.synchronize()
-    dzo.profile_reset(); dzo.profile_enable(2)
+    dzo.profile_reset(); dzo.profile_enable(events)
     done = 0; trials = 0; el = 0.0
     for _ in range(12):                                  # each step timed by itself; the step that ends stuck (dozens of halvings) is left out
         t0 = time.perf_counter()
@@ -29,8 +29,9 @@ for points in (1, 0, 1, 0):
         if opt.is_stuck:
             break
         done += 1; trials += opt.last_trials; el += dt_step
-    print(f"points={points} layout {opt.ring_layout} n={n} m={m} {np.dtype(dt).name}: {done} steps, {done / el:.1f} step!()/s, {1e3 * el / max(done, 1):.3f} ms/step, "
+    print(f"points={points} events={events} layout {opt.ring_layout} n={n} m={m} {np.dtype(dt).name}: {done} steps, {done / el:.1f} step!()/s, {1e3 * el / max(done, 1):.3f} ms/step, "
           f"{trials / max(done, 1):.2f} evals/step, f = {opt.current_objective_value:.10g}", flush=True)
     dzo.profile_enable(0)
-    print("   ", {k: (v[0], round(1e3 * v[1] / v[0], 1)) for k, v in sorted(dzo.profile_table().items(), key=lambda kv: -kv[1][1]) if v[0]})
+    if events:
+        print("   ", {k: (v[0], round(1e3 * v[1] / v[0], 1)) for k, v in sorted(dzo.profile_table().items(), key=lambda kv: -kv[1][1]) if v[0]})
     opt.close()
