@@ -157,6 +157,11 @@ struct dzo_lbfgs_s {
     // gradient, so a pair y_i = g_i - g_i+1 is only the reference's stored pair while the decorators are the ones that
     // were in force when those gradients were first formed.  A change on the user's problem handle (this build lets
     // them be changed between steps) therefore turns the ring into the pair ring under the OLD set (lbfgs_step).
+    // General path: the accepted step's tail (delta_point, delta_gradient, rho) deferred into the next step's Gram pass
+    // (gram_pass_lanes_kernel<POST>): until then the newest pair's s slot holds x_old, post_g_old the gradient buffer that
+    // was current, and whoever needs the pair or the caller's arrays first calls lbfgs_flush_post
+    bool post_pending = false;
+    void *post_g_old = nullptr;
     dzo::RingDecor ring_dec;
     int ring_obj = 0;               // the objective the passes recompute (ChainObj: 0 Rosenbrock, 1 chained quadratic; 2: log-sum-exp, its own kernels) ...
     double ring_obj_lambda = 0;     // ... and its parameter
@@ -382,6 +387,10 @@ template <typename T> struct GramParams {
     const T *y[kMaxHistory];
     double *partials;           // [kGramValues * k][gridDim.x]
     int64_t rowbytes;           // blocked ring: bytes between consecutive wave-rows (BLK kernels only)
+    // POST kernels: the pivot pair does not exist yet -- it is the accepted step's (delta_point, delta_gradient), formed here
+    // from x, x_old (which the first trial saved in the pivot's s slot, :118) and g (new), g_old, and WRITTEN to the pivot's slots
+    const T *x, *g_old;
+    T *sp_out, *yp_out;
 };
 
 __device__ __forceinline__ void wave_sum5(const double (&t)[5], int lane, double (&tot)[5]) {
@@ -650,7 +659,10 @@ __global__ __launch_bounds__(kFusedFinishThreads) void gram_reduce_finish_kernel
 // butterfly and added into lane i's accumulators for pair i, so a lane carries 5 fp64
 // accumulators whatever k is (k <= 64 = wave width), occupancy stays high, and no operand is
 // loaded twice.  VALU/LDS cost of the butterflies: ~15 % of the memory time at U = 4.
-template <typename T, bool VEC, int U, bool BLK = false>
+// POST (general path, round 4): the accepted step's tail rides in this pass -- delta_point = x - x_old (:145), delta_gradient = g - g_old
+// (:478-480) are formed per element, stored to the pivot pair's slots and used as the pivot pair at once (their dots include
+// rho = delta_point . delta_gradient, :505); replaces accept_delta_rho_kernel + the re-read of the pair it wrote.
+template <typename T, bool VEC, int U, bool BLK = false, bool POST = false>
 __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p) {
     using L = Ld<T, VEC>;
     constexpr int N = L::N;
@@ -676,6 +688,22 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
         for (int u = 0; u < U; ++u) {
             const int64_t vi = base + (int64_t)u * kBlock + threadIdx.x;
             ok[u] = FULL || vi < nvec;
+            if constexpr (POST) {
+                if (ok[u]) {
+                    T xv[N], go[N];
+                    L::load(p.g + vi * N, gv[u]);
+                    L::load(p.x + vi * N, xv);
+                    L::load(sp + vi * N, spv[u]);                        // x_old
+                    L::load(p.g_old + vi * N, go);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { spv[u][j] = xv[j] - spv[u][j]; ypv[u][j] = gv[u][j] - go[j]; }
+                    L::store(p.sp_out + vi * N, spv[u]);
+                    L::store(p.yp_out + vi * N, ypv[u]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { gv[u][j] = 0; spv[u][j] = 0; ypv[u][j] = 0; }
+                }
+            } else
             if (ok[u]) {
                 if (p.fresh_plain) {
                     L::load(p.g + vi * N, gv[u]);
@@ -777,9 +805,17 @@ __global__ __launch_bounds__(kBlock) void gram_pass_lanes_kernel(GramParams<T> p
     else { for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) do_tile(tile * tile_v, std::false_type{}); }
     (void)nthreads;
     // scalar tail (n not a multiple of the vector width): lane i of wave 0 in block 0 owns pair i
+    if constexpr (POST) {
+        // (the tail elements of the new pair, once, before anybody's dots read them: this wave is the only one that does)
+        if (VEC && blockIdx.x == 0 && wave == 0 && lane == 0) {
+            for (int64_t e = nvec * N; e < p.n; ++e) { p.sp_out[e] = p.x[e] - sp[e]; p.yp_out[e] = p.g[e] - p.g_old[e]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
     if (VEC && blockIdx.x == 0 && wave == 0 && lane < k) {
         for (int64_t e = nvec * N; e < p.n; ++e) {
-            const double ge = (double)p.g[e], spe = (double)sp[e], ype = (double)yp[e];
+            const double ge = (double)p.g[e], spe = (double)(POST ? p.sp_out[e] : sp[e]), ype = (double)(POST ? p.yp_out[e] : yp[e]);
             const double sx = (double)p.s[lane][e], yx = (double)p.y[lane][e];
             acc[0] = __builtin_fma(sx, ge, acc[0]);
             acc[1] = __builtin_fma(yx, ge, acc[1]);
@@ -2351,6 +2387,11 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
     gp.peel = o->gram_peel;
     gp.fresh_plain = o->gram_fresh_plain;
     gp.pivot_first = (o->gram_skip0 && pivot == 0) ? 1 : 0;
+    const bool post = o->post_pending;                    // (lbfgs_direction made sure: pivot 0, slabs, aligned operands, pivot served from registers)
+    if (post) {
+        gp.x = (const T *)c.x; gp.g_old = (const T *)o->post_g_old;
+        gp.sp_out = o->s_slot<T>(o->slot_of(0)); gp.yp_out = o->y_slot<T>(o->slot_of(0));
+    }
     const bool vec = al16(c.g);
     if (o->gram_variant == 1) {
         // lane-distributed accumulators: one launch shape for every k (the pair-per-wave
@@ -2370,6 +2411,7 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
 #define GL(UU)                                                                                                  \
     do {                                                                                                        \
         auto kern = o->blocked ? gram_pass_lanes_kernel<T, true, UU, true>                                      \
+                    : post ? gram_pass_lanes_kernel<T, true, UU, false, true>                                   \
                     : vec ? gram_pass_lanes_kernel<T, true, UU> : gram_pass_lanes_kernel<T, false, UU>;         \
         int64_t cap = o->gram_grid;                                                                             \
         if (o->gram_bpc <= 0) { const int64_t res = (int64_t)ctx().cus * resident_blocks((const void *)kern); if (res < cap) cap = res; } \
@@ -2384,6 +2426,15 @@ template <typename T> static int32_t gram_pass(dzo_lbfgs_s *o, int pivot, bool r
         const int pcount = lgrid;
         const int nvals = kGramValues * k;
         const bool rho = o->rho_pending;
+        if (post) {                                       // rho of the new pair is value 4 of pair 0 (s_p . y_p): gram_finish takes it from there
+            o->post_pending = false;
+            {
+                DZO_TIMED("lbfgs_gram_reduce", s);
+                hipLaunchKernelGGL(gram_reduce_kernel, dim3(nvals), dim3(kBlock), 0, s, o->gram_partials, pcount, vals, nvals, (const double *)nullptr, 0,
+                                   (double *)nullptr, 0);
+            }
+            return gram_finish_launch(o, pivot, recurrence, vals, true);
+        }
         if (o->fused_finish && (int64_t)nvals * pcount <= o->fused_finish_max) {
             // small problem: the scalar stage in one launch (see gram_reduce_finish_kernel)
             const GramFinishParams fp = gram_finish_params(o, pivot, recurrence, vals, false, nullptr);
@@ -2485,8 +2536,40 @@ template <typename T> static int32_t direction_gram(dzo_lbfgs_s *o) {
 
 static int32_t lbfgs_flush_rho(dzo_lbfgs_s *o);
 
+// the deferred tail of the last accepted step, now (somebody needs delta_point / delta_gradient / rho or the buffers they
+// are formed from before a Gram pass could form them on its way): accept_delta_rho_kernel, as the undeferred path runs it
+static int32_t lbfgs_flush_post(dzo_lbfgs_s *o) {
+    if (!o->post_pending) return DZO_OK;
+    OptCore &c = o->core;
+    o->post_pending = false;
+    void *dx = o->s_slot_v(o->newest), *dg = o->y_slot_v(o->newest);
+    const bool vec = al16(c.x) && al16(dx) && al16(c.g) && al16(o->post_g_old) && al16(dg);
+    const int grid = stream_grid(c.n, (vec ? 16 / (int)dtype_size(c.dtype) : 1) * 2);
+    {
+        DZO_TIMED("lbfgs_accept_delta_rho", c.stream);
+        if (vec) DZO_DISPATCH(c.dtype, hipLaunchKernelGGL((accept_delta_rho_kernel<T, true>), dim3(grid), dim3(kBlock), 0, c.stream, c.n, (const T *)c.x, (T *)dx,
+                                                          (const T *)c.g, (const T *)o->post_g_old, (T *)dg, c.partials()));
+        else DZO_DISPATCH(c.dtype, hipLaunchKernelGGL((accept_delta_rho_kernel<T, false>), dim3(grid), dim3(kBlock), 0, c.stream, c.n, (const T *)c.x, (T *)dx,
+                                                      (const T *)c.g, (const T *)o->post_g_old, (T *)dg, c.partials()));
+    }
+    DZO_HIP(hipGetLastError());
+    // rho of the newest pair: summed lazily like after any two-pass step (lbfgs_finish_push's rho_pending)
+    if (o->mode == DZO_TWOLOOP_GRAM) { o->rho_pending = true; o->rho_pending_count = grid; o->rho_pending_slot = o->newest; }
+    else {
+        DZO_TIMED("lbfgs_rho_finish", c.stream);
+        hipLaunchKernelGGL(finish_to_kernel, dim3(1), dim3(kBlock), 0, c.stream, c.partials(), grid, o->rho + o->newest, c.dtype == DZO_F32 ? 1 : 0, (const int32_t *)nullptr);
+        DZO_HIP(hipGetLastError());
+    }
+    return DZO_OK;
+}
+
 static int32_t lbfgs_direction(dzo_lbfgs_s *o) {
     OptCore &c = o->core;
+    // the deferred tail rides in the Gram pass only in its plain form: GRAM mode, one pass with pivot 0 served from registers
+    if (o->post_pending && (o->mode != DZO_TWOLOOP_GRAM || o->k == 0 || o->blocked || o->gram_rebuild || o->gram_stale > 1 || !o->gram_skip0 ||
+                            o->gram_variant != 1 || o->spec_scalars || o->scalars_ready || o->gram_ready ||
+                            !(al16(c.x) && al16(c.g) && al16(o->post_g_old) && al16(o->s_slot_v(o->newest)) && al16(o->y_slot_v(o->newest)))))
+        DZO_TRY(lbfgs_flush_post(o));
     if (o->k == 0) {                                      // :438 then the :443 guard
         DZO_HIP(hipMemcpyAsync(o->d, c.g, (size_t)c.n * dtype_size(c.dtype), hipMemcpyDeviceToDevice, c.stream));
         return DZO_OK;
@@ -2524,6 +2607,7 @@ static int32_t lbfgs_post_gradient(dzo_lbfgs_s *o) {
 // rho of the newest pair is summed lazily: in GRAM mode the next direction's gram_reduce launch
 // carries it; anything else that needs rho on the device or host flushes it first.
 static int32_t lbfgs_flush_rho(dzo_lbfgs_s *o) {
+    DZO_TRY(lbfgs_flush_post(o));
     if (o->gram_ready) {
         // rho of the newest pair still sits in the single pass's dots (value 4 of pair 0 = s_p.y_p).
         // Sum it exactly as the coming gram_reduce launch will (same kernel, same order), so that
@@ -2893,6 +2977,7 @@ static void lbfgs_mark_unsettled(dzo_lbfgs_s *o);
 // one line search along o->d followed, when it succeeds, by the post-gradient phase and the push
 static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
     OptCore &c = o->core;
+    DZO_TRY(lbfgs_flush_post(o));                         // (a trial overwrites x: a deferred tail that no Gram pass consumed is formed first)
     o->refresh_delta_ptrs();                              // deltas move to the spare slots
     o->scalars_ready = false; o->gram_ready = false;      // x, g and the history are about to change
     o->spec_scalars = false;
@@ -2954,6 +3039,15 @@ static int32_t lbfgs_search_and_post(dzo_lbfgs_s *o, int trials_rejected = 0) {
         int32_t rcg = core_gradient(c);
         if (rcg != DZO_OK) { c.g = g_old; return rcg; }
         o->g_twin = g_old;
+        if (!o->blocked && o->mode == DZO_TWOLOOP_GRAM && !safeguards && tune("DZO_TUNE_GENERIC_POST", 1) >= 2) {
+            // deferred: the next step's Gram pass forms the pair on its way (gram_pass_lanes_kernel<POST>); the getters and
+            // everything else that needs it earlier call lbfgs_flush_post
+            lbfgs_mark_unsettled(o);
+            done = lbfgs_finish_push(o, 0, true, true);
+            o->post_pending = true; o->post_g_old = g_old;
+            DZO_TRY(done);
+            return DZO_OK;
+        }
         const bool vec = al16(c.x) && al16(c.dx) && al16(c.g) && al16(g_old) && al16(c.dg);
         const int grid = stream_grid(c.n, (vec ? 16 / (int)dtype_size(c.dtype) : 1) * 2);
         {
@@ -3043,6 +3137,7 @@ static void lbfgs_mark_unsettled(dzo_lbfgs_s *o) {
 static int32_t lbfgs_settle(dzo_lbfgs_s *o) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
+    DZO_TRY(lbfgs_flush_post(o));                         // (the copy below may overwrite g_old: the caller's array may be that buffer)
     if (o->points) {
         DZO_TRY(lbfgs_points_settle(o));
         lbfgs_mark_unsettled(o);
@@ -4225,6 +4320,7 @@ int32_t dzo_lbfgs_set_history(dzo_lbfgs_t o, int32_t k, const void *S_dev, const
     DZO_REQUIRE(k >= 0 && k <= o->m, DZO_ERR_INVALID, "k = %d exceeds history_length %d", k, o->m);
     DZO_REQUIRE(k == 0 || (S_dev && Y_dev), DZO_ERR_INVALID, "null history");
     DeviceScope scope(o->device);
+    DZO_TRY(lbfgs_flush_post(o));                        // (a deferred tail belongs to the history that is being replaced: formed, then overwritten)
     if (o->points) {                                     // installed PAIRS: the ring is a pair ring from here on
         DZO_TRY(lbfgs_materialize_d(o));
         DZO_TRY(lbfgs_points_settle(o));
