@@ -359,6 +359,41 @@ def test_callback_path_equals_builtin_path():
     assert calls["f"] >= 26 and calls["g"] == 26 and calls["c"] >= 26
 
 
+@pytest.mark.parametrize("n", [4100, 4099, 100_003])
+def test_deferred_tail_in_the_gram_pass_gives_the_same_run(n, monkeypatch):
+    """DZO_TUNE_GENERIC_POST=2 (off by default: measured slower, DESIGN round-4 table row 2): on the general path the accepted
+    step's delta_point / delta_gradient / rho are formed by the NEXT step's Gram pass on its way (gram_pass_lanes_kernel<POST>)
+    -- or, when somebody looks first, by lbfgs_flush_post.  Same elementwise values; rho is summed in another order, so two
+    free runs agree to rounding.  Run A never looks between steps (every tail rides in a Gram pass), run B looks after every
+    step (every tail is flushed), run C is the default."""
+    m = 4
+    x0 = orc.rosenbrock_chain_x0(n)
+
+    def run(knob, look):
+        monkeypatch.setenv("DZO_TUNE_GENERIC_POST", str(knob))
+        prob = dzo.Problem(dzo.ROSENBROCK_CHAIN, n)
+        opt = dzo.LBFGSOptimizer(None, prob.native_callbacks(), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        trials = []
+        for _ in range(m + 6):
+            opt.step()
+            trials.append(opt.last_trials)
+            if look:
+                s0 = opt.delta_point.to_host(); y0 = opt.delta_gradient.to_host()
+                assert np.array_equal(s0, opt.delta_point_history[0].to_host()) and np.array_equal(y0, opt.delta_gradient_history[0].to_host())
+                assert opt.rho_history[0] == pytest.approx(float(s0 @ y0), rel=1e-12)
+        x, g = opt.current_point.to_host(), opt.current_gradient.to_host()
+        S = np.stack([h.to_host() for h in opt.delta_point_history]); rho = opt.rho_history.copy()
+        assert np.array_equal(g, orc.Problem(orc.ROSENBROCK_CHAIN, n).grad(x))
+        assert np.allclose(rho, [float(a @ b) for a, b in zip(S, np.stack([h.to_host() for h in opt.delta_gradient_history]))], rtol=1e-12, atol=0)
+        return trials, x, opt.current_objective_value
+    ta, xa, fa = run(2, False)
+    tb, xb, fb = run(2, True)
+    tc, xc, fc = run(1, False)
+    assert ta == tb == tc
+    assert rel(xa, xc) <= 1e-9 and rel(xb, xc) <= 1e-9
+    assert fa == pytest.approx(fc, rel=1e-10) and fb == pytest.approx(fc, rel=1e-10)
+
+
 def test_split_entry_points_reproduce_step(monkeypatch):
     n, m = 257, 3
     # (bit for bit: both on the two-pass kernels -- the split entry points are those kernels driven from the host, and
