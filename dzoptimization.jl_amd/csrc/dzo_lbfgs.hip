@@ -3358,7 +3358,8 @@ template <typename T> static void (*point_pass_kernel_sel(dzo_lbfgs_s *o))(Fused
                    : o->m <= 10 ? lbfgs_point_pass_kernel<T, 10, false, 1> : lbfgs_point_pass_kernel<T, 12, false, 1>;
         }
     }
-    if constexpr (sizeof(T) == 8) { if (o->m > 20) return lbfgs_point_pass_kernel<T, 24, false, 2>; }   // (m <= 24: point_max_k)
+    // (m <= 24: point_max_k; K = 22 for m = 21, 22: on K = 24 they paid for two or three masked pairs)
+    if constexpr (sizeof(T) == 8) { if (o->m > 20) return o->m <= 22 ? lbfgs_point_pass_kernel<T, 22, false, 2> : lbfgs_point_pass_kernel<T, 24, false, 2>; }
     return o->m <= 8 ? lbfgs_point_pass_kernel<T, 8, false, 2>
            : o->m <= 12 ? lbfgs_point_pass_kernel<T, 12, false, 2>
            : o->m <= 16 ? lbfgs_point_pass_kernel<T, 16, false, 2>

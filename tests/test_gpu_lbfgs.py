@@ -1029,7 +1029,7 @@ def test_blocked_ring_hands_out_the_pairs_as_plain_vectors(n, m, dtype):
 _POINT_RING_CASES = [(n, m, s0, dt) for dt in (np.float64, np.float32)
                      for n, m, s0 in [(16, 3, 1.0), (2 * 62 * 3 + 12, 5, 1.0), (4100, 20, 1.0), (100_004, 7, 1.0), (4100, 6, 300.0), (4100, 23, 1.0),
                                       (17, 3, 1.0), (125, 4, 1.0), (249, 4, 1.0), (385, 5, 1.0), (4097, 9, 1.0), (4098, 11, 1.0), (4099, 20, 1.0),
-                                      (100_003, 7, 1.0), (4101, 6, 300.0), (4099, 23, 1.0)]
+                                      (100_003, 7, 1.0), (4101, 6, 300.0), (4099, 23, 1.0), (4100, 21, 1.0), (4099, 22, 1.0)]
                      if not (dt == np.float32 and m > 20)]
 
 

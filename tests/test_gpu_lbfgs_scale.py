@@ -94,8 +94,9 @@ CASES = [
     (np.float64, 2_500_000, 20, None),         # K = 20, 20 rows per wave: full staging bursts
     (np.float64, 2_500_000, 20, 0),
     (np.float64, 10_000_000, 20, None),        # config 3 itself
-    (np.float64, 400_000, 24, None),           # K = 24: two register sets, one wave per SIMD (m = 21 .. 24, fp64 only)
-    (np.float64, 2_500_000, 22, 0),            # K = 24, tile-major forced, 20 rows per wave
+    (np.float64, 400_000, 24, None),           # K = 24: two register sets, one wave per SIMD (m = 23, 24, fp64 only)
+    (np.float64, 2_500_000, 22, 0),            # K = 22 (m = 21, 22; round 4), tile-major forced, 20 rows per wave
+    (np.float64, 400_000, 21, None),           # K = 22
     (np.float32, 500_000, 6, None),            # fp32, K = 6
     (np.float32, 500_000, 7, None),            # fp32, K = 8, tile-major
     (np.float32, 500_000, 10, None),           # fp32, K = 10
