@@ -16,7 +16,13 @@ struct AdgdDev {
     int32_t sel;                     // the pass reads point / gradient buffer sel and writes buffer (sel + 1) % 3
     int32_t halvings;
     int32_t stuck;                   // the search ended (unchanged point, halving limit): later passes do nothing
-    int32_t seq;                     // passes decided so far
+    int32_t seq;                     // number of the pass this state belongs to
+};
+// The rounding rule of the optimizer's element type and the halving limit: what the decision needs besides the sums.
+struct AdgdRule {
+    int32_t to_f32;
+    double inv_sqrt_two;
+    int64_t max_halvings;
 };
 }  // namespace dzo
 
@@ -54,21 +60,27 @@ struct dzo_adgd_s {
     bool norms_ready = false;        // |delta_point|^2, |delta_gradient|^2 of the last step are in norm2[]
     double norm2[2] = {0, 0};
     int64_t fused_steps = 0, fused_rejections = 0;
-    // Pipelined step: behind every pass + decision the NEXT pass is enqueued at once, reading its step size and
-    // buffer roles from `dev` (the decision kernel runs the recurrence of :285-299 / the halving of :152 on the
-    // device), so the GPU never waits for the host's round trip.  Between two step! calls exactly one pass is in
+    // Pipelined step: behind every pass the NEXT pass is enqueued at once; it takes its step size and buffer roles
+    // from the device-side state (the decision runs the recurrence of :285-299 / the halving of :152 on the
+    // device), so the GPU never waits for the host's round trip.  Round 4: the decision on pass s is no kernel of
+    // its own any more -- every block of pass s + 1 evaluates it in its prologue (the same fixed-order sums of the
+    // partials of pass s, so every block arrives at the same bits), block 0 stores the new state and publishes
+    // the outcome to the host; the pass, the state and the changed-flag rotate through 2 / 2 / 3 buffers so that
+    // nothing a prologue reads is written by the pass it belongs to.  A stand-alone decision kernel remains for
+    // the pass behind which nothing is enqueued (DZO_TUNE_ADGD_PIPELINE=0) and for DZO_TUNE_ADGD_PROLOGUE=0, the
+    // round-3 sequence pass, decision, pass, decision.  Between two step! calls exactly one pass is in
     // flight and it writes only buffers the current state does not live in: a getter that hands out a pointer or
     // a changed option just drains the stream and the next pass starts from the host's state.  The host evaluates
     // the same recurrence and checks the value the device used (spec_corrected counts disagreements: none, both
     // sides evaluate the same IEEE expressions).
     bool pipeline = true;            // DZO_TUNE_ADGD_PIPELINE=0: one host round trip per pass
     bool nt_stores = true;           // DZO_TUNE_ADGD_NT_STORES=0: plain stores of the trial point / gradient (measured: no difference)
-    dzo::AdgdDev *dev = nullptr;
-    double *pass_partials = nullptr; // [3][grid] partial sums of the fused pass (its own buffer: the grid may exceed what the core's workspace holds)
+    bool prologue = true;            // DZO_TUNE_ADGD_PROLOGUE=0: a decision kernel behind every pass
+    dzo::AdgdDev *dev = nullptr;     // [2] states (pass s uses dev[s & 1]) + 4 int32 changed-flags behind them (pass s raises flag s % 3)
+    double *pass_partials = nullptr; // [2][3][kMaxPartialBlocks] partial sums of the fused pass (pass s writes set s & 1)
     int pass_bpc = 4;                // DZO_TUNE_ADGD_BPC: blocks of the fused pass per CU (measured: 4 / 6 / 8 -> 22.0 / 21.4 / 20.4 k step!()/s at n = 1e7)
-    double *slots = nullptr, *slots_dev = nullptr;   // pinned: 2 x 8 doubles, outcome of the last two decisions
-    hipEvent_t decided[2] = {nullptr, nullptr};
-    bool spec_pending = false;       // a pass + decision is enqueued whose outcome the host has not consumed
+    double *slots = nullptr, *slots_dev = nullptr;   // pinned: 2 x 8 doubles, outcome of the last two decisions (6 words + their seal)
+    bool spec_pending = false;       // a pass is enqueued whose outcome the host has not consumed
     int spec_slot = 0;
     int32_t seq = 0;                 // decisions enqueued so far (mod 2 = slot of the next one)
     int64_t spec_adopted = 0, spec_discarded = 0, spec_corrected = 0;
@@ -96,30 +108,142 @@ constexpr int kAdgdOwn = 62;
 
 template <typename T> struct AdgdFusedParams {
     int64_t n;
-    const AdgdDev *st;                         // step size, which buffer pair holds the current state
+    AdgdDev *st;                               // [2]: the state of pass s is st[s & 1]
     T *x0, *g0, *x1, *g1, *x2, *g2;            // the three pairs
-    double *partials;                          // [3][gridDim.x]: objective, |dx|^2, |dg|^2
-    int32_t *changed;
+    double *partials;                          // [2][3][kMaxPartialBlocks]: objective, |dx|^2, |dg|^2 of pass s in set s & 1
+    int32_t *flags;                            // [3]: pass s raises flags[s % 3] when the trial point differs (:128)
+    double *slots;                             // [2][8] pinned: the outcome of pass s goes to slot s & 1
+    AdgdRule rule;
+    int32_t seq;                               // the number of this pass
+    int32_t mode;                              // 0: decide pass seq - 1 first (prologue); 1: st[seq & 1] is ready
     int nt_stores;                             // DZO_TUNE_ADGD_NT_STORES
 };
+
+constexpr int64_t kAdgdPartialSet = 3 * (int64_t)kMaxPartialBlocks;
+
+__device__ __forceinline__ double adgd_pack2(int32_t lo, int32_t hi) {
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo));
+}
+
+// The :128 / :139 decision on the pass that ran from state `st` (v = its three sums, ch = its changed flag) and the
+// state of the pass behind it: after an accepted trial the step-size recurrence of :285-299 (expression by expression
+// as adgd_step evaluates it on the host, which checks the value before it adopts the pass), after a rejected one half
+// the step (:152).  status 3: the search was over before that pass, it did nothing.
+__device__ __forceinline__ AdgdDev adgd_next_state(const AdgdDev &st, const double (&v)[3], int32_t ch, const AdgdRule &r, int32_t *status_out) {
+    AdgdDev nx = st;
+    nx.seq = st.seq + 1;
+    if (st.stuck) { *status_out = 3; return nx; }
+    auto rnd = [&](double x) { return r.to_f32 ? (double)(float)x : x; };
+    auto root = [&](double x) { return r.to_f32 ? (double)sqrtf((float)x) : sqrt(x); };
+    const double f_new = rnd(v[0]);
+    int32_t status = 0;
+    if (ch == 0) status = 2;
+    else if (f_new < st.f_cur) status = 1;
+    *status_out = status;
+    if (status == 1) {
+        const double previous = st.prev, current = st.cur;                   // :285-286 of the next step!
+        double next = current;                                               // :287
+        if (previous != 0.0) {                                               // (:289 asserts it; the host raises the error)
+            const double theta = rnd(current / previous);                    // :290
+            next = rnd(next * root(1.0 + theta));                            // :291
+            const double dgn = root(v[2]);                                   // :292
+            if (dgn != 0.0) {                                                // :293
+                const double inv_L = rnd(root(v[1]) / dgn);                  // :294
+                const double cap = rnd(r.inv_sqrt_two * inv_L);
+                next = next < cap ? next : cap;                              // :295
+            }
+        } else {
+            nx.stuck = 1;
+        }
+        nx.prev = current; nx.cur = next; nx.t = next;                       // :298-299, :301
+        nx.f_cur = f_new;
+        nx.sel = (st.sel + 1) % 3;
+        nx.halvings = 0;
+    } else if (status == 0) {
+        nx.t = rnd(st.t * 0.5);                                              // :152
+        nx.halvings = st.halvings + 1;
+        if (r.max_halvings > 0 && nx.halvings >= r.max_halvings) nx.stuck = 1;
+    } else {
+        nx.stuck = 1;
+    }
+    return nx;
+}
+
+// The outcome of the pass that ran from `st` into the host's pinned slot: {sum f, t used, (roles used, pass number),
+// (status, changed), |dx|^2, |dg|^2} and the seal over the six words and the ticket st.seq + 1 -- the host
+// (wait_sealed) accepts the slot only when all seven words belong together, so no ordering between the stores is needed.
+__device__ __forceinline__ void adgd_publish(double *__restrict__ slot, const AdgdDev &st, const double (&v)[3], int32_t status, int32_t ch) {
+    const double w[6] = {status == 3 ? 0.0 : v[0], st.t, adgd_pack2(st.sel, st.seq), adgd_pack2(status, ch),
+                         status == 3 ? 0.0 : v[1], status == 3 ? 0.0 : v[2]};
+    unsigned long long x = seal_bits((double)(st.seq + 1));
+    // system-scope stores (sc0 sc1: written through to the host's memory now, not when the kernel ends -- the pass this
+    // runs in the prologue of lasts 30 us and the host is waiting; a __threadfence_system() would do it too, by writing
+    // back every dirty line of the L2 the pass is filling)
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(slot);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        __hip_atomic_store(out + i, seal_bits(w[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        x ^= seal_bits(w[i]);
+    }
+    __hip_atomic_store(out + 6, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// thread 0 of the calling block obtains the three sums of one set of partials (fixed order: what every block and the
+// stand-alone decision kernel compute alike)
+__device__ __forceinline__ void adgd_sum_partials(const double *__restrict__ set, int grid, double *lds, double (&v)[3]) {
+    double a[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < grid; i += kBlock) {
+        a[0] += set[i];
+        a[1] += set[(int64_t)kMaxPartialBlocks + i];
+        a[2] += set[2 * (int64_t)kMaxPartialBlocks + i];
+    }
+    block_sum_multi<3>(a, lds, v);
+}
 
 // One kernel for the first trial and for every later trial of the same step (:151-152): x and g still hold
 // x_old / g_old, whatever happened before.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParams<T> p) {
     constexpr int N = Vec16<T>::N;
-    __shared__ double lds[kWaves];
+    __shared__ double lds[3 * kWaves];
     __shared__ int lds_flag;
+    __shared__ double s_t;
+    __shared__ int s_sel, s_stuck;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t nvec = p.n / N;
     const int64_t rows = (nvec + kAdgdOwn - 1) / kAdgdOwn;
     const bool halo_lane = lane == 0 || lane == 63;
+    const int q = p.seq & 1;
     double fobj = 0, sdx = 0, sdg = 0;
     bool diff = false;
-    if (p.st->stuck) return;                                                 // (uniform: the search is over, nothing to do)
-    const T t = (T)(-p.st->t);
-    const int sel = p.st->sel;
+    double t_state;
+    int sel, stuck;
+    if (p.mode == 0) {
+        // the decision on the pass before this one, by every block for itself (block 0 keeps the books)
+        const AdgdDev old = p.st[q ^ 1];                                     // (uniform: scalar loads, in flight with the partials)
+        const int32_t ch = p.flags[(p.seq + 2) % 3];
+        double v[3];
+        adgd_sum_partials(p.partials + (q ^ 1) * kAdgdPartialSet, (int)gridDim.x, lds, v);
+        if (threadIdx.x == 0) {
+            int32_t status;
+            const AdgdDev nx = adgd_next_state(old, v, ch, p.rule, &status);
+            s_t = nx.t; s_sel = nx.sel; s_stuck = nx.stuck;
+            if (blockIdx.x == 0) {
+                p.st[q] = nx;
+                adgd_publish(p.slots + 8 * (q ^ 1), old, v, status, ch);
+                p.flags[(p.seq + 1) % 3] = 0;                                // (the flag of the NEXT pass: last read by the pass before this one)
+            }
+        }
+        __syncthreads();
+        t_state = s_t; sel = s_sel; stuck = s_stuck;
+    } else {
+        const AdgdDev st = p.st[q];
+        t_state = st.t; sel = st.sel; stuck = st.stuck;
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.flags[(p.seq + 1) % 3] = 0;
+    }
+    if (stuck) return;                                                       // (uniform: the search is over, nothing to do)
+    const T t = (T)(-t_state);
     const T *__restrict__ xin = sel == 0 ? p.x0 : (sel == 1 ? p.x1 : p.x2);
     T *__restrict__ xout = sel == 0 ? p.x1 : (sel == 1 ? p.x2 : p.x0);
     for (int64_t row = (int64_t)blockIdx.x * kWaves + wave; row < rows; row += (int64_t)gridDim.x * kWaves) {
@@ -164,89 +288,36 @@ __global__ __launch_bounds__(kBlock) void adgd_fused_rosen_kernel(AdgdFusedParam
             else store16(xout + v * N, xn);
         }
     }
-    block_raise_flag(diff, p.changed, &lds_flag);
-    const double f = block_sum(fobj, lds);
-    const double a = block_sum(sdx, lds);
-    const double b = block_sum(sdg, lds);
+    block_raise_flag(diff, p.flags + p.seq % 3, &lds_flag);
+    const double sums[3] = {fobj, sdx, sdg};
+    double out[3];
+    block_sum_multi<3>(sums, lds, out);                                      // (bit for bit what three block_sum calls give)
     if (threadIdx.x == 0) {
-        p.partials[blockIdx.x] = f;
-        p.partials[(int64_t)gridDim.x + blockIdx.x] = a;
-        p.partials[2 * (int64_t)gridDim.x + blockIdx.x] = b;
+        double *set = p.partials + q * kAdgdPartialSet;
+        set[blockIdx.x] = out[0];
+        set[(int64_t)kMaxPartialBlocks + blockIdx.x] = out[1];
+        set[2 * (int64_t)kMaxPartialBlocks + blockIdx.x] = out[2];
     }
 }
 
-// host state -> device state (a pass that is not the continuation of the passes in flight)
-__global__ void adgd_seed_kernel(AdgdDev *st, AdgdDev v) { *st = v; }
+// host state -> device state (a pass that is not the continuation of the passes in flight); its changed-flag starts clear
+__global__ void adgd_seed_kernel(AdgdDev *st, AdgdDev v, int32_t *flag) { *st = v; *flag = 0; }
 
-// Fixed-order sums of the three partial arrays, the :128 / :139 decision, the outcome into the host's pinned slot
-// {sum f, t used, roles used, status, changed, |dx|^2, |dg|^2, seq} -- and the state of the NEXT pass: after an
-// accepted trial the step-size recurrence of :285-299 (expression by expression as adgd_step evaluates it on
-// the host, which checks the value before it adopts the pass), after a rejected one half the step (:152).
-__global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__restrict__ partials, int grid,
-                                                             int32_t *__restrict__ changed, AdgdDev *__restrict__ st, int to_f32,
-                                                             double inv_sqrt_two, int64_t max_halvings,
+// The decision on pass s as a kernel of its own: for the pass nothing is enqueued behind.  It leaves the state of pass
+// s + 1 in place as well (a later pass may start from it in mode 1).
+__global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__restrict__ set, int grid, const int32_t *__restrict__ changed,
+                                                             const AdgdDev *__restrict__ st, AdgdDev *__restrict__ st_next, AdgdRule rule,
                                                              double *__restrict__ slot) {
     __shared__ double lds[3 * kWaves];
-    // This kernel stands between two passes of every step: the three sets of partials are requested together, behind the
-    // request for the state word, and summed behind ONE pair of barriers (block_sum_multi: every sum bit for bit what
-    // block_sum gives) -- it used to be three rounds of load, barrier, barrier after a first round trip for `stuck`.
-    const int stuck = st->stuck;
-    double a[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < grid; i += kBlock) {
-        a[0] += partials[i];
-        a[1] += partials[(int64_t)grid + i];
-        a[2] += partials[2 * (int64_t)grid + i];
-    }
-    if (stuck) {                                                             // (uniform)
-        if (threadIdx.x == 0) { reinterpret_cast<int32_t *>(slot + 3)[0] = 3; slot[7] = (double)st->seq; st->seq += 1; __threadfence_system(); }
-        return;
-    }
+    const AdgdDev old = *st;
+    const int32_t ch = *changed;
     double v[3];
-    block_sum_multi<3>(a, lds, v);
+    adgd_sum_partials(set, grid, lds, v);
     if (threadIdx.x == 0) {
-        auto rnd = [&](double x) { return to_f32 ? (double)(float)x : x; };
-        auto root = [&](double x) { return to_f32 ? (double)sqrtf((float)x) : sqrt(x); };
-        const double f_new = rnd(v[0]);
-        const int32_t ch = *changed;
-        int32_t status = 0;
-        if (ch == 0) status = 2;
-        else if (f_new < st->f_cur) status = 1;
-        *changed = 0;
-        slot[0] = v[0];
-        slot[1] = st->t;
-        slot[2] = (double)st->sel;
-        slot[5] = v[1];
-        slot[6] = v[2];
-        slot[7] = (double)st->seq;
-        reinterpret_cast<int32_t *>(slot + 3)[0] = status;
-        reinterpret_cast<int32_t *>(slot + 4)[0] = ch;
-        st->seq += 1;
-        if (status == 1) {
-            const double previous = st->prev, current = st->cur;             // :285-286 of the next step!
-            double next = current;                                           // :287
-            if (previous != 0.0) {                                           // (:289 asserts it; the host raises the error)
-                const double theta = rnd(current / previous);                // :290
-                next = rnd(next * root(1.0 + theta));                        // :291
-                const double dgn = root(v[2]);                               // :292
-                if (dgn != 0.0) {                                            // :293
-                    const double inv_L = rnd(root(v[1]) / dgn);              // :294
-                    const double cap = rnd(inv_sqrt_two * inv_L);
-                    next = next < cap ? next : cap;                          // :295
-                }
-            } else {
-                st->stuck = 1;
-            }
-            st->prev = current; st->cur = next; st->t = next;                // :298-299, :301
-            st->f_cur = f_new;
-            st->sel = (st->sel + 1) % 3;
-            st->halvings = 0;
-        } else if (status == 0) {
-            st->t = rnd(st->t * 0.5);                                        // :152
-            st->halvings += 1;
-            if (max_halvings > 0 && st->halvings >= max_halvings) st->stuck = 1;
-        } else {
-            st->stuck = 1;
-        }
+        int32_t status;
+        const AdgdDev nx = adgd_next_state(old, v, ch, rule, &status);
+        *st_next = nx;
+        adgd_publish(slot, old, v, status, ch);
         __threadfence_system();
     }
 }
@@ -266,7 +337,6 @@ static int32_t adgd_cancel_pipeline(dzo_adgd_s *o) {
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     o->spec_pending = false;
     o->spec_discarded += 1;
-    o->core.flag_armed = true;                                               // (every decision re-arms the flag)
     return DZO_OK;
 }
 
@@ -366,12 +436,14 @@ static bool adgd_fused_ok(dzo_adgd_s *o) {
         o->xbuf[1] = b; o->gbuf[1] = b + slot; o->xbuf[2] = b + 2 * slot; o->gbuf[2] = b + 3 * slot;
     }
     if (!o->dev) {
-        bool ok = hipMalloc((void **)&o->dev, sizeof(AdgdDev)) == hipSuccess;
-        ok = ok && hipMalloc((void **)&o->pass_partials, sizeof(double) * 3 * kMaxPartialBlocks) == hipSuccess;
+        const size_t state_bytes = 2 * sizeof(AdgdDev) + 4 * sizeof(int32_t);
+        bool ok = hipMalloc((void **)&o->dev, state_bytes) == hipSuccess;
+        ok = ok && hipMemsetAsync(o->dev, 0, state_bytes, c.stream) == hipSuccess;
+        ok = ok && hipMalloc((void **)&o->pass_partials, sizeof(double) * 2 * kAdgdPartialSet) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&o->slots, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         ok = ok && hipHostGetDevicePointer((void **)&o->slots_dev, o->slots, 0) == hipSuccess;
-        for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&o->decided[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); o->fused = false; return false; }
+        memset(o->slots, 0, sizeof(double) * 16);
     }
     return true;
 }
@@ -392,7 +464,12 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     fp.x0 = (T *)o->xbuf[0]; fp.g0 = (T *)o->gbuf[0]; fp.x1 = (T *)o->xbuf[1]; fp.g1 = (T *)o->gbuf[1];
     fp.x2 = (T *)o->xbuf[2]; fp.g2 = (T *)o->gbuf[2];
     fp.partials = o->pass_partials;
-    fp.changed = c.flag();
+    int32_t *flags = reinterpret_cast<int32_t *>(o->dev + 2);
+    fp.flags = flags;
+    fp.slots = o->slots_dev;
+    fp.rule.to_f32 = c.dtype == DZO_F32 ? 1 : 0;
+    fp.rule.inv_sqrt_two = c.dtype == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);
+    fp.rule.max_halvings = (int64_t)c.max_halvings;
     fp.nt_stores = o->nt_stores ? 1 : 0;
     // grid: four blocks per CU.  (The pass holds 46 registers, so eight would be resident, and a wave has only one row in
     // flight at a time -- but more blocks do not make the pass faster, 33.2-33.7 us by HIP events at 4 / 6 / 8 per CU, and
@@ -402,19 +479,25 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     if (blocks > cap) blocks = cap;
     if (blocks > kMaxPartialBlocks) blocks = kMaxPartialBlocks;
     const int grid = (int)(blocks < 1 ? 1 : blocks);
-    const double inv_sqrt_two = c.dtype == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);
     auto roles = [&]() { return o->cur; };                                   // the pair a pass from the CURRENT state reads
-    auto enqueue = [&](bool retry) -> int32_t {                              // one pass + its decision, outcome into slot seq & 1
-        const int slot = o->seq & 1;
+    // pass number o->seq.  from_state: its state is in dev[seq & 1] already (the seed, or the decision kernel behind
+    // the pass before it); otherwise the pass decides on its predecessor in its prologue.
+    auto enqueue_pass = [&](bool from_state, bool retry) -> int32_t {
+        fp.seq = o->seq;
+        fp.mode = from_state ? 1 : 0;
         {
             DZO_TIMED(retry ? "adgd_fused_retry" : "adgd_fused_step", s);
             hipLaunchKernelGGL(adgd_fused_rosen_kernel<T>, dim3(grid), dim3(kBlock), 0, s, fp);
         }
-        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)o->pass_partials, grid, c.flag(), o->dev,
-                           c.dtype == DZO_F32 ? 1 : 0, inv_sqrt_two, (int64_t)c.max_halvings, o->slots_dev + 8 * slot);
         DZO_HIP(hipGetLastError());
-        DZO_HIP(hipEventRecord(o->decided[slot], s));
         o->seq += 1;
+        return DZO_OK;
+    };
+    auto enqueue_decision = [&](int32_t q) -> int32_t {                      // the decision on pass q as a kernel: outcome into slot q & 1
+        hipLaunchKernelGGL(adgd_decide_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)(o->pass_partials + (q & 1) * kAdgdPartialSet), grid,
+                           (const int32_t *)(flags + q % 3), (const AdgdDev *)(o->dev + (q & 1)), o->dev + ((q + 1) & 1), fp.rule,
+                           o->slots_dev + 8 * (q & 1));
+        DZO_HIP(hipGetLastError());
         return DZO_OK;
     };
     auto give_up = [&]() -> int32_t {                                        // :118 delta_point holds x_old when the search gives up
@@ -428,42 +511,47 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
     int64_t halvings = 0;
     double t = step;
     for (bool first = true;;) {                                              // :121
-        // a decided pass for this trial: the one already in flight, or a fresh one from the host's state
+        // a pass for this trial: the one already in flight, or a fresh one from the host's state
         const bool in_flight = o->spec_pending;
-        int slot;
         if (in_flight) {
-            slot = o->spec_slot;
             o->spec_pending = false;
         } else {
-            if (!c.flag_armed) DZO_HIP(hipMemsetAsync(c.flag(), 0, sizeof(int32_t), s));
             AdgdDev v;
             v.t = t; v.f_cur = c.f; v.prev = o->previous_step_size; v.cur = o->current_step_size;
             v.sel = roles();
             v.halvings = (int32_t)halvings; v.stuck = 0; v.seq = o->seq;
-            hipLaunchKernelGGL(adgd_seed_kernel, dim3(1), dim3(1), 0, s, o->dev, v);
-            slot = o->seq & 1;
-            DZO_TRY(enqueue(!first));
+            hipLaunchKernelGGL(adgd_seed_kernel, dim3(1), dim3(1), 0, s, o->dev + (o->seq & 1), v, flags + o->seq % 3);
+            DZO_TRY(enqueue_pass(true, !first));
+            if (!o->prologue) DZO_TRY(enqueue_decision(o->seq - 1));
         }
-        c.flag_armed = true;
         const int32_t my_seq = o->seq - 1;
-        if (o->pipeline) {                                                   // the pass after this one, whatever this one's outcome
-            o->spec_slot = o->seq & 1;
-            DZO_TRY(enqueue(false));
+        if (o->pipeline) {                                                   // the pass after this one, whatever this one's outcome:
+            DZO_TRY(enqueue_pass(!o->prologue, false));                      // its prologue decides on pass my_seq
+            if (!o->prologue) DZO_TRY(enqueue_decision(o->seq - 1));
             o->spec_pending = true;
+        } else if (o->prologue) {
+            DZO_TRY(enqueue_decision(my_seq));
         }
-        DZO_HIP(hipEventSynchronize(o->decided[slot]));
-        const double *out = o->slots + 8 * slot;
+        const double *out = o->slots + 8 * (my_seq & 1);
+        DZO_TRY(wait_sealed(s, out, 6, out + 6, (double)(my_seq + 1)));
+        int32_t out_sel, out_seq, status, out_changed;
+        {
+            long long w2, w3;
+            memcpy(&w2, out + 2, sizeof(w2)); memcpy(&w3, out + 3, sizeof(w3));
+            out_sel = (int32_t)(uint32_t)(w2 & 0xffffffffll); out_seq = (int32_t)(uint32_t)((unsigned long long)w2 >> 32);
+            status = (int32_t)(uint32_t)(w3 & 0xffffffffll); out_changed = (int32_t)(uint32_t)((unsigned long long)w3 >> 32);
+        }
+        (void)out_changed;
         if (in_flight) {
-            const int32_t st = reinterpret_cast<const int32_t *>(out + 3)[0];
-            if (st == 3) {                                                   // the device had closed the search: nothing ran
+            if (status == 3) {                                                   // the device had closed the search: nothing ran
                 DZO_TRY(adgd_cancel_pipeline(o));
                 continue;                                                    // the same trial again, from the host's state
             }
             // The pass continued the device's own chain: it must be decision number my_seq with the buffer roles
             // the host derives from its pointers (anything else is a bug, and the pass after it may already have
             // written over the current state: stop).
-            DZO_REQUIRE((int32_t)out[7] == my_seq && (int)out[2] == roles(), DZO_ERR_STATE,
-                        "AdGD pipeline out of step with the host (decision %d / %d, buffer pair %d / %d)", (int)out[7], (int)my_seq, (int)out[2], roles());
+            DZO_REQUIRE(out_seq == my_seq && out_sel == roles(), DZO_ERR_STATE,
+                        "AdGD pipeline out of step with the host (decision %d / %d, buffer pair %d / %d)", (int)out_seq, (int)my_seq, (int)out_sel, roles());
             // Its step size comes from the device-side evaluation of :285-299 / :152 -- the same IEEE expressions
             // the host evaluates, so the two agree bit for bit; if they ever do not, the pass that ran is still a
             // valid step! with the device's value, which then is the optimizer's step size.
@@ -474,7 +562,6 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
             }
             o->spec_adopted += 1;
         }
-        const int32_t status = reinterpret_cast<const int32_t *>(out + 3)[0];
         if (status == 2) {                                                   // :128-130 (x_new == x_old bit for bit)
             DZO_TRY(give_up());
             c.is_stuck = true;
@@ -486,7 +573,7 @@ template <typename T> static int32_t adgd_fused_step(dzo_adgd_s *o, double step,
             const double f_new = round_to_dtype(c.dtype, out[0]);
             c.df = round_to_dtype(c.dtype, f_new - c.f);                     // :142-143
             c.f = f_new;                                                     // :144
-            o->norm2[0] = out[5]; o->norm2[1] = out[6];
+            o->norm2[0] = out[4]; o->norm2[1] = out[5];
             o->norms_ready = true;
             o->cur = (o->cur + 1) % 3;                                       // the trial point is the current one now; its gradient exists
             c.x = o->xbuf[o->cur]; c.g = o->gbuf[o->cur];                    // in no array yet (adgd_ensure_g)
@@ -618,6 +705,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     o->fused = getenv("DZO_TUNE_ADGD_FUSED") ? atoi(getenv("DZO_TUNE_ADGD_FUSED")) != 0 : true;
     o->pipeline = getenv("DZO_TUNE_ADGD_PIPELINE") ? atoi(getenv("DZO_TUNE_ADGD_PIPELINE")) != 0 : true;
     o->nt_stores = getenv("DZO_TUNE_ADGD_NT_STORES") ? atoi(getenv("DZO_TUNE_ADGD_NT_STORES")) != 0 : true;
+    o->prologue = getenv("DZO_TUNE_ADGD_PROLOGUE") ? atoi(getenv("DZO_TUNE_ADGD_PROLOGUE")) != 0 : true;
     o->pass_bpc = getenv("DZO_TUNE_ADGD_BPC") ? atoi(getenv("DZO_TUNE_ADGD_BPC")) : 4;
     *out = o;
     return DZO_OK;
@@ -655,7 +743,6 @@ int32_t dzo_adgd_destroy(dzo_adgd_t o) {
     if (o->dev) (void)hipFree(o->dev);
     if (o->pass_partials) (void)hipFree(o->pass_partials);
     if (o->slots) (void)hipHostFree(o->slots);
-    for (int i = 0; i < 2; ++i) if (o->decided[i]) (void)hipEventDestroy(o->decided[i]);
     core_free(o->core);
     delete o;
     return DZO_OK;

@@ -579,12 +579,14 @@ def test_adgd_pipelined_passes_are_the_same_steps(n, step0, dtype, monkeypatch):
     host adopts such a pass only when the device used exactly the host's own value, so a pipelined run must be
     the run with one host round trip per pass (DZO_TUNE_ADGD_PIPELINE=0), bit for bit -- scalars included --
     and the passes must really have been adopted; handing out a pointer in between drops the pass in flight
-    and changes nothing either."""
+    and changes nothing either.  Since round 4 the decision on a pass is taken in the prologue of the pass behind it;
+    DZO_TUNE_ADGD_PROLOGUE=0 keeps it a kernel of its own ("kernel" below), the same steps again."""
     K = 30
     x0 = orc.rosenbrock_chain_x0(n).astype(dtype)
     runs = {}
-    for mode in ("1", "0", "peek"):
-        monkeypatch.setenv("DZO_TUNE_ADGD_PIPELINE", "0" if mode == "0" else "1")
+    for mode in ("1", "0", "peek", "kernel", "kernel0"):
+        monkeypatch.setenv("DZO_TUNE_ADGD_PIPELINE", "0" if mode in ("0", "kernel0") else "1")
+        monkeypatch.setenv("DZO_TUNE_ADGD_PROLOGUE", "0" if mode.startswith("kernel") else "1")
         opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype=dtype), None, dzo.DeviceArray.from_host(x0), step0)
         scal = []
         for it in range(K):
@@ -596,7 +598,7 @@ def test_adgd_pipelined_passes_are_the_same_steps(n, step0, dtype, monkeypatch):
                       opt.delta_gradient.to_host(), opt.fused_steps, opt.fused_rejections, opt.pipelined_passes, opt.pipeline_discards)
         assert opt.pipeline_corrections == 0
     a, b, c = runs["1"], runs["0"], runs["peek"]
-    for other in (b, c):
+    for other in (b, c, runs["kernel"], runs["kernel0"]):
         assert a[0] == other[0]
         for i in (1, 2, 3, 4):
             assert np.array_equal(a[i], other[i])
@@ -605,4 +607,5 @@ def test_adgd_pipelined_passes_are_the_same_steps(n, step0, dtype, monkeypatch):
     assert a[5] == its and its >= 10
     assert b[7] == 0 and b[8] == 0
     assert a[7] >= its - 2 and a[8] <= 2                    # every pass but the very first was already in flight
+    assert runs["kernel"][7] >= its - 2 and runs["kernel0"][7] == 0
     assert c[8] >= min(its, K) // 3 - 1 and c[7] >= 1
