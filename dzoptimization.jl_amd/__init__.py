@@ -142,6 +142,14 @@ def calibrate_read_bandwidth(nbytes, repeats=20):
     return r.value
 
 
+def calibrate_read_bandwidth_of(array, repeats=20):
+    """GB/s of the same streaming read over the bytes of a DeviceArray, whatever it holds."""
+    _need_init()
+    r = C.c_double()
+    _check(lib().dzo_calibrate_read_bandwidth_of(array.ptr, int(array.size * array.dtype.itemsize), int(repeats), C.byref(r)))
+    return r.value
+
+
 # ------------------------------------------------------------------------------ ABI table
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 CONSTRAINT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
@@ -157,6 +165,7 @@ ABI = {
     "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_unsealed_first_reads": [_P(_i64)], "dzo_profile_count": [_P(_i32)],
     "dzo_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_dbl)],
     "dzo_calibrate_read_bandwidth": [_i64, _i32, _P(_dbl)],
+    "dzo_calibrate_read_bandwidth_of": [_vp, _i64, _i32, _P(_dbl)],
     "dzo_malloc": [_P(_vp), _i64], "dzo_free": [_vp], "dzo_memcpy_h2d": [_vp, _vp, _i64],
     "dzo_memcpy_d2h": [_vp, _vp, _i64], "dzo_memcpy_d2d": [_vp, _vp, _i64],
     "dzo_axpy": [_i64, _i32, _dbl, _vp, _vp], "dzo_axpby": [_i64, _i32, _dbl, _vp, _dbl, _vp],

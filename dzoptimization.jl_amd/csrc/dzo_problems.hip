@@ -471,6 +471,129 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
     }
 }
 
+// The same launch with a block walking CG columns at once and three register sets of requests in flight (round 4).  The
+// one-column kernel waits for each iteration's four loads before it asks for the next ones (24 KB per CU in flight).  Here
+// the loads of iterations it + 1 and it + 2 are on their way while iteration it is computed -- and they are UNCONDITIONAL
+// (addresses clamped to the last vector, the sums predicated instead): a prefetch under `if (i < n)` makes the compiler
+// wait for vmcnt(0) before the older set may be used, because requests complete in order and a younger request that may
+// not have been issued cannot be counted on (that is why the first pipelined forms of this kernel measured nothing,
+// profiles/r04_phi6_experiments.md).  x, dir_a, dir_b are loaded and the six trial values formed once per CG columns.
+// Element i still belongs to thread (i / N) % 256 in iteration i / (256 N), the per-thread sums run over q, then over the
+// iterations, and the block sum is wave_sum + the waves in order: every value is bit for bit what quadratic_phi6_kernel
+// (and quadratic_phi_kernel, quadratic_kernel) give.  n % N == 0 only.
+template <typename T, int CG>
+__global__ __launch_bounds__(kBlock) void quadratic_phi6_cols_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
+                                                                     PhiDir<T> a, PhiDir<T> b,
+                                                                     double *__restrict__ partials, int32_t *__restrict__ flags,
+                                                                     const PhiReqDev *__restrict__ dreq) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ double lds[CG * 6 * kWaves];
+    if (dreq) { if (!phi6_take_requests<T>(a, b, dreq)) return; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups = (n + CG - 1) / CG;
+    const int64_t st = (int64_t)kBlock * N;
+    const int64_t i0 = (int64_t)threadIdx.x * N;
+    const int iters = (int)((n + st - 1) / st);                             // (uniform; a thread's own count may be one less)
+    const int64_t ilast = n - N;
+    struct Tile { T av[CG][N], xv[N], da[N], db[N]; };
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t j0 = grp * CG;
+        double acc[CG][6];
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[c][r] = 0;
+        auto fetch = [&](Tile &t, int it) {                                  // always issued; past the end: the last vector again
+            int64_t i = i0 + (int64_t)it * st;
+            i = i < n ? i : ilast;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const int64_t jc = j0 + c < n ? j0 + c : n - 1;              // (a column past the end: loaded, never used)
+                load16(A + jc * n + i, t.av[c]);
+            }
+            load16(x + i, t.xv);
+            load16(a.dir + i, t.da);
+            load16(b.dir + i, t.db);
+        };
+        auto consume = [&](const Tile &t, int it) {
+            if (i0 + (int64_t)it * st >= n) return;
+            double xt[6][N];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) {
+                    xt[r][q] = a.active[r] ? (double)dfma(a.ts[r], t.da[q], t.xv[q]) : 0.0;
+                    xt[3 + r][q] = b.active[r] ? (double)dfma(b.ts[r], t.db[q], t.xv[q]) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {                              // (wave-uniform skips, as in the one-column kernel)
+                        if (a.active[r]) acc[c][r] = __builtin_fma((double)t.av[c][q], xt[r][q], acc[c][r]);
+                        if (b.active[r]) acc[c][3 + r] = __builtin_fma((double)t.av[c][q], xt[3 + r][q], acc[c][3 + r]);
+                    }
+                }
+            }
+        };
+        Tile t0, t1, t2;
+        fetch(t0, 0);
+        fetch(t1, 1);
+        int it = 0;
+        for (; it + 3 <= iters; it += 3) {
+            fetch(t2, it + 2); consume(t0, it);
+            fetch(t0, it + 3); consume(t1, it + 1);
+            fetch(t1, it + 4); consume(t2, it + 2);
+        }
+        if (it < iters) consume(t0, it);
+        if (it + 1 < iters) consume(t1, it + 1);
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int on = r < 3 ? a.active[r] : b.active[r - 3];
+                if (!on) continue;                                           // (uniform; an inactive request's sum is never read)
+                const double w = wave_sum(acc[c][r]);
+                if (lane == 0) lds[(c * 6 + r) * kWaves + wave] = w;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < CG && j0 + threadIdx.x < n) {
+            const int c = threadIdx.x;
+            const int64_t j = j0 + c;
+            const T xo = x[j];
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const PhiDir<T> &d = side ? b : a;
+                const T dj = d.dir[j];
+                T xtj[3], refv[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) xtj[r] = dfma(d.ts[r], dj, xo);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) refv[r] = (d.active[r] && d.ref[r]) ? d.ref[r][j] : (T)0;   // first: a reference may be one of this launch's own output buffers
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (!d.active[r]) continue;
+                    const int slot = side * 3 + r;
+                    double cs = 0;
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) cs += lds[(c * 6 + slot) * kWaves + w];
+                    partials[(int64_t)slot * n + j] = cs * (double)xtj[r];
+                    d.point_out[r][j] = xtj[r];
+                    if (d.grad_out[r]) d.grad_out[r][j] = (T)cs;             // exactly what quadratic_kernel<WRITE_G> stores
+                    if (xo != xtj[r]) flags[slot * 3 + 0] = 1;
+                    if (dj != (T)0) flags[slot * 3 + 1] = 1;
+                    if (d.ref[r]) { if (!is_equal(xtj[r], refv[r])) flags[slot * 3 + 2] = 1; }
+                    else if (d.ref_req[r] >= 0) { if (!is_equal(xtj[r], xtj[d.ref_req[r]])) flags[slot * 3 + 2] = 1; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same evaluations on the LOWER TRIANGLE of A (round 4).  A is symmetric by definition (f = 1/2 x'Ax, "dense
 // symmetric A", include/dzo.h), so c = A x_t needs every element of the triangle once:
@@ -1123,8 +1246,19 @@ bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const Ph
             }
         }
         if (quad_tri_on(p)) quad_tri_launch<T>(p, s, (const T *)x, d[0], d[1], flags, dreq);
-        else hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
-                                p->scratch, flags, dreq);
+        else {
+            // DZO_TUNE_PHI6_COLS: columns of A a block walks at once (1: the one-column kernel; 2, the default: 28.9 against 33.5 us
+            // per round at config 2; 4: 30.1)
+            const int cols_knob = getenv("DZO_TUNE_PHI6_COLS") ? atoi(getenv("DZO_TUNE_PHI6_COLS")) : 2;
+            constexpr int N = Vec16<T>::N;
+            const int cg = (n % N != 0 || n < 64) ? 1 : cols_knob;
+            const int64_t groups = (n + (cg > 1 ? cg : 1) - 1) / (cg > 1 ? cg : 1);
+            const int ggrid = (int)(groups < 65535 ? groups : 65535);
+            if (cg == 4) hipLaunchKernelGGL((quadratic_phi6_cols_kernel<T, 4>), dim3(ggrid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1], p->scratch, flags, dreq);
+            else if (cg == 2) hipLaunchKernelGGL((quadratic_phi6_cols_kernel<T, 2>), dim3(ggrid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1], p->scratch, flags, dreq);
+            else hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
+                                    p->scratch, flags, dreq);
+        }
     };
     if (p->dtype == DZO_F64) launch(double{}); else launch(float{});
     if (dreq) return true;                                       // (the caller's finish kernel sums, advances the searches and posts the next requests)

@@ -423,6 +423,31 @@ int32_t dzo_calibrate_read_bandwidth(int64_t bytes, int32_t repeats, double *gbp
     return DZO_OK;
 }
 
+// The same reader over a buffer of the caller's (whatever it holds): GB/s over `repeats` back-to-back passes.
+int32_t dzo_calibrate_read_bandwidth_of(const void *buf, int64_t bytes, int32_t repeats, double *gbps) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(buf && gbps && bytes >= kCalibTiles * 1024 && repeats >= 1, DZO_ERR_INVALID, "bad argument (at least 32 KiB, one repeat)");
+    double *sink = nullptr;
+    DZO_HIP(hipMalloc((void **)&sink, sizeof(double) * 4096));
+    hipStream_t s = ctx().stream;
+    const int64_t nchunks = bytes / (kCalibTiles * 1024);
+    int grid = (int)((nchunks + kWaves - 1) / kWaves);
+    if (grid > ctx().cus * 2) grid = ctx().cus * 2;
+    hipEvent_t a, b;
+    DZO_HIP(hipEventCreate(&a)); DZO_HIP(hipEventCreate(&b));
+    hipLaunchKernelGGL(calib_read_kernel, dim3(grid), dim3(kBlock), 0, s, (const char *)buf, nchunks, sink);
+    DZO_HIP(hipEventRecord(a, s));
+    for (int r = 0; r < repeats; ++r) hipLaunchKernelGGL(calib_read_kernel, dim3(grid), dim3(kBlock), 0, s, (const char *)buf, nchunks, sink);
+    DZO_HIP(hipEventRecord(b, s));
+    DZO_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    DZO_HIP(hipEventElapsedTime(&ms, a, b));
+    *gbps = (double)nchunks * (kCalibTiles * 1024.0) * repeats / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    return DZO_OK;
+}
+
 int32_t dzo_trial_point(int64_t n, int32_t dtype, void *dst_dev, double t, const void *d_dev, const void *x_dev) {
     DZO_CHECK_VEC(n, dst_dev, d_dev, x_dev);
     DZO_DISPATCH(dtype, launch_axpy_oop<T>(ctx().stream, n, (T *)dst_dev, (T)t, (const T *)d_dev, (const T *)x_dev));

@@ -123,6 +123,8 @@ int32_t dzo_unsealed_first_reads(int64_t *count);
  * `bytes` of device memory re-read `repeats` times.  <= ~200 MiB stays in the Infinity Cache (the ceiling of
  * config 2, H = 128 MiB); several GiB give the HBM streaming ceiling. */
 int32_t dzo_calibrate_read_bandwidth(int64_t bytes, int32_t repeats, double *gbps);
+/* the same reader over a device buffer of the caller's, whatever it holds */
+int32_t dzo_calibrate_read_bandwidth_of(const void *buf_dev, int64_t bytes, int32_t repeats, double *gbps);
 
 /* ---------------------------------------------------------------------------------------
  * device memory (what `similar` / `copy` / `Array(x)` do for a GPU array type A)

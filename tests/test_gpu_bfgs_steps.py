@@ -358,3 +358,36 @@ def test_dense_step_on_the_lower_triangle_of_A_matches_the_oracle(monkeypatch):
         assert np.linalg.norm(x - ref.current_point) <= 1e-9 * np.linalg.norm(ref.current_point), it
         assert opt.current_objective_value == pytest.approx(ref.current_objective_value, rel=1e-9)
         assert np.array_equal(opt.current_gradient.to_host(), prob.gradient_(dzo.DeviceArray(n, np.float64), opt.current_point).to_host())   # run_and_test! :1025-1032
+
+
+@pytest.mark.parametrize("n,dtype", [(1024, np.float64), (1030, np.float64), (772, np.float32), (96, np.float64)])
+def test_search_rounds_over_several_columns_at_once_are_the_same_bits(n, dtype, monkeypatch):
+    """quadratic_phi6_cols_kernel (default: two columns of A per block, three register sets of requests in flight, every
+    request unconditional) keeps the one-column kernel's assignment of elements to threads and its order of sums, so a run
+    with DZO_TUNE_PHI6_COLS = 1 / 2 / 4 is the same run bit for bit -- points, gradients (the search's by-product against a
+    separate evaluation, run_and_test! legacy :1025-1032), step types and evaluation counts.  n = 1030 / 772: a last iteration
+    that only some threads have, a last group with a column past the end."""
+    rng = np.random.default_rng(7)
+    U = rng.standard_normal((n, 6))
+    A = np.diag(1.0 + 49.0 * rng.random(n)) + U @ U.T / 6
+    A = (0.5 * (A + A.T)).astype(dtype)
+    x0 = (rng.random(n) - 0.5).astype(dtype)
+    runs = []
+    for cols in ("1", "2", "4"):
+        monkeypatch.setenv("DZO_TUNE_PHI6_COLS", cols)
+        prob = dzo.Problem(dzo.QUADRATIC, n, dtype=dtype, A=A)
+        opt = dzo.BFGSOptimizer(prob, None, dzo.DeviceArray.from_host(x0), 1.0)
+        trace = []
+        for it in range(10):
+            opt.step()
+            x = opt.current_point.to_host()
+            g = opt.current_gradient.to_host()
+            assert np.array_equal(g, prob.gradient_(dzo.DeviceArray(n, dtype), opt.current_point).to_host())
+            trace.append((x, g, opt.current_objective_value, opt.last_step_type, opt.objective_evaluations))
+            if opt.has_terminated:
+                break
+        runs.append(trace)
+    for other in runs[1:]:
+        assert len(other) == len(runs[0])
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
