@@ -193,7 +193,7 @@ ABI = {
     "dzo_lbfgs_accept": [_vp, _dbl], "dzo_lbfgs_reject": [_vp], "dzo_lbfgs_pre_gradient": [_vp],
     "dzo_lbfgs_post_gradient": [_vp], "dzo_lbfgs_get_i": [_vp, _i32, _P(_i64)],
     "dzo_lbfgs_get_s": [_vp, _i32, _P(_dbl)], "dzo_lbfgs_set_s": [_vp, _i32, _dbl],
-    "dzo_lbfgs_set_stuck": [_vp, _i32], "dzo_lbfgs_get_ptr": [_vp, _i32, _i32, _P(_vp)],
+    "dzo_lbfgs_set_stuck": [_vp, _i32], "dzo_lbfgs_get_ptr": [_vp, _i32, _i32, _P(_vp)], "dzo_lbfgs_read": [_vp, _i32, _i32, _vp],
     "dzo_lbfgs_get_rho": [_vp, _P(_dbl), _i32, _P(_i32)],
     "dzo_lbfgs_get_alpha": [_vp, _P(_dbl), _i32, _P(_i32)],
     "dzo_lbfgs_set_history": [_vp, _i32, _vp, _vp, _P(_dbl), _i64], "dzo_lbfgs_stream": [_vp, _P(_vp)],
@@ -203,7 +203,7 @@ ABI = {
     "dzo_adgd_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_adgd_destroy": [_vp],
     "dzo_adgd_set_callbacks": [_vp, CONSTRAINT_FN, OBJECTIVE_FN, GRADIENT_FN, _vp], "dzo_adgd_step": [_vp],
     "dzo_adgd_get_i": [_vp, _i32, _P(_i64)], "dzo_adgd_get_s": [_vp, _i32, _P(_dbl)],
-    "dzo_adgd_get_ptr": [_vp, _i32, _P(_vp)],
+    "dzo_adgd_get_ptr": [_vp, _i32, _P(_vp)], "dzo_adgd_read": [_vp, _i32, _vp],
     "dzo_bfgs_create_callbacks": [OBJECTIVE_FN, GRADIENT_FN, CONSTRAINT_FN, _vp, _i64, _i32, _vp, _dbl,
                                   _P(_vp)],
     "dzo_bfgs_create_problem": [_vp, _vp, _dbl, _P(_vp)], "dzo_bfgs_destroy": [_vp], "dzo_bfgs_step": [_vp],
@@ -549,6 +549,35 @@ class LineSearchEvaluator:
         return f.value
 
 
+class _FieldView(DeviceArray):
+    """A vector field of a live optimizer (``opt.current_point`` ...).  ``to_host()`` goes through ``dzo_<opt>_read``: a copy to
+    the host without a pointer hand-out, so the step behind a monitoring read does not have to check the aliased arrays for
+    host writes.  Everything that needs the device pointer (``ptr``, ``upload``, ``copy``, passing the field to a kernel) asks
+    ``dzo_<opt>_get_ptr`` at that moment -- the hand-out after which the host may have written (src/DZOptimization.jl:393)."""
+
+    def __init__(self, opt, what, idx):
+        self._opt, self._what, self._idx = opt, what, idx
+        self.shape = (int(opt.n),)
+        self.dtype = np.dtype(opt.dtype)
+        self.size = int(opt.n)
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = False
+
+    @property
+    def ptr(self):
+        return int(self._opt._get_ptr(self._what, self._idx))
+
+    def free(self):
+        pass
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        o = self._opt
+        fn = getattr(lib(), f"dzo_{o._prefix}_read")
+        _check(fn(o.h, self._what, self._idx, out.ctypes.data) if o._ptr_idx else fn(o.h, self._what, out.ctypes.data))
+        return out
+
+
 class _OptBase:
     _prefix = ""
     _ptr_idx = True
@@ -563,11 +592,18 @@ class _OptBase:
         _check(getattr(lib(), f"dzo_{self._prefix}_get_s")(self.h, what, C.byref(v)))
         return v.value
 
-    def _p(self, what, idx=0, shape=None):
+    _has_read = False                # the C ABI has dzo_<prefix>_read (a copy to the host without a pointer hand-out)
+
+    def _get_ptr(self, what, idx=0):
         p = C.c_void_p()
         fn = getattr(lib(), f"dzo_{self._prefix}_get_ptr")
         _check(fn(self.h, what, idx, C.byref(p)) if self._ptr_idx else fn(self.h, what, C.byref(p)))
-        return DeviceArray(self.n if shape is None else shape, self.dtype, ptr=p.value, owner=False)
+        return p.value
+
+    def _p(self, what, idx=0, shape=None):
+        if self._has_read and shape is None:
+            return _FieldView(self, what, idx)
+        return DeviceArray(self.n if shape is None else shape, self.dtype, ptr=self._get_ptr(what, idx), owner=False)
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:
@@ -596,6 +632,7 @@ class LBFGSOptimizer(_OptBase):
     is ignored and may be ``None``).  The optimizer ALIASES ``initial_point`` (:393)."""
 
     _prefix = "lbfgs"
+    _has_read = True
 
     def __init__(self, constraint_function_, objective_function, gradient_function_, initial_point, *rest):
         _need_init()
@@ -695,6 +732,7 @@ class LBFGSOptimizer(_OptBase):
     tile_arrangement = property(lambda s: s._i(15))       # 0 no tiles (slabs), 1 tile-major, 2 stream-major
     pass_recomputes_gradients = property(lambda s: bool(s._i(16)))   # point pass: gradients of the ring's points recomputed from the point tiles
     pass_register_sets = property(lambda s: s._i(17))     # point pass: register sets per wave (1 = two waves per SIMD)
+    host_write_checks = property(lambda s: s._i(18))      # point ring: steps that first compared the aliased arrays with the ring
 
     def compute_step_direction(self, sync=True):
         """``compute_lbfgs_step_direction!`` (:430-451).  ``sync=False`` only enqueues the kernels (the
@@ -741,6 +779,7 @@ class AdGDOptimizer(_OptBase):
 
     _prefix = "adgd"
     _ptr_idx = False
+    _has_read = True
 
     def __init__(self, constraint_function_, objective_function, gradient_function_, initial_point,
                  initial_step_length):

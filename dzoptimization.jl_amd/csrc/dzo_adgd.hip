@@ -325,7 +325,9 @@ __global__ __launch_bounds__(kBlock) void adgd_decide_kernel(const double *__res
 static int32_t adgd_settle_entry(void *h);
 
 static void adgd_mark_unsettled(dzo_adgd_s *o) {
-    const bool dirty = o->cur != 0;
+    // (... or the arrays are the live pair but no look at them is on record: the next dzo_synchronize / dzo_memcpy_* must
+    // leave one, because the host may write into current_gradient behind it)
+    const bool dirty = o->cur != 0 || !o->g_host_may_write;
     if (dirty && !o->unsettled) { unsettled_add(o, adgd_settle_entry); o->unsettled = true; }
     if (!dirty && o->unsettled) { unsettled_remove(o); o->unsettled = false; }
 }
@@ -369,7 +371,7 @@ static int32_t adgd_materialize_deltas(dzo_adgd_s *o) {
 }
 
 // current_point / current_gradient back into the arrays the optimizer aliases
-static int32_t adgd_settle(dzo_adgd_s *o) {
+static int32_t adgd_settle(dzo_adgd_s *o, bool hand_out = true) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
     DZO_TRY(adgd_cancel_pipeline(o));
@@ -383,7 +385,7 @@ static int32_t adgd_settle(dzo_adgd_s *o) {
         o->cur = 0; c.x = o->x_user; c.g = o->g_user;
         o->g_valid[0] = true;
     }
-    o->g_host_may_write = true;                                              // (whoever asked may write into the arrays)
+    if (hand_out) o->g_host_may_write = true;                                // (whoever is handed the arrays may write into them; dzo_adgd_read hands out nothing)
     adgd_mark_unsettled(o);
     return DZO_OK;
 }
@@ -620,6 +622,7 @@ static int32_t adgd_step(dzo_adgd_s *o) {
         if (!current) { fused_ok = false; o->host_gradient_steps += 1; }
     }
     o->g_host_may_write = false;
+    adgd_mark_unsettled(o);
     if (!fused_ok) DZO_TRY(adgd_cancel_pipeline(o));
     const double half = 0.5;
     const double inv_sqrt_two = dt == DZO_F32 ? (double)sqrtf(0.5f) : sqrt(0.5);   // :283
@@ -796,14 +799,12 @@ int32_t dzo_adgd_get_s(dzo_adgd_t o, int32_t what, double *value) {
     return DZO_OK;
 }
 
-int32_t dzo_adgd_get_ptr(dzo_adgd_t o, int32_t what, void **ptr_dev) {
-    DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
-    DeviceScope scope(o->device);
+static int32_t adgd_field_ptr(dzo_adgd_t o, int32_t what, bool hand_out, void **ptr_dev) {
     if (what == 1 || what == 3) DZO_TRY(adgd_materialize_deltas(o)); // after one-pass steps the two vectors are formed here
-    DZO_TRY(adgd_settle(o));                                         // current_point / current_gradient ARE the caller's arrays again
+    DZO_TRY(adgd_settle(o, hand_out));                               // current_point / current_gradient ARE the caller's arrays again
     DZO_HIP(hipStreamSynchronize(o->core.stream));
     // the caller may write through the pointer: do not trust what the fused step cached about it
-    if (what == 1 || what == 3) o->norms_ready = false;
+    if (hand_out && (what == 1 || what == 3)) o->norms_ready = false;
     switch (what) {
     case 0: *ptr_dev = o->core.x; break;
     case 1: *ptr_dev = o->core.dx; break;
@@ -811,6 +812,22 @@ int32_t dzo_adgd_get_ptr(dzo_adgd_t o, int32_t what, void **ptr_dev) {
     case 3: *ptr_dev = o->core.dg; break;
     default: set_error("dzo_adgd_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
     }
+    return DZO_OK;
+}
+
+int32_t dzo_adgd_get_ptr(dzo_adgd_t o, int32_t what, void **ptr_dev) {
+    DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
+    return adgd_field_ptr(o, what, true, ptr_dev);
+}
+
+int32_t dzo_adgd_read(dzo_adgd_t o, int32_t what, void *host_dst) {
+    DZO_REQUIRE(o && host_dst, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    void *src = nullptr;
+    DZO_TRY(adgd_field_ptr(o, what, false, &src));
+    DZO_HIP(hipMemcpy(host_dst, src, (size_t)o->core.n * dtype_size(o->core.dtype), hipMemcpyDeviceToHost));
     return DZO_OK;
 }
 

@@ -172,6 +172,7 @@ struct dzo_lbfgs_s {
     // host may have looked (a gather into them; construction) the next step first compares them with point 0 and,
     // if somebody changed them, continues on the pair ring with the caller's values (lbfgs_adopt_host_writes).
     bool xg_host_may_write = false;
+    int64_t host_write_checks = 0;   // steps that compared the caller's arrays with the ring first (lbfgs_adopt_host_writes)
     int32_t *xg_differs = nullptr;  // device flag of that comparison
     // step_direction is not written by the passes (nothing on the point ring reads it: every trial recomputes it in
     // registers): it is formed when somebody asks, by one more pass over the view of the ring the step started from
@@ -2717,14 +2718,18 @@ static int32_t lbfgs_ensure_g(dzo_lbfgs_s *o, int slot) {
 }
 
 // point ring: current_point / current_gradient into the caller's arrays (the optimizer aliases them, :393)
-static int32_t lbfgs_points_settle(dzo_lbfgs_s *o) {
-    if (!o->points || !o->xg_lin_stale) return DZO_OK;
+// hand_out = false (dzo_lbfgs_read): the arrays are filled for a copy to the host that the library makes itself; nobody
+// gets a pointer, so the next step need not check them against the ring (lbfgs_adopt_host_writes: a regrad, two compare
+// passes and a host round trip -- what a monitoring read of current_point used to cost the step behind it).
+static int32_t lbfgs_points_settle(dzo_lbfgs_s *o, bool hand_out = true) {
+    if (!o->points) return DZO_OK;
+    if (hand_out) o->xg_host_may_write = true;            // (whoever is handed the arrays may write into them)
+    if (!o->xg_lin_stale) return DZO_OK;
     DZO_TRY(lbfgs_ensure_g(o, o->newest));
     DZO_TIMED("lbfgs_ring_gather", o->core.stream);
     DZO_DISPATCH(o->core.dtype, (ring_gather<T>(o, o->s_slot_v(o->newest), o->x_user), ring_gather<T>(o, o->y_slot_v(o->newest), o->g_user)));
     DZO_HIP(hipGetLastError());
     o->xg_lin_stale = false;
-    o->xg_host_may_write = true;                          // (whoever asked for the gather may write into the arrays)
     return DZO_OK;
 }
 
@@ -3127,19 +3132,21 @@ static bool points_ok(dzo_lbfgs_s *o) {
 static int32_t lbfgs_settle_entry(void *h);
 
 static void lbfgs_mark_unsettled(dzo_lbfgs_s *o) {
-    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user || (o->points && o->xg_lin_stale);
+    // (point ring, arrays filled for a read-only copy: the handle stays registered, so that the next dzo_synchronize /
+    // dzo_memcpy_* -- after which the host may write into them -- still marks them as handed out)
+    const bool dirty = o->core.x != o->x_user || o->core.g != o->g_user || (o->points && (o->xg_lin_stale || !o->xg_host_may_write));
     if (dirty && !o->unsettled) { unsettled_add(o, lbfgs_settle_entry); o->unsettled = true; }
     if (!dirty && o->unsettled) { unsettled_remove(o); o->unsettled = false; }
 }
 
 // current_point / current_gradient back into the arrays the optimizer aliases (a device copy each, only
 // when they currently live in the twins)
-static int32_t lbfgs_settle(dzo_lbfgs_s *o) {
+static int32_t lbfgs_settle(dzo_lbfgs_s *o, bool hand_out = true) {
     std::lock_guard<std::recursive_mutex> lk(o->mu);
     OptCore &c = o->core;
     DZO_TRY(lbfgs_flush_post(o));                         // (the copy below may overwrite g_old: the caller's array may be that buffer)
     if (o->points) {
-        DZO_TRY(lbfgs_points_settle(o));
+        DZO_TRY(lbfgs_points_settle(o, hand_out));
         lbfgs_mark_unsettled(o);
         return DZO_OK;
     }
@@ -3749,6 +3756,7 @@ static int32_t lbfgs_adopt_host_writes(dzo_lbfgs_s *o) {
     o->xg_host_may_write = false;
     if (o->xg_lin_stale) return DZO_OK;                   // (the arrays do not hold a gathered copy at all)
     DZO_TRY(lbfgs_ensure_g(o, o->newest));
+    o->host_write_checks += 1;
     DZO_HIP(hipMemsetAsync(o->xg_differs, 0, sizeof(int32_t), c.stream));
     DZO_DISPATCH(c.dtype, (ring_compare<T>(o, o->s_slot_v(o->newest), o->x_user), ring_compare<T>(o, o->y_slot_v(o->newest), o->g_user)));
     DZO_HIP(hipGetLastError());
@@ -4196,6 +4204,7 @@ int32_t dzo_lbfgs_get_i(dzo_lbfgs_t o, int32_t what, int64_t *value) {
     case 14: *value = o->points ? 2 : (o->blocked ? 1 : 0); break;   // history layout: 0 slabs, 1 tiles of pairs, 2 tiles of points
     case 15: *value = o->blocked ? (o->tile_stride == kTileBytes ? 1 : 2) : 0; break;   // arrangement of the tiles: 1 tile-major, 2 stream-major
     case 16: *value = (o->points && DZO_PP_REGRAD != 0) ? 1 : 0; break;   // point pass: 1 = the points' gradients are recomputed from the point tiles, not streamed
+    case 18: *value = o->host_write_checks; break;        // steps that first compared the aliased arrays with the point ring (after a pointer hand-out)
     case 17: { int sets = 0; if (o->points) { DZO_DISPATCH(o->core.dtype, sets = point_one_set<T>(o) ? 1 : 2); } *value = sets; break; }   // register sets per wave of the point pass
     default: set_error("dzo_lbfgs_get_i: unknown field %d", what); return DZO_ERR_INVALID;
     }
@@ -4244,10 +4253,10 @@ int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t o, int32_t is_stuck) {
     return DZO_OK;
 }
 
-int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_dev) {
-    DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
-    DeviceScope scope(o->device);
-    DZO_TRY(lbfgs_settle(o));                             // current_point / current_gradient ARE the caller's arrays again
+// where field `what` can be read (after this returns, with the stream drained).  hand_out: the caller receives the pointer
+// and may write through it (dzo_lbfgs_get_ptr); otherwise the library copies from it itself (dzo_lbfgs_read).
+static int32_t lbfgs_field_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, bool hand_out, void **ptr_dev) {
+    DZO_TRY(lbfgs_settle(o, hand_out));                   // current_point / current_gradient ARE the caller's arrays again
     if (what == 1 || what == 3) DZO_TRY(lbfgs_refresh_lin(o));   // blocked ring: delta_point / delta_gradient gathered on demand
     if (what == 4) DZO_TRY(lbfgs_materialize_d(o));              // point ring: step_direction formed on demand
     if ((what == 5 || what == 6) && o->blocked) {
@@ -4287,6 +4296,22 @@ int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_d
         break;
     default: set_error("dzo_lbfgs_get_ptr: unknown field %d", what); return DZO_ERR_INVALID;
     }
+    return DZO_OK;
+}
+
+int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, void **ptr_dev) {
+    DZO_REQUIRE(o && ptr_dev, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
+    return lbfgs_field_ptr(o, what, idx, true, ptr_dev);
+}
+
+int32_t dzo_lbfgs_read(dzo_lbfgs_t o, int32_t what, int32_t idx, void *host_dst) {
+    DZO_REQUIRE(o && host_dst, DZO_ERR_INVALID, "null argument");
+    DeviceScope scope(o->device);
+    std::lock_guard<std::recursive_mutex> lk(o->mu);
+    void *src = nullptr;
+    DZO_TRY(lbfgs_field_ptr(o, what, idx, false, &src));
+    DZO_HIP(hipMemcpy(host_dst, src, (size_t)o->core.n * dtype_size(o->core.dtype), hipMemcpyDeviceToHost));
     return DZO_OK;
 }
 

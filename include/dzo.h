@@ -245,7 +245,9 @@ int32_t dzo_lbfgs_set_max_halvings(dzo_lbfgs_t opt, int64_t max_halvings);
  * (DESIGN.md "point ring"); field 15: arrangement of the tiles -- 1 tile-major, 2 stream-major
  * (informational); field 16: 1 when the pass over the point ring recomputes the points' gradients from the
  * point tiles instead of streaming them; field 17: register sets per wave of that pass (1 = two waves per
- * SIMD, 2 = one), 0 when the optimizer is not on the point ring (both informational);
+ * SIMD, 2 = one), 0 when the optimizer is not on the point ring (both informational); field 18: steps that first
+ * compared the aliased arrays with the point ring because a pointer to them had been handed out (dzo_lbfgs_read hands
+ * out none);
  * dzo_lbfgs_get_s field 2: last_step_length. */
 int32_t dzo_lbfgs_set_safeguards(dzo_lbfgs_t opt, int32_t descent_check, int32_t steepest_descent_fallback);
 
@@ -300,6 +302,12 @@ int32_t dzo_lbfgs_get_s(dzo_lbfgs_t opt, int32_t what, double *value);
 int32_t dzo_lbfgs_set_s(dzo_lbfgs_t opt, int32_t what, double value);
 int32_t dzo_lbfgs_set_stuck(dzo_lbfgs_t opt, int32_t is_stuck);
 int32_t dzo_lbfgs_get_ptr(dzo_lbfgs_t opt, int32_t what, int32_t idx, void **ptr_dev);
+/* Field `what` (get_ptr's numbering; n elements of the optimizer's dtype) copied to host memory, synchronously.  Unlike
+ * get_ptr this hands out no pointer: the host cannot have written into current_point / current_gradient through it, so the
+ * step behind a read does not have to check the aliased arrays against the optimizer's own state (after get_ptr,
+ * dzo_synchronize or dzo_memcpy_* it does: the reference's step! walks from whatever those arrays hold, :393).  The way to
+ * watch an optimization from the host. */
+int32_t dzo_lbfgs_read(dzo_lbfgs_t opt, int32_t what, int32_t idx, void *host_dst);
 /* rho_history / alpha_history (:341-342), newest first; *count receives the length */
 int32_t dzo_lbfgs_get_rho(dzo_lbfgs_t opt, double *out, int32_t capacity, int32_t *count);
 int32_t dzo_lbfgs_get_alpha(dzo_lbfgs_t opt, double *out, int32_t capacity, int32_t *count);
@@ -352,6 +360,8 @@ int32_t dzo_adgd_step(dzo_adgd_t opt);
 int32_t dzo_adgd_get_i(dzo_adgd_t opt, int32_t what, int64_t *value);
 int32_t dzo_adgd_get_s(dzo_adgd_t opt, int32_t what, double *value);
 int32_t dzo_adgd_get_ptr(dzo_adgd_t opt, int32_t what, void **ptr_dev);
+/* as dzo_lbfgs_read: field `what` to host memory without handing out a pointer */
+int32_t dzo_adgd_read(dzo_adgd_t opt, int32_t what, void *host_dst);
 
 /* ---------------------------------------------------------------------------------------
  * BFGSOptimizer (legacy/DZOptimization.jl:733-994; README.md:33-41)

@@ -609,3 +609,33 @@ def test_adgd_pipelined_passes_are_the_same_steps(n, step0, dtype, monkeypatch):
     assert a[7] >= its - 2 and a[8] <= 2                    # every pass but the very first was already in flight
     assert runs["kernel"][7] >= its - 2 and runs["kernel0"][7] == 0
     assert c[8] >= min(its, K) // 3 - 1 and c[7] >= 1
+
+
+def test_adgd_watched_through_read_is_the_same_run():
+    """dzo_adgd_read (behind `opt.current_point.to_host()`): no pointer hand-out, so the next step neither checks the gradient
+    array against the point nor leaves the one-pass kernel; the run is the unwatched run bit for bit.  A write through the
+    caller's own handle behind such a read is still seen (the handle stays registered for dzo_memcpy_*)."""
+    n = 100_000
+    x0 = orc.rosenbrock_chain_x0(n)
+    runs = []
+    for watch in (False, True):
+        xd = dzo.DeviceArray.from_host(x0)
+        opt = dzo.AdGDOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, xd, 0.1)
+        for it in range(12):
+            opt.step()
+            if watch and it % 2 == 0:
+                x = opt.current_point.to_host()
+                assert np.array_equal(opt.current_gradient.to_host(), orc.Problem(orc.ROSENBROCK_CHAIN, n).grad(x))
+        assert opt.host_gradient_steps == 0 and opt.fused_steps == 12
+        runs.append((opt.current_point.to_host(), opt.current_objective_value, opt.current_step_size, opt.previous_step_size))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1:] == runs[1][1:]
+    # a read, then the host overwrites current_gradient through a handle of its own: the next step walks along what it wrote
+    g = opt.current_gradient.to_host()
+    gd = dzo.DeviceArray(n, np.float64, ptr=opt._get_ptr(2), owner=False)     # (the pointer a caller would have kept from the constructor)
+    opt.step()                                                                 # (that hand-out is consumed by this step's check)
+    before = opt.host_gradient_steps
+    _ = opt.current_point.to_host()                                            # read-only look
+    g2 = opt.current_gradient.to_host() * 0.5
+    gd.upload(g2)                                                              # dzo_memcpy_h2d: the look goes on record
+    opt.step()
+    assert opt.host_gradient_steps == before + 1

@@ -1508,3 +1508,41 @@ def test_fused_reduce_finish_launch_gives_the_same_scalars_bit_for_bit(monkeypat
     d1, a1 = direction(1)
     assert np.array_equal(a0, a1)
     assert np.array_equal(d0, d1)
+
+
+@pytest.mark.parametrize("n", [4100, 4099])
+def test_watching_the_point_ring_through_read_costs_the_next_step_no_check(n):
+    """dzo_lbfgs_read (what `opt.current_point.to_host()` goes through): the field is copied to the host without a pointer
+    hand-out, so the step behind it does not compare the aliased arrays with the ring (a monitoring read used to
+    cost the next step a regrad, two compare passes and a host round trip).  A pointer hand-out (`.ptr`, get_ptr) still does,
+    and so does a write through the caller's own handle after a read (dzo_memcpy_* leaves the look on record)."""
+    m = 5
+    x0 = orc.rosenbrock_chain_x0(n)
+    runs = []
+    for watch in (False, True):
+        xd = dzo.DeviceArray.from_host(x0)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, xd, 1.0, m)
+        opt.step()
+        checks0 = opt.host_write_checks
+        seen = []
+        for _ in range(10):
+            opt.step()
+            if watch:
+                seen.append((opt.current_point.to_host(), opt.current_gradient.to_host(), opt.delta_point.to_host()))
+        assert opt.ring_layout == 2 and opt.host_write_checks == checks0
+        runs.append((opt.current_point.to_host(), opt.current_gradient.to_host(), opt.current_objective_value, opt.iteration_count))
+        if watch:
+            ref = orc.LBFGS(orc.Problem(orc.ROSENBROCK_CHAIN, n), x0.copy(), 1.0, m)
+            for _ in range(2):
+                ref.step()
+            assert rel(seen[0][0], ref.current_point) <= 1e-12 and np.array_equal(seen[0][1], orc.Problem(orc.ROSENBROCK_CHAIN, n).grad(seen[0][0]))
+            assert np.array_equal(xd.to_host(), runs[-1][0])          # the caller's own array IS current_point (:393)
+            _ = opt.current_point.ptr                                  # a hand-out: the host may write through it
+            opt.step()
+            assert opt.host_write_checks == checks0 + 1 and opt.ring_layout == 2
+            x = opt.current_point.to_host()                            # a read, then a write through the caller's handle
+            xd.upload((x + 1e-3 * np.cos(np.arange(n))))
+            opt.step()
+            assert opt.host_write_checks == checks0 + 2 and opt.ring_layout == (1 if n % 2 == 0 else 0)   # seen, adopted: the run continues on the pair ring (a ragged n: on the slabs)
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
