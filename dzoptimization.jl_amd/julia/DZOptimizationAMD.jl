@@ -25,7 +25,7 @@ export HipVector, LBFGSOptimizer, BFGSOptimizer, AdGDOptimizer, GradientDescentO
        RosenbrockChain, Rosenbrock2D, DenseQuadratic, LogSumExp, QuadraticChain, BuiltinProblem,
        BatchedBFGSOptimizer, count_active, LineSearchEvaluator, compute_lbfgs_step_direction!,
        update_inverse_hessian!, reset_inverse_hessian!, synchronize,
-       norm2, inv_norm, negate!, scale!, HipBackend, install_state!, ShardComm, all_done
+       norm2, inv_norm, negate!, scale!, HipBackend, install_state!, ShardComm, all_done, read_field
 
 const libdzo = get(ENV, "DZO_LIB", joinpath(@__DIR__, "..", "libdzo_hip.so"))
 
@@ -343,6 +343,17 @@ function _lb_p(o::LBFGSOptimizer{T}, w, idx=0) where {T}
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:dzo_lbfgs_get_ptr, libdzo), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}), getfield(o, :handle), w, idx, p))
     return HipVector{T}(p[], length(getfield(o, :current_point)))
+end
+"""`read_field(opt, :current_point)` (also `:delta_point`, `:current_gradient`, `:delta_gradient`, `:step_direction`): the field as
+a host `Vector{T}`, copied by the library itself (`dzo_lbfgs_read`).  No device pointer is handed out, so the step behind the read
+does not have to check the aliased arrays for host writes (src/DZOptimization.jl:393; after `opt.current_point`, which hands the
+pointer out, it does) -- the way to watch a run."""
+function read_field(o::LBFGSOptimizer{T}, s::Symbol) where {T}
+    w = findfirst(==(s), (:current_point, :delta_point, :current_gradient, :delta_gradient, :step_direction))
+    w === nothing && throw(ArgumentError("read_field: unknown field $s"))
+    out = Vector{T}(undef, length(getfield(o, :current_point)))
+    check(ccall((:dzo_lbfgs_read, libdzo), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), getfield(o, :handle), w - 1, 0, out))
+    return out
 end
 function _lb_hist(o::LBFGSOptimizer{T}, rho::Bool) where {T}   # (ccall needs a literal symbol name)
     buf = Vector{Cdouble}(undef, 64); cnt = Ref{Cint}(0)
