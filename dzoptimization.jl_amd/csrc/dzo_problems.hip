@@ -481,8 +481,8 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_kernel(int64_t n, const
 // Element i still belongs to thread (i / N) % 256 in iteration i / (256 N), the per-thread sums run over q, then over the
 // iterations, and the block sum is wave_sum + the waves in order: every value is bit for bit what quadratic_phi6_kernel
 // (and quadratic_phi_kernel, quadratic_kernel) give.  n % N == 0 only.
-template <typename T, int CG>
-__global__ __launch_bounds__(kBlock) void quadratic_phi6_cols_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
+template <typename T, int CG, int DEPTH = 2, int BPC = 1>
+__global__ __launch_bounds__(kBlock, BPC) void quadratic_phi6_cols_kernel(int64_t n, const T *__restrict__ A, const T *__restrict__ x,
                                                                      PhiDir<T> a, PhiDir<T> b,
                                                                      double *__restrict__ partials, int32_t *__restrict__ flags,
                                                                      const PhiReqDev *__restrict__ dreq) {
@@ -538,17 +538,28 @@ __global__ __launch_bounds__(kBlock) void quadratic_phi6_cols_kernel(int64_t n, 
                 }
             }
         };
-        Tile t0, t1, t2;
-        fetch(t0, 0);
-        fetch(t1, 1);
-        int it = 0;
-        for (; it + 3 <= iters; it += 3) {
-            fetch(t2, it + 2); consume(t0, it);
-            fetch(t0, it + 3); consume(t1, it + 1);
-            fetch(t1, it + 4); consume(t2, it + 2);
+        if constexpr (DEPTH == 2) {
+            Tile t0, t1, t2;
+            fetch(t0, 0);
+            fetch(t1, 1);
+            int it = 0;
+            for (; it + 3 <= iters; it += 3) {
+                fetch(t2, it + 2); consume(t0, it);
+                fetch(t0, it + 3); consume(t1, it + 1);
+                fetch(t1, it + 4); consume(t2, it + 2);
+            }
+            if (it < iters) consume(t0, it);
+            if (it + 1 < iters) consume(t1, it + 1);
+        } else {
+            Tile t0, t1;
+            fetch(t0, 0);
+            int it = 0;
+            for (; it + 2 <= iters; it += 2) {
+                fetch(t1, it + 1); consume(t0, it);
+                fetch(t0, it + 2); consume(t1, it + 1);
+            }
+            if (it < iters) consume(t0, it);
         }
-        if (it < iters) consume(t0, it);
-        if (it + 1 < iters) consume(t1, it + 1);
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
 #pragma unroll
@@ -1247,15 +1258,20 @@ bool problem_phi6_async(dzo_problem_s *p, hipStream_t s, const void *x, const Ph
         }
         if (quad_tri_on(p)) quad_tri_launch<T>(p, s, (const T *)x, d[0], d[1], flags, dreq);
         else {
-            // DZO_TUNE_PHI6_COLS: columns of A a block walks at once (1: the one-column kernel; 2, the default: 28.9 against 33.5 us
-            // per round at config 2; 4: 30.1)
+            // DZO_TUNE_PHI6_COLS: columns of A a block walks at once.  1: the one-column kernel (32.4 us per round at config 2);
+            // 2, the default: two columns, ONE set of requests ahead, 108 registers = four blocks per CU, so that the 2048 groups
+            // are two full rounds of the 1024 resident blocks (27.3 us); 22: two sets ahead, 140 registers, three blocks per CU,
+            // 2.67 rounds (28.8 us); 4: four columns, two sets ahead (30.2 us).  Forms pressed into more blocks per CU than their
+            // registers allow spill and lose everything (35-55 us).
             const int cols_knob = getenv("DZO_TUNE_PHI6_COLS") ? atoi(getenv("DZO_TUNE_PHI6_COLS")) : 2;
             constexpr int N = Vec16<T>::N;
             const int cg = (n % N != 0 || n < 64) ? 1 : cols_knob;
-            const int64_t groups = (n + (cg > 1 ? cg : 1) - 1) / (cg > 1 ? cg : 1);
+            const int cgc = cg == 22 ? 2 : (cg > 1 ? cg : 1);
+            const int64_t groups = (n + cgc - 1) / cgc;
             const int ggrid = (int)(groups < 65535 ? groups : 65535);
             if (cg == 4) hipLaunchKernelGGL((quadratic_phi6_cols_kernel<T, 4>), dim3(ggrid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1], p->scratch, flags, dreq);
-            else if (cg == 2) hipLaunchKernelGGL((quadratic_phi6_cols_kernel<T, 2>), dim3(ggrid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1], p->scratch, flags, dreq);
+            else if (cg == 2) hipLaunchKernelGGL((quadratic_phi6_cols_kernel<T, 2, 1, (sizeof(T) == 8 ? 4 : 2)>), dim3(ggrid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1], p->scratch, flags, dreq);
+            else if (cg == 22) hipLaunchKernelGGL((quadratic_phi6_cols_kernel<T, 2, 2, 1>), dim3(ggrid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1], p->scratch, flags, dreq);
             else hipLaunchKernelGGL(quadratic_phi6_kernel<T>, dim3(grid), dim3(kBlock), 0, s, n, (const T *)p->A, (const T *)x, d[0], d[1],
                                     p->scratch, flags, dreq);
         }

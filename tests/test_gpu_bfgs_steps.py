@@ -364,7 +364,7 @@ def test_dense_step_on_the_lower_triangle_of_A_matches_the_oracle(monkeypatch):
 def test_search_rounds_over_several_columns_at_once_are_the_same_bits(n, dtype, monkeypatch):
     """quadratic_phi6_cols_kernel (default: two columns of A per block, three register sets of requests in flight, every
     request unconditional) keeps the one-column kernel's assignment of elements to threads and its order of sums, so a run
-    with DZO_TUNE_PHI6_COLS = 1 / 2 / 4 is the same run bit for bit -- points, gradients (the search's by-product against a
+    with DZO_TUNE_PHI6_COLS = 1 / 2 / 22 / 4 is the same run bit for bit -- points, gradients (the search's by-product against a
     separate evaluation, run_and_test! legacy :1025-1032), step types and evaluation counts.  n = 1030 / 772: a last iteration
     that only some threads have, a last group with a column past the end."""
     rng = np.random.default_rng(7)
@@ -373,7 +373,7 @@ def test_search_rounds_over_several_columns_at_once_are_the_same_bits(n, dtype, 
     A = (0.5 * (A + A.T)).astype(dtype)
     x0 = (rng.random(n) - 0.5).astype(dtype)
     runs = []
-    for cols in ("1", "2", "4"):
+    for cols in ("1", "2", "22", "4"):
         monkeypatch.setenv("DZO_TUNE_PHI6_COLS", cols)
         prob = dzo.Problem(dzo.QUADRATIC, n, dtype=dtype, A=A)
         opt = dzo.BFGSOptimizer(prob, None, dzo.DeviceArray.from_host(x0), 1.0)
