@@ -36,7 +36,7 @@ def durs(d):
     if f:
         for r in csv.DictReader(open(f[0])): agg[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     return agg
-want = {'dense': ('tri_pass_kernel', 'tri_reduce_kernel', 'quadratic_phi6_kernel', 'bfgs_move', 'finish_phi6_advance_kernel', 'norm2_pair_begin_kernel'), 'batched': ('batch_step_kernel',),
+want = {'dense': ('tri_pass_kernel', 'tri_reduce_kernel', 'quadratic_phi6_kernel', 'quadratic_phi6_cols_kernel', 'bfgs_move', 'finish_phi6_advance_kernel', 'norm2_pair_begin_kernel'), 'batched': ('batch_step_kernel',),
         'adgd': ('adgd_fused_rosen_kernel',), 'lse': ('gram_pass_lanes_kernel', 'gram_reduce_finish_kernel', 'combine_kernel')}
 table = {}
 lines = [f'# PMC traffic and rocprofv3 kernel times of the secondary workloads ({tag})', '',
