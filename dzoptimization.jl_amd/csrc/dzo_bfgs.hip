@@ -419,22 +419,37 @@ __global__ __launch_bounds__(kBlock) void tri_pass_kernel(int64_t n, T *__restri
     }
     const double v0 = row < n ? (double)v[row] : 0.0, v1 = row < n ? (double)v[row + 1] : 0.0;
     double acc[2] = {0, 0};
-    auto issue = [&](int c0, T (&hv)[kTriUJ][2]) {
+    // INTERIOR tiles -- the whole window left of the panel's first row and the whole panel inside the matrix: 968 of the
+    // 1096 tiles at n = 4096 -- need none of the predicates below: every element is active and strictly lower.  The
+    // generic form spends some thirty instructions per load on the selects and the 64-bit address of `act ? ... : H`
+    // (1746 instructions per tile and wave: half the pass's time was instruction issue); here a column is one pointer
+    // increment away from the last.  Same operations on the same operands.
+    const bool interior = c_first + kTriCW <= (int64_t)P * kTriPH && ((int64_t)P + 1) * kTriPH <= n;
+    auto issue = [&](int c0, T (&hv)[kTriUJ][2], auto inner) {
+        constexpr bool IN = decltype(inner)::value;
+        if constexpr (IN) {
+            const T *pcol = H + (c_first + half + 2 * c0) * n + row;
 #pragma unroll
-        for (int u = 0; u < kTriUJ; ++u) {
-            const int64_t j = c_first + half + 2 * (c0 + u);
-            const bool act = c0 + u < kTriCW / 2 && j < n && row < n && row + 1 >= j;
-            tri_load2<T>(act ? H + j * n + row : H, hv[u]);
+            for (int u = 0; u < kTriUJ; ++u) { tri_load2<T>(pcol, hv[u]); pcol += 2 * n; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kTriUJ; ++u) {
+                const int64_t j = c_first + half + 2 * (c0 + u);
+                const bool act = c0 + u < kTriCW / 2 && j < n && row < n && row + 1 >= j;
+                tri_load2<T>(act ? H + j * n + row : H, hv[u]);
+            }
         }
     };
-    auto chunk = [&](int c0, const T (&hv)[kTriUJ][2]) {
+    auto chunk = [&](int c0, const T (&hv)[kTriUJ][2], auto inner) {
+        constexpr bool IN = decltype(inner)::value;
         double col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        T *pcol = H + (c_first + half + 2 * c0) * n + row;                  // (interior form only)
 #pragma unroll
         for (int u = 0; u < kTriUJ; ++u) {
             const int64_t j = c_first + half + 2 * (c0 + u);
-            const bool inw = c0 + u < kTriCW / 2 && j < n;
-            const bool act = inw && row < n && row + 1 >= j;
-            const bool lo0 = act && row >= j;                              // (row == j - 1: an upper element, left alone)
+            const bool inw = IN || (c0 + u < kTriCW / 2 && j < n);
+            const bool act = IN || (inw && row < n && row + 1 >= j);
+            const bool lo0 = IN || (act && row >= j);                      // (row == j - 1: an upper element, left alone)
             const int64_t jc = inw ? j : 0;
             const double vj = inw ? (double)v[jc] : 0.0;
             T nv[2] = {hv[u][0], hv[u][1]};
@@ -443,12 +458,13 @@ __global__ __launch_bounds__(kBlock) void tri_pass_kernel(int64_t n, T *__restri
                 nv[0] = nv[0] + (delta * (di[0] * sj) - (ti[0] * sj + di[0] * tj));   // :882-884
                 nv[1] = nv[1] + (delta * (di[1] * sj) - (ti[1] * sj + di[1] * tj));
                 if (!lo0) nv[0] = hv[u][0];
-                tri_store2<T>(act ? H + j * n + row : dummy, nv);
+                if constexpr (IN) { tri_store2<T>(pcol, nv); pcol += 2 * n; }
+                else tri_store2<T>(act ? H + j * n + row : dummy, nv);
             }
             const double h0 = lo0 ? (double)nv[0] : 0.0, h1 = act ? (double)nv[1] : 0.0;
             acc[0] = __builtin_fma(h0, vj, acc[0]);
             acc[1] = __builtin_fma(h1, vj, acc[1]);
-            const double m0 = row > j ? h0 : 0.0, m1 = row + 1 > j ? h1 : 0.0;   // strictly lower: the mirror part
+            const double m0 = (IN || row > j) ? h0 : 0.0, m1 = (IN || row + 1 > j) ? h1 : 0.0;   // strictly lower: the mirror part
             col[u] = __builtin_fma(m0, v0, col[u]);
             col[u] = __builtin_fma(m1, v1, col[u]);
         }
@@ -458,10 +474,17 @@ __global__ __launch_bounds__(kBlock) void tri_pass_kernel(int64_t n, T *__restri
     };
     {
         T hvA[kTriUJ][2], hvB[kTriUJ][2];
-        issue(0, hvA);
-        issue(kTriUJ, hvB);
-        chunk(0, hvA);
-        chunk(kTriUJ, hvB);
+        if (interior) {                                                     // (uniform)
+            issue(0, hvA, std::true_type{});
+            issue(kTriUJ, hvB, std::true_type{});
+            chunk(0, hvA, std::true_type{});
+            chunk(kTriUJ, hvB, std::true_type{});
+        } else {
+            issue(0, hvA, std::false_type{});
+            issue(kTriUJ, hvB, std::false_type{});
+            chunk(0, hvA, std::false_type{});
+            chunk(kTriUJ, hvB, std::false_type{});
+        }
     }
     // row part: the two column parities of a row pair; column part: the two waves of a parity
     if (half == 1) { rp[2 * lane_h] = acc[0]; rp[2 * lane_h + 1] = acc[1]; }
