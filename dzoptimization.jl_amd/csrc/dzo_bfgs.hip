@@ -450,7 +450,9 @@ __global__ __launch_bounds__(kBlock) void tri_pass_kernel(int64_t n, T *__restri
             const bool inw = IN || (c0 + u < kTriCW / 2 && j < n);
             const bool act = IN || (inw && row < n && row + 1 >= j);
             const bool lo0 = IN || (act && row >= j);                      // (row == j - 1: an upper element, left alone)
-            const int64_t jc = inw ? j : 0;
+            // (a column is the same for the whole wave -- `half` is: its three vector elements come through the scalar cache
+            // instead of as 48 more vector loads per thread behind the tile's own)
+            const int64_t jc = __builtin_amdgcn_readfirstlane((int)(inw ? j : 0));
             const double vj = inw ? (double)v[jc] : 0.0;
             T nv[2] = {hv[u][0], hv[u][1]};
             if constexpr (UPDATE) {
