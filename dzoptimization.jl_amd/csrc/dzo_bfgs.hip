@@ -399,7 +399,9 @@ __global__ __launch_bounds__(kBlock) void tri_pass_kernel(int64_t n, T *__restri
                                                           const T *__restrict__ dp, const T *__restrict__ tvec,
                                                           const double *__restrict__ part_ov, const double *__restrict__ part_vt,
                                                           int nparts, T lambda, T *__restrict__ dummy) {
-    const int P = blockIdx.y, W = blockIdx.x;
+    // (windows from the right: the blocks right of the diagonal leave at once, the panel's eight diagonal tiles -- the slow
+    // form -- start first and the interior ones fill in behind them, instead of the slow tiles being every panel's tail)
+    const int P = blockIdx.y, W = (int)gridDim.x - 1 - (int)blockIdx.x;
     if ((int64_t)W * kTriCW >= ((int64_t)P + 1) * kTriPH || (int64_t)W * kTriCW >= n) return;   // window right of the panel's diagonal
     __shared__ double lds[kWaves];
     __shared__ double wp[kWaves][kTriCW];
