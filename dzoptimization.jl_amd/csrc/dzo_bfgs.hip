@@ -522,7 +522,20 @@ __global__ __launch_bounds__(kBlock) void tri_reduce_kernel(int64_t n, const dou
     const int64_t np = (n + kTriPH - 1) / kTriPH;
     double a = 0;
     if (i < n) {
-        for (int64_t w = gq; w <= i / kTriCW; w += kTriRG) a += rowpart[w * n + i];
+        // (eight loads in flight, then the adds in the plain loop's order: the loop was a chain of up to sixteen dependent
+        // load-add steps, 5.4 us for 2.5 MB)
+        const int64_t wmax = i / kTriCW;
+        for (int64_t w0 = gq; w0 <= wmax; w0 += 8 * kTriRG) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t w = w0 + (int64_t)u * kTriRG;
+                t[u] = rowpart[(w <= wmax ? w : wmax) * n + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (w0 + (int64_t)u * kTriRG <= wmax) a += t[u];
+        }
         for (int64_t p = i / kTriPH + gq; p < np; p += kTriRG) a += colpart[p * n + i];
     }
     grp[gq][li] = a;
