@@ -1306,16 +1306,30 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void norm2_pair_begin_kernel(int64_t n, const T *__restrict__ a, const T *__restrict__ b,
                                                                   BfgsSearchDev *__restrict__ S, double f0, double step_length,
                                                                   int32_t dt, double sign) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     __shared__ BfgsSearchDev L;
     double sa = 0, sb = 0;
-    for (int64_t i = threadIdx.x; i < n; i += kBlock) {          // (norm2_pair_kernel's sums)
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kBlock < n; i += 8 * kBlock) {                // (norm2_pair_kernel's sums: sixteen loads in flight, then the
+        T ta[8], tb[8];                                          // fmas in the plain loop's order -- one block, latency-bound)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ta[u] = a[i + (int64_t)u * kBlock]; tb[u] = b[i + (int64_t)u * kBlock]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double va = (double)ta[u], vb = (double)tb[u];
+            sa = __builtin_fma(va, va, sa);
+            sb = __builtin_fma(vb, vb, sb);
+        }
+    }
+    for (; i < n; i += kBlock) {
         const double va = (double)a[i], vb = (double)b[i];
         sa = __builtin_fma(va, va, sa);
         sb = __builtin_fma(vb, vb, sb);
     }
-    const double ra = block_sum(sa, lds);
-    const double rb = block_sum(sb, lds);
+    const double sums[2] = {sa, sb};
+    double red[2];
+    block_sum_multi<2>(sums, lds, red);                          // (bit for bit what two block_sum calls give)
+    const double ra = red[0], rb = red[1];
     if (threadIdx.x == 0) {
         const double na = dt == DZO_F32 ? (double)sqrtf((float)ra) : sqrt(ra);
         const double nb = dt == DZO_F32 ? (double)sqrtf((float)rb) : sqrt(rb);
