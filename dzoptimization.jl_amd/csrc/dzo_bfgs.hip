@@ -1280,8 +1280,11 @@ __device__ __forceinline__ unsigned long long phi_dev_summary(const PhiDev &q, d
     const int64_t packed = (int64_t)q.want | ((int64_t)q.state << 8) | ((int64_t)(q.best_grad + 1) << 16) | ((int64_t)q.best_round << 32);
     const double v[kSumStride] = {(double)packed, q.t_best, q.f_best, q.t0, norm};
     unsigned long long seal = 0;
+    // (system-scope stores: written through to the host's memory at once, no fence needed -- the host accepts the summary
+    // only when its seal matches, wait_sealed)
+    unsigned long long *ob = reinterpret_cast<unsigned long long *>(o);
 #pragma unroll
-    for (int i = 0; i < kSumStride; ++i) { o[i] = v[i]; seal ^= seal_bits(v[i]); }
+    for (int i = 0; i < kSumStride; ++i) { __hip_atomic_store(ob + i, seal_bits(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); seal ^= seal_bits(v[i]); }
     return seal;
 }
 
@@ -1413,16 +1416,14 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const doubl
             phi_dev_post(dt, sign, q[1], R, 1);
             L.evals = evals;
         }
-        if (publish) {                                           // (the host waits for the last enqueued round only: a system-scope
+        if (publish) {                                           // (the host waits for the last enqueued round only)
             unsigned long long seal = seal_bits(ticket);         // (wait_sealed: the host checks it before it reads the summary)
-            seal ^= phi_dev_summary(q[0], L.norm[0], out + kSumBase);   // fence pair over PCIe costs more than the rest of this kernel)
+            seal ^= phi_dev_summary(q[0], L.norm[0], out + kSumBase);
             seal ^= phi_dev_summary(q[1], L.norm[1], out + kSumBase + kSumStride);
-            out[kSumBase + 2 * kSumStride] = (double)evals;
+            unsigned long long *ob = reinterpret_cast<unsigned long long *>(out);
+            __hip_atomic_store(ob + kSumBase + 2 * kSumStride, seal_bits((double)evals), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             seal ^= seal_bits((double)evals);
-            store_seal(out + kSumBase + 2 * kSumStride + 1, seal);
-            __threadfence_system();
-            out[20] = ticket;
-            __threadfence_system();
+            __hip_atomic_store(ob + kSumBase + 2 * kSumStride + 1, seal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     __syncthreads();
@@ -1480,7 +1481,6 @@ static int32_t bfgs_dev_search(dzo_bfgs_s *o, double step_length, double *grad_n
     const double *sum = o->host + kSumBase;
     for (int batch = dev_search_rounds();; batch = 1) {
         for (int i = 0; i < batch; ++i) DZO_TRY(enqueue_round(i + 1 == batch));
-        DZO_TRY(wait_ticket(s, o->host + 20, o->ticket));
         DZO_TRY(wait_sealed(s, o->host + kSumBase, 2 * kSumStride + 1, o->host + kSumBase + 2 * kSumStride + 1, o->ticket));
         if ((((int64_t)sum[0]) & 0xFF) == 0 && (((int64_t)sum[kSumStride]) & 0xFF) == 0) break;   // neither search wants another evaluation
     }
