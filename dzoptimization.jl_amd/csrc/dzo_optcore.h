@@ -153,16 +153,20 @@ __device__ __forceinline__ void decide_body(const DecideArgs &a, double *lds) {
         // outcome straight into the pinned host mirror: no D->H blit kernel on the critical path
         // (whole 64-bit words, and their seal in word 6: core_wait_decision checks it -- dzo_common.h, wait_sealed)
         const unsigned long long sw = (unsigned long long)(uint32_t)st, cw = (unsigned long long)(uint32_t)ch;
-        a.host_out[0] = f_raw;
-        a.host_out[1] = f_second;
-        a.host_out[2] = 0; a.host_out[5] = 0;                    // (core_wait_decision's seal covers words 0..5: the two this block does not use are
+        // System-scope stores (sc0 sc1: written through to the host's memory at once) and no fence: the host takes the
+        // outcome only when the six words, the ticket and the seal belong together, whatever order they arrive in.  (Until
+        // round 4 a pair of __threadfence_system() stood here: this block is the last of its kernel to finish, and the
+        // recurrence kernel of the next two-loop waits behind it.)
+        unsigned long long *ho = reinterpret_cast<unsigned long long *>(a.host_out);
+        auto put = [&](int i, unsigned long long w) { __hip_atomic_store(ho + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+        put(0, seal_bits(f_raw));
+        put(1, seal_bits(f_second));
+        put(2, 0ull); put(5, 0ull);                              // (core_wait_decision's seal covers words 0..5: the two this block does not use are
                                                                  // written too, whatever a host-driven trial's copy of result() left there)
-        reinterpret_cast<unsigned long long *>(a.host_out)[3] = sw;
-        reinterpret_cast<unsigned long long *>(a.host_out)[4] = cw;
-        store_seal(a.host_out + 6, seal_bits(f_raw) ^ seal_bits(f_second) ^ sw ^ cw ^ seal_bits(a.ticket));
-        __threadfence_system();
-        a.host_out[7] = a.ticket;                                // the host spins on this word (core_wait_decision)
-        __threadfence_system();
+        put(3, sw);
+        put(4, cw);
+        put(6, seal_bits(f_raw) ^ seal_bits(f_second) ^ sw ^ cw ^ seal_bits(a.ticket));
+        put(7, seal_bits(a.ticket));                             // the host spins on this word (core_wait_decision), then checks the seal
     }
 }
 
