@@ -192,10 +192,21 @@ __device__ __forceinline__ void adgd_publish(double *__restrict__ slot, const Ad
 // stand-alone decision kernel compute alike)
 __device__ __forceinline__ void adgd_sum_partials(const double *__restrict__ set, int grid, double *lds, double (&v)[3]) {
     double a[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < grid; i += kBlock) {
-        a[0] += set[i];
-        a[1] += set[(int64_t)kMaxPartialBlocks + i];
-        a[2] += set[2 * (int64_t)kMaxPartialBlocks + i];
+    // (every block of a pass runs this in its prologue: the twelve loads of four strides are requested together, the adds
+    // keep the plain loop's order)
+    for (int i0 = threadIdx.x; i0 < grid; i0 += 4 * kBlock) {
+        double t[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kBlock < grid ? i0 + u * kBlock : i0;
+            t[u][0] = set[i];
+            t[u][1] = set[(int64_t)kMaxPartialBlocks + i];
+            t[u][2] = set[2 * (int64_t)kMaxPartialBlocks + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * kBlock < grid) { a[0] += t[u][0]; a[1] += t[u][1]; a[2] += t[u][2]; }
+        }
     }
     block_sum_multi<3>(a, lds, v);
 }
