@@ -1385,35 +1385,48 @@ __global__ __launch_bounds__(kBlock) void finish_phi6_advance_kernel(const doubl
     }
     double sres[6];
     block_sum_multi<6>(v, lds6, sres);
+    // The two searches are independent machines (their own PhiDev, their own side of the request table): wave 0's first
+    // lane drives the one along the gradient, wave 1's the one along the BFGS direction -- side by side instead of one
+    // after the other on a single lane walking structures in LDS, which was most of this kernel's 7.7 us.
+    __shared__ double s_sum[6];
+    __shared__ int64_t s_evals[2];
     if (threadIdx.x == 0) {
-        PhiDev *q = L.q;                                         // (worked on in LDS: private copies end up in scratch memory, 4x slower)
-        PhiReqDev &R = L.req;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s_sum[r] = sres[r];
+    }
+    __syncthreads();
+    if (live && (threadIdx.x == 0 || threadIdx.x == 64)) {
+        const int r = threadIdx.x >> 6;
+        PhiDev &sm = L.q[r];                                     // (worked on in LDS: private copies end up in scratch memory, 4x slower)
+        int64_t evals = 0;
+        if (sm.active[0]) {
+            const double f3[3] = {dev_rt(dt, scale * s_sum[r * 3 + 0]), dev_rt(dt, scale * s_sum[r * 3 + 1]), dev_rt(dt, scale * s_sum[r * 3 + 2])};
+            int used = 0, slot = 0;
+            for (int turn = 0; turn < 3; ++turn) {           // (at most the three requests of this direction)
+                used |= 1 << slot;
+                const int changed = sel3(slot, hf_s[r * 9 + 0], hf_s[r * 9 + 3], hf_s[r * 9 + 6]);
+                const int nonzero = sel3(slot, hf_s[r * 9 + 1], hf_s[r * 9 + 4], hf_s[r * 9 + 7]);
+                const int differs = sel3(slot, hf_s[r * 9 + 2], hf_s[r * 9 + 5], hf_s[r * 9 + 8]);
+                phi_dev_feed(dt, max_increases, sm, sel3(slot, f3[0], f3[1], f3[2]), changed != 0, nonzero != 0, differs == 0,
+                             slot, (round % 4) * 6 + r * 3 + slot, round, evals);
+                if (!sm.want) break;
+                int next = -1;
+#pragma unroll
+                for (int e = 1; e < 3; ++e)
+                    if (sm.active[e] && !(used & (1 << e)) && sm.spec_t[e] == sm.req_t && sm.spec_ref[e] == sm.req_ref) next = e;
+                if (next < 0) break;
+                slot = next;
+            }
+        }
+        phi_dev_post(dt, sign, sm, L.req, r);
+        s_evals[r] = evals;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PhiDev *q = L.q;
         int64_t evals = L.evals;
         if (live) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                PhiDev &sm = q[r];
-                if (!sm.active[0]) continue;
-                const double f3[3] = {dev_rt(dt, scale * sres[r * 3 + 0]), dev_rt(dt, scale * sres[r * 3 + 1]), dev_rt(dt, scale * sres[r * 3 + 2])};
-                int used = 0, slot = 0;
-                for (int turn = 0; turn < 3; ++turn) {           // (at most the three requests of this direction)
-                    used |= 1 << slot;
-                    const int changed = sel3(slot, hf_s[r * 9 + 0], hf_s[r * 9 + 3], hf_s[r * 9 + 6]);
-                    const int nonzero = sel3(slot, hf_s[r * 9 + 1], hf_s[r * 9 + 4], hf_s[r * 9 + 7]);
-                    const int differs = sel3(slot, hf_s[r * 9 + 2], hf_s[r * 9 + 5], hf_s[r * 9 + 8]);
-                    phi_dev_feed(dt, max_increases, sm, sel3(slot, f3[0], f3[1], f3[2]), changed != 0, nonzero != 0, differs == 0,
-                                 slot, (round % 4) * 6 + r * 3 + slot, round, evals);
-                    if (!sm.want) break;
-                    int next = -1;
-#pragma unroll
-                    for (int e = 1; e < 3; ++e)
-                        if (sm.active[e] && !(used & (1 << e)) && sm.spec_t[e] == sm.req_t && sm.spec_ref[e] == sm.req_ref) next = e;
-                    if (next < 0) break;
-                    slot = next;
-                }
-            }
-            phi_dev_post(dt, sign, q[0], R, 0);
-            phi_dev_post(dt, sign, q[1], R, 1);
+            evals += s_evals[0] + s_evals[1];
             L.evals = evals;
         }
         if (publish) {                                           // (the host waits for the last enqueued round only)
