@@ -142,6 +142,15 @@ def calibrate_read_bandwidth(nbytes, repeats=20):
     return r.value
 
 
+def selftest_fast_div(seed, pairs, mode):
+    """(checked, mismatches, first) of ``dzo_selftest_fast_div``: the recurrence's division-free quotient against ``a / b``."""
+    _need_init()
+    chk, bad = C.c_int64(), C.c_int64()
+    first = (C.c_double * 4)()
+    _check(lib().dzo_selftest_fast_div(int(seed), int(pairs), int(mode), C.byref(chk), C.byref(bad), first))
+    return chk.value, bad.value, list(first)
+
+
 def calibrate_read_bandwidth_of(array, repeats=20):
     """GB/s of the same streaming read over the bytes of a DeviceArray, whatever it holds."""
     _need_init()
@@ -165,6 +174,7 @@ ABI = {
     "dzo_profile_enable": [_i32], "dzo_profile_reset": [], "dzo_unsealed_first_reads": [_P(_i64)], "dzo_profile_count": [_P(_i32)],
     "dzo_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_dbl)],
     "dzo_calibrate_read_bandwidth": [_i64, _i32, _P(_dbl)],
+    "dzo_selftest_fast_div": [C.c_uint64, _i64, _i32, _P(_i64), _P(_i64), _P(_dbl)],
     "dzo_calibrate_read_bandwidth_of": [_vp, _i64, _i32, _P(_dbl)],
     "dzo_malloc": [_P(_vp), _i64], "dzo_free": [_vp], "dzo_memcpy_h2d": [_vp, _vp, _i64],
     "dzo_memcpy_d2h": [_vp, _vp, _i64], "dzo_memcpy_d2d": [_vp, _vp, _i64],

@@ -439,6 +439,7 @@ struct GramFinishParams {
     double *Gyy, *Gsy;
     double *sg, *yg;
     double *alpha, *coef, *scale;
+    int fast_div;               // the recurrence's quotients by fd_div (DZO_TUNE_FAST_DIV, default 1; 0: every one an IEEE division)
 };
 
 // Second stage of the Gram pass: one block per value sums that value's per-block partials in
@@ -485,6 +486,26 @@ __global__ __launch_bounds__(kBlock) void gram_reduce_decide_kernel(const double
     gram_reduce_body(partials, grid, vals, nvals, nullptr, 0, nullptr, 0, lds);
 }
 // (1) refresh of the pivot row/column of the slot-indexed Gram caches from the reduced values,
+// a / b without the division's instruction chain, for the dependent quotients of the recurrence below (2k of them per
+// two-loop, ~200 cycles each as the compiler expands an IEEE division: more than half of gram_finish_kernel's time).
+// y = RN(1 / b) is formed once per lane, off the chain, by a real division.  Then q0 = RN(a y) is within two ulps of
+// a / b; r0 = RN(a - q0 b), q1 = RN(q0 + r0 y) is a faithful rounding; r1 = a - q1 b is exact (fma) and
+// q2 = RN(q1 + r1 y) is the correctly rounded quotient (Markstein's theorem: y correctly rounded, q1 faithful) -- the
+// value `a / b` has, bit for bit, whenever nothing under- or overflows on the way.  fd_mid() keeps the operands in
+// the middle of the exponent range (zeros, subnormals, infinities and NaNs excluded with it); anything else takes the
+// division.  dzo_selftest_fast_div compares the two on the device over as many operand pairs as the caller likes.
+__device__ __forceinline__ bool fd_mid(double v) {
+    const int e = (int)((__double_as_longlong(v) >> 52) & 0x7ff);
+    return e > 1023 - 500 && e < 1023 + 500;
+}
+__device__ __forceinline__ double fd_div(double a, double b, double y) {
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-q0, b, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-q1, b, a);
+    return __builtin_fma(r1, y, q1);
+}
+
 // (2) the two-loop recursion on SCALARS by one wave, lane i owning pair i:
 //     s_i.q_i = s_i.g - sum_{j<i} alpha_j (s_i.y_j)                     (:440)
 //     y_i.r_i = scale*(y_i.g - sum_j alpha_j y_i.y_j) - sum_{l>i} c_l (s_l.y_i)   (:447)
@@ -534,13 +555,16 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     // current one, so the LDS round trip runs under the division instead of in front of it.  Same operations on the same
     // operands in the same order -- the scalars are bit for bit what the plain loops gave.
     const int row = on ? lane : 0;                                 // (lanes beyond k read row 0 and use nothing)
+    const double y_i = 1.0 / rho_i;                                // (for fd_div: one real division per lane, off the chains)
+    const bool fd_b = p.fast_div != 0 && fd_mid(rho_i) && fd_mid(y_i);
     double acc = on ? vals[lane * kGramValues + 0] : 0.0;          // s_i.g
     double alpha_i = 0;
     double nxt = sy[row * ld + 0];
     for (int j = 0; j < k; ++j) {                                  // :439 newest -> oldest
         const double syj = nxt;
         if (j + 1 < k) nxt = sy[row * ld + j + 1];
-        const double cand = acc / rho_i;                           // :440 (lane j's value counts)
+        double cand = fd_div(acc, rho_i, y_i);                     // :440 acc / rho_i (lane j's value counts: ...
+        if (lane == j && !(fd_b && fd_mid(acc))) cand = acc / rho_i;   // ... the division itself when ITS operands are unusual)
         const double aj = readlane_f64(cand, j);                    // (uniform j: v_readlane, no LDS round trip)
         if (lane == j) alpha_i = cand;
         if (on && lane > j) acc = __builtin_fma(-aj, syj, acc);
@@ -563,7 +587,9 @@ __device__ __forceinline__ void gram_finish_body(const GramFinishParams &p, doub
     for (int l = k - 1; l >= 0; --l) {                             // :446 oldest -> newest
         const double syl = nxt;
         if (l > 0) nxt = sy[(l - 1) * ld + row];
-        const double cand = alpha_i + acc / rho_i;                 // :447-448
+        double quo = fd_div(acc, rho_i, y_i);                      // :447-448 alpha_i + acc / rho_i (lane l's value counts)
+        if (lane == l && !(fd_b && fd_mid(acc))) quo = acc / rho_i;
+        const double cand = alpha_i + quo;
         const double cl = readlane_f64(cand, l);
         if (lane == l) c_i = cand;
         if (on && lane < l) acc = __builtin_fma(-cl, syl, acc);
@@ -2358,6 +2384,7 @@ static GramFinishParams gram_finish_params(dzo_lbfgs_s *o, int pivot, bool recur
     fp.Gyy = o->Gyy; fp.Gsy = o->Gsy; fp.sg = o->sg; fp.yg = o->yg;
     fp.alpha = o->alpha; fp.coef = o->coef; fp.scale = o->scale;
     if (gate) { fp.alpha = o->alpha_sp; fp.coef = o->coef_sp; fp.scale = o->scale_sp; }   // next step's set
+    fp.fast_div = tune("DZO_TUNE_FAST_DIV", 1) != 0 ? 1 : 0;
     return fp;
 }
 
@@ -4410,5 +4437,83 @@ extern "C" int32_t dzo_debug_wave_times(unsigned long long *out_host, int32_t co
     DZO_HIP(hipDeviceSynchronize());
     DZO_REQUIRE(out_host && count > 0 && count <= 1024 * 4 * 2, DZO_ERR_INVALID, "count out of range");
     DZO_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(dzo::g_dev_wave_times), sizeof(unsigned long long) * (size_t)count));
+    return DZO_OK;
+}
+
+// ---------------------------------------------------------------------------- self-test of fd_div (see there)
+namespace dzo {
+__device__ __forceinline__ uint64_t fd_mix(uint64_t z) {       // splitmix64
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double fd_make(uint64_t bits, int exp_span) {   // a double with the given significand bits and a mid-range exponent
+    const uint64_t mant = bits & 0xfffffffffffffull;
+    const int e = 1023 - exp_span + (int)((bits >> 52) % (uint64_t)(2 * exp_span + 1));
+    const uint64_t sign = (bits >> 63) << 63;
+    return __longlong_as_double((long long)(sign | ((uint64_t)e << 52) | mant));
+}
+// mode 0: random a, b.  1: b with a special significand (all ones, all zeros, one bit), random a.  2: a = RN(q b) for a
+// random q (quotients that are exact or one rounding away from exact).  3: a = RN((q + half an ulp) b): quotients next to
+// a rounding boundary.  4: small integers.  Counts the pairs whose fd_div differs from a / b in any bit.
+__global__ __launch_bounds__(kBlock) void fd_selftest_kernel(uint64_t seed, int64_t per_thread, int mode, unsigned long long *mismatches,
+                                                             unsigned long long *checked, double *first) {
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long bad = 0, seen = 0;
+    for (int64_t it = 0; it < per_thread; ++it) {
+        const uint64_t r0 = fd_mix(seed + tid * 0x100000001b3ull + (uint64_t)it * 0x9e3779b97f4a7c15ull);
+        const uint64_t r1 = fd_mix(r0), r2 = fd_mix(r1);
+        double a = fd_make(r0, 400), b = fd_make(r1, 400);
+        if (mode == 1) {
+            const int pick = (int)(r2 % 6);
+            uint64_t mant = pick == 0 ? 0xfffffffffffffull : pick == 1 ? 0ull : pick == 2 ? 1ull : pick == 3 ? 0xffffffffffffeull
+                          : pick == 4 ? (1ull << (r2 >> 8) % 52) : 0x8000000000000ull;
+            b = fd_make((r1 & ~0xfffffffffffffull) | mant, 400);
+        } else if (mode == 2 || mode == 3) {
+            const double q = fd_make(r2, 50);
+            b = fd_make(r1, 100);
+            double qq = q;
+            if (mode == 3) qq = __longlong_as_double(__double_as_longlong(q)) ;   // (the half ulp comes from the product's own rounding below)
+            a = qq * b;                                                           // RN(q b): a / b is q or next to a boundary around q
+            if (mode == 3) a = __builtin_fma(qq, b, 0.5 * (__longlong_as_double(__double_as_longlong(qq) + 1) - qq) * b);
+        } else if (mode == 4) {
+            a = (double)(int64_t)(r0 % 100000) - 50000.0;
+            b = (double)(int64_t)(r1 % 4096 + 1);
+        }
+        if (b == 0.0) continue;
+        const double y = 1.0 / b;
+        if (!(fd_mid(a) && fd_mid(b) && fd_mid(y))) continue;
+        const double want = a / b, got = fd_div(a, b, y);
+        seen += 1;
+        if (__double_as_longlong(want) != __double_as_longlong(got)) {
+            if (bad == 0 && atomicAdd(mismatches, 0ull) == 0) { first[0] = a; first[1] = b; first[2] = want; first[3] = got; }
+            bad += 1;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    atomicAdd(checked, seen);
+}
+}  // namespace dzo
+
+extern "C" int32_t dzo_selftest_fast_div(uint64_t seed, int64_t pairs, int32_t mode, int64_t *checked, int64_t *mismatches, double *first4) {
+    DZO_TRY(require_init());
+    DZO_REQUIRE(checked && mismatches && pairs >= 1 && mode >= 0 && mode <= 4, DZO_ERR_INVALID, "bad argument");
+    unsigned long long *dev = nullptr;
+    double *first = nullptr;
+    DZO_HIP(hipMalloc((void **)&dev, 2 * sizeof(unsigned long long)));
+    DZO_HIP(hipMalloc((void **)&first, 4 * sizeof(double)));
+    DZO_HIP(hipMemset(dev, 0, 2 * sizeof(unsigned long long)));
+    DZO_HIP(hipMemset(first, 0, 4 * sizeof(double)));
+    const int grid = ctx().cus * 8;
+    const int64_t per_thread = (pairs + (int64_t)grid * kBlock - 1) / ((int64_t)grid * kBlock);
+    hipLaunchKernelGGL(fd_selftest_kernel, dim3(grid), dim3(kBlock), 0, ctx().stream, seed, per_thread, mode, dev, dev + 1, first);
+    DZO_HIP(hipGetLastError());
+    DZO_HIP(hipStreamSynchronize(ctx().stream));
+    unsigned long long host[2] = {0, 0};
+    DZO_HIP(hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost));
+    if (first4) DZO_HIP(hipMemcpy(first4, first, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dev); (void)hipFree(first);
+    *mismatches = (int64_t)host[0]; *checked = (int64_t)host[1];
     return DZO_OK;
 }

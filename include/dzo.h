@@ -122,6 +122,10 @@ int32_t dzo_unsealed_first_reads(int64_t *count);
 /* Calibration (SURVEY.md 8(d) "calibrate on the box"): GB/s of a plain read-only streaming kernel over
  * `bytes` of device memory re-read `repeats` times.  <= ~200 MiB stays in the Infinity Cache (the ceiling of
  * config 2, H = 128 MiB); several GiB give the HBM streaming ceiling. */
+/* Self-test: the quotient the L-BFGS recurrence forms without a division (fd_div, csrc/dzo_lbfgs.hip) against a / b on the
+ * device, `pairs` operand pairs of kind `mode` (0 random, 1 special divisors, 2 exact-ish quotients, 3 quotients next to a
+ * rounding boundary, 4 small integers); *mismatches must come back 0.  first4: a, b, a / b, fd_div of the first mismatch. */
+int32_t dzo_selftest_fast_div(uint64_t seed, int64_t pairs, int32_t mode, int64_t *checked, int64_t *mismatches, double *first4);
 int32_t dzo_calibrate_read_bandwidth(int64_t bytes, int32_t repeats, double *gbps);
 /* the same reader over a device buffer of the caller's, whatever it holds */
 int32_t dzo_calibrate_read_bandwidth_of(const void *buf_dev, int64_t bytes, int32_t repeats, double *gbps);

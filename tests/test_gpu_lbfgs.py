@@ -1546,3 +1546,32 @@ def test_watching_the_point_ring_through_read_costs_the_next_step_no_check(n):
             assert opt.host_write_checks == checks0 + 2 and opt.ring_layout == (1 if n % 2 == 0 else 0)   # seen, adopted: the run continues on the pair ring (a ragged n: on the slabs)
     a, b = runs
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_the_recurrences_division_free_quotient_is_the_quotient(mode):
+    """gram_finish's 2k dependent quotients (src/DZOptimization.jl:440, :447) are formed from a correctly rounded reciprocal
+    and four fused multiply-adds (fd_div: Markstein's final step behind one refinement) instead of an IEEE division each.
+    The claim is bit equality with `a / b` for operands in the middle of the exponent range (everything else takes the
+    division): checked here on the device over 2^27 operand pairs per kind -- random, special divisors (significand all
+    ones / all zeros / one bit), quotients that are exact or one rounding from exact, quotients next to a rounding boundary,
+    small integers."""
+    checked, bad, first = dzo.selftest_fast_div(1234 + mode, 1 << 27, mode)
+    assert checked > (1 << 26) and bad == 0, (mode, checked, bad, first)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fast_division_knob_changes_no_bit(dtype, monkeypatch):
+    """DZO_TUNE_FAST_DIV=0 puts the IEEE divisions back into the recurrence: same alpha / coef / scale, same run."""
+    n, m = 4100 if dtype == np.float64 else 8200, 7
+    x0 = orc.rosenbrock_chain_x0(n, dtype)
+    runs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("DZO_TUNE_FAST_DIV", knob)
+        opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n, dtype), None, dzo.DeviceArray.from_host(x0), 1.0, m)
+        trace = []
+        for _ in range(25):
+            opt.step()
+            trace.append((opt.current_objective_value, opt.last_trials, tuple(opt.alpha_history), tuple(opt.rho_history)))
+        runs.append((trace, opt.current_point.to_host()))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
