@@ -881,7 +881,8 @@ def main():
                     help="HIP events in the timed region: 1 = the two-loop (roofline) kernels only, 2 = every kernel")
     ap.add_argument("--event-sample", type=int, default=1,
                     help="lbfgs: bracket the roofline kernel's launches with HIP events in every Nth step of the timed region only (a "
-                         "bracket costs a few us of stream time; measured in round 4: 2552 / 2562 / 2584 step!()/s with every 5th step, every step, no step bracketed -- within the run-to-run noise, so the default stays every step)")
+                         "bracket costs about 8 us of stream time; measured in round 4, five interleaved runs on one box: 2531 step!()/s with every step "
+                         "bracketed, 2565 with every 4th, i.e. +1.4 %; the default stays every step -- every launch of the timed region is then in the average)")
     ap.add_argument("--workload", default="lbfgs", choices=["lbfgs", "bfgs_dense", "bfgs_batched", "lbfgs_lse_f32", "adgd", "launch_check"],
                     help="lbfgs = BASELINE configs[2] (the headline; default). The others are the remaining "
                          "BASELINE configs, reported as secondary lines.")
