@@ -609,6 +609,14 @@ function Base.getproperty(o::AdGDOptimizer{T,A,C,F,G}, s::Symbol) where {T,A,C,F
     return getfield(o, s)
 end
 
+function read_field(o::AdGDOptimizer{T}, s::Symbol) where {T}       # (dzo_adgd_read: the same, for AdGD's four vector fields)
+    w = findfirst(==(s), (:current_point, :delta_point, :current_gradient, :delta_gradient))
+    w === nothing && throw(ArgumentError("read_field: unknown field $s"))
+    out = Vector{T}(undef, length(getfield(o, :current_point)))
+    check(ccall((:dzo_adgd_read, libdzo), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), getfield(o, :handle), w - 1, out))
+    return out
+end
+
 ################################################################################ batched dense BFGS
 
 """`BatchedBFGSOptimizer(kind, x0, n, initial_step_length)`: `length(x0) / n` independent `BFGSOptimizer`s
