@@ -705,7 +705,7 @@ int32_t dzo_adgd_create(int64_t n, int32_t dtype, void *x_dev, void *g_dev, doub
     if (hipMalloc(&o->dx_buf, bytes) != hipSuccess || hipMalloc(&o->dg_buf, bytes) != hipSuccess) {
         dzo_adgd_destroy(o);
         set_error("out of device memory allocating AdGD state");
-        return DZO_ERR_NOMEM;
+        (void)hipGetLastError(); return DZO_ERR_NOMEM;
     }
     DZO_HIP(hipMemsetAsync(o->dx_buf, 0, bytes, c.stream));        // :219-222
     DZO_HIP(hipMemsetAsync(o->dg_buf, 0, bytes, c.stream));        // :224-227

@@ -709,7 +709,7 @@ static int32_t batch_create_impl(const BatchObjective &ob, int64_t batch, int64_
     if (e != hipSuccess) {
         dzo_bfgs_batch_destroy(b);
         set_error("out of device memory for %lld instances of %lld x %lld", (long long)batch, (long long)n, (long long)n);
-        return DZO_ERR_NOMEM;
+        (void)hipGetLastError(); return DZO_ERR_NOMEM;
     }
     DZO_HIP(hipHostMalloc((void **)&b->count_host, sizeof(unsigned long long), hipHostMallocDefault));
     DZO_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));

@@ -1639,14 +1639,14 @@ static int32_t bfgs_alloc(dzo_bfgs_s *o) {
                      &o->spec_buf[0], &o->spec_buf[1], &o->spec_buf[2], &o->spec_buf[3]};
     for (void **v : vecs) {
         hipError_t e = hipMalloc(v, vbytes);
-        if (e != hipSuccess) { set_error("out of device memory allocating BFGS vectors"); return DZO_ERR_NOMEM; }
+        if (e != hipSuccess) { set_error("out of device memory allocating BFGS vectors"); (void)hipGetLastError(); return DZO_ERR_NOMEM; }
         DZO_HIP(hipMemset(*v, 0, vbytes));                      // :777-778 zero deltas
     }
     if (!o->no_hessian) {
         hipError_t e = hipMalloc(&o->H, (size_t)o->n * (size_t)o->n * es);
         if (e != hipSuccess) {
             set_error("out of device memory allocating the %lld x %lld inverse Hessian", (long long)o->n, (long long)o->n);
-            return DZO_ERR_NOMEM;
+            (void)hipGetLastError(); return DZO_ERR_NOMEM;
         }
     }
     {

@@ -21,6 +21,7 @@ void set_error(const char *fmt, ...) {
 
 int32_t hip_fail(hipError_t e, const char *what, const char *file, int line) {
     set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();    // (reported once: the runtime keeps the last error until somebody asks, and a later, unrelated hipGetLastError() check would report it again)
     return DZO_ERR_HIP;
 }
 
@@ -400,7 +401,7 @@ int32_t dzo_malloc(void **ptr_dev, int64_t bytes) {
     hipError_t e = hipMalloc(ptr_dev, (size_t)(bytes > 0 ? bytes : 16));
     if (e == hipErrorOutOfMemory) {
         set_error("hipMalloc(%lld bytes): out of device memory", (long long)bytes);
-        return DZO_ERR_NOMEM;
+        (void)hipGetLastError(); return DZO_ERR_NOMEM;
     }
     DZO_HIP(e);
     return DZO_OK;

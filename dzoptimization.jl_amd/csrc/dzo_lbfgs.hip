@@ -2830,7 +2830,7 @@ static int32_t lbfgs_unblock(dzo_lbfgs_s *o) {
     const size_t slab = (size_t)m1 * (size_t)o->stride * es;
     void *ring = nullptr;
     hipError_t e = hipMalloc(&ring, 2 * slab);
-    if (e != hipSuccess) { set_error("out of device memory converting the history ring (%zu bytes)", 2 * slab); return DZO_ERR_NOMEM; }
+    if (e != hipSuccess) { set_error("out of device memory converting the history ring (%zu bytes)", 2 * slab); (void)hipGetLastError(); return DZO_ERR_NOMEM; }
     DZO_HIP(hipMemsetAsync(ring, 0, 2 * slab, c.stream));
     void *Yb = (char *)ring + (size_t)o->stride * es;
     const int64_t ps = 2 * o->stride;
@@ -3899,7 +3899,7 @@ int32_t dzo_lbfgs_create(int64_t n, int32_t history_length, int32_t dtype, void 
     hipError_t e;
 #define ALLOC(ptr, bytes)                                                                          \
     e = hipMalloc((void **)&(ptr), (bytes));                                                       \
-    if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    if (e != hipSuccess) { dzo_lbfgs_destroy(o); if (e == hipErrorOutOfMemory) { set_error("out of device memory allocating the L-BFGS state (%zu bytes)", (size_t)(bytes)); (void)hipGetLastError(); return DZO_ERR_NOMEM; } return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     o->interleaved = tune("DZO_TUNE_INTERLEAVE", 1) != 0;
     if (o->blocked) {
         const int64_t nvec = (n + 16 / (int64_t)es - 1) / (16 / (int64_t)es);
@@ -4293,7 +4293,7 @@ static int32_t lbfgs_field_ptr(dzo_lbfgs_t o, int32_t what, int32_t idx, bool ha
         const size_t vb = (size_t)o->stride * dtype_size(o->core.dtype);
         if (!o->export_slab) {
             hipError_t e = hipMalloc(&o->export_slab, 2 * (size_t)o->m * vb);
-            if (e != hipSuccess) { set_error("out of device memory for the contiguous copies of the history (%zu bytes)", 2 * (size_t)o->m * vb); return DZO_ERR_NOMEM; }
+            if (e != hipSuccess) { set_error("out of device memory for the contiguous copies of the history (%zu bytes)", 2 * (size_t)o->m * vb); (void)hipGetLastError(); return DZO_ERR_NOMEM; }
         }
         void *dst = (char *)o->export_slab + ((what == 5 ? 0 : (size_t)o->m) + (size_t)idx) * vb;
         const void *src = what == 5 ? o->s_slot_v(o->slot_of(idx)) : o->y_slot_v(o->slot_of(idx));

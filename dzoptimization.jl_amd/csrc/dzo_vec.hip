@@ -401,7 +401,7 @@ int32_t dzo_calibrate_read_bandwidth(int64_t bytes, int32_t repeats, double *gbp
     void *buf = nullptr;
     double *sink = nullptr;
     hipError_t e = hipMalloc(&buf, (size_t)bytes);
-    if (e != hipSuccess) { set_error("out of device memory for a %lld-byte calibration buffer", (long long)bytes); return DZO_ERR_NOMEM; }
+    if (e != hipSuccess) { set_error("out of device memory for a %lld-byte calibration buffer", (long long)bytes); (void)hipGetLastError(); return DZO_ERR_NOMEM; }
     DZO_HIP(hipMalloc((void **)&sink, sizeof(double) * 4096));
     hipStream_t s = ctx().stream;
     DZO_HIP(hipMemsetAsync(buf, 0, (size_t)bytes, s));

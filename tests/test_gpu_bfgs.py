@@ -639,3 +639,17 @@ def test_adgd_watched_through_read_is_the_same_run():
     gd.upload(g2)                                                              # dzo_memcpy_h2d: the look goes on record
     opt.step()
     assert opt.host_gradient_steps == before + 1
+
+
+def test_a_failed_allocation_does_not_poison_later_calls():
+    """hipMalloc leaves its error with the runtime until somebody calls hipGetLastError(): an out-of-memory dzo_malloc used to
+    come back as a spurious 'HIP error 2 (out of memory)' from the next unrelated launch check (found by tools/soak.py's
+    memory probe).  Every out-of-memory return of the library clears it now."""
+    with pytest.raises(dzo.DzoError):
+        dzo.DeviceArray(1 << 46)                                            # 512 TiB
+    n = 4100
+    x0 = orc.rosenbrock_chain_x0(n)
+    opt = dzo.LBFGSOptimizer(None, dzo.Problem(dzo.ROSENBROCK_CHAIN, n), None, dzo.DeviceArray.from_host(x0), 1.0, 5)
+    for _ in range(3):
+        opt.step()
+    assert np.isfinite(opt.current_objective_value)
