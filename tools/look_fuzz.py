@@ -26,7 +26,7 @@ for case in range(cases):
     for s in range(steps):
         b.step()
         for _ in range(int(rng.integers(0, 3))):
-            act = int(rng.integers(7))
+            act = int(rng.integers(10 if kind == "lbfgs" else 7))
             if act == 0: b.current_point.to_host()
             elif act == 1: b.current_gradient.to_host()
             elif act == 2: b.delta_point.to_host(); b.delta_gradient.to_host()
@@ -34,6 +34,9 @@ for case in range(cases):
             elif act == 4: dzo.synchronize()
             elif act == 5: xd.upload(b.current_point.to_host())                     # the same values through the caller's handle
             elif act == 6: b.current_gradient.upload(b.current_gradient.to_host())
+            elif act == 7: b.step_direction.to_host()
+            elif act == 8: [h.to_host() for h in b.delta_point_history[:2]]; [h.to_host() for h in b.delta_gradient_history[:2]]
+            elif act == 9: _ = (b.rho_history, b.alpha_history)
     got = (b.current_point.to_host(), b.current_gradient.to_host(), b.current_objective_value, b.iteration_count, b.is_stuck)
     ok = np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]) and want[2:] == got[2:]
     if kind == "lbfgs" and not ok:
