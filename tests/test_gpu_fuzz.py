@@ -73,3 +73,9 @@ def test_regression_case_of_the_round_3_memory_fault():
         if mode == 1:
             assert layouts[:2] == [2, 1] and set(layouts[1:]) == {1}      # points at step 0, pairs from step 1 on: where it faulted
         opt.close(); ref.close()
+
+
+def test_fuzz_looks_between_steps_change_nothing():
+    import fuzz_looks
+    out = fuzz_looks.run(cases=60, seed=1357)
+    assert out["cases"] == 60
